@@ -1,0 +1,179 @@
+/*
+ * photoverse_hip.h - C-ABI of libphotoverse_hip.so, the MI355X (gfx950) kernels behind the
+ * PhotoVerse denoising hot path.
+ *
+ * The reference (idonahum/photoVerse) is pure Python on top of diffusers and has no FFI of
+ * its own.  Its "operators" for this path are the vendor kernels the
+ * eager PyTorch graph dispatches to.  Each entry point below replaces one family of those
+ * dispatches; the call site in the reference that reaches it is cited per function.  The
+ * Python host layer (photoverse_amd/) binds these with ctypes and mirrors the reference's
+ * Python interfaces (attention-processor protocol, UNet call, run_inference).
+ *
+ * Conventions
+ *   - plain C, raw device pointers, caller-owned outputs and workspace;
+ *   - no allocation, no host synchronisation, safe under HIP stream capture;
+ *   - every launcher returns a hipError_t value as int (0 = success) and enqueues on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - activations are NHWC / token-major fp16: a (B,C,H,W) tensor of the reference is stored
+ *     as rows [B*H*W][C] with an explicit row stride `ld*` in elements;
+ *   - GEMM weights are fp16 [N][K] (torch Linear layout); 3x3 conv weights are repacked to
+ *     [Cout][ky][kx][Cin];  biases / norm affine parameters are fp32.
+ */
+#ifndef PHOTOVERSE_HIP_H
+#define PHOTOVERSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_ABI_VERSION 1
+
+enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
+
+int pv_abi_version(void);
+/* number of HIP devices visible, or -1 on runtime error; never initialises a context */
+int pv_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * pv_gemm_conv: out[M][N] = epilogue( A[M][K] * W[N][K]^T ), MFMA f16 -> f32 accumulate.
+ *   taps == 1 : Linear / 1x1 conv.  Replaces nn.Linear / Conv2d(k=1) dispatches of
+ *               attention_processor.py:297,304-305,392-393,423 (to_q/to_k/to_v/to_k_ip/
+ *               to_v_ip/to_out), adapters.py:14-28, and the [EXT] diffusers proj_in/proj_out/
+ *               GEGLU/FF/time-embedding/conv_shortcut layers reached from infer.py:103-114.
+ *   taps == 9 : implicit-GEMM 3x3 conv, padding 1, stride 1|2, optional nearest x2 upsample
+ *               folded into the gather (ResnetBlock2D conv1/conv2, Downsample2D, Upsample2D).
+ *   A may come from two tensors concatenated along channels (skip connections): channels
+ *   [0,c0) from a0 and [c0,c0+c1) from a1; c0, c1 multiples of 64.
+ *   epilogue: (+bias[n]) (+rowadd[img][n]) act (+residual[m][n]) -> fp16 (or fp32) store.
+ *   Requirements: N % 128 == 0 or N % 160 == 0; (c0+c1) % 64 == 0; pointers 16-byte aligned.
+ */
+typedef struct pv_gemm_params {
+    const void* a0;        /* fp16 */
+    const void* a1;        /* fp16 or NULL */
+    int32_t c0, c1;        /* channels taken from a0 / a1 */
+    int32_t lda0, lda1;    /* row strides in elements */
+    const void* w;         /* fp16 [N][taps*(c0+c1)] */
+    const float* bias;     /* [N] or NULL */
+    const float* rowadd;   /* fp32 [images][rowadd_ld] added per image (time embedding) or NULL */
+    int32_t rowadd_ld;     /* 0 => one row shared by all images */
+    const void* residual;  /* fp16 [M][ldr] or NULL */
+    int32_t ldr;
+    void* out;             /* fp16 [M][ldc] (fp32 when out_f32) */
+    int32_t ldc;
+    int32_t M, N;
+    int32_t taps;          /* 1 or 9 */
+    int32_t batch, hin, win, hout, wout; /* taps==9 geometry; taps==1: hout*wout = rows per image */
+    int32_t stride;        /* 1 or 2 */
+    int32_t upsample;      /* 1 => logical input is the x2 nearest upsample of (hin,win) */
+    int32_t act;           /* enum pv_act */
+    int32_t out_f32;
+    int32_t geglu;         /* 1 => W rows are tile-interleaved (value|gate); out[M][N/2] = value*gelu(gate) */
+    const void* zero_page; /* >= 256 bytes of zeros (padding taps / M tail) */
+} pv_gemm_params;
+int pv_gemm_conv(const pv_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) over NHWC fp16, optionally over a channel concat of two tensors.
+ * Replaces F.group_norm (+ SiLU) dispatches of [EXT] ResnetBlock2D.norm1/norm2,
+ * Transformer2DModel.norm, conv_norm_out.
+ *   pv_groupnorm_stats : partial (sum, sumsq) per (image, split, group) -> partial[B][S][G][2]
+ *   pv_groupnorm_apply : y = act(gamma*(x-mean)*rstd+beta), contiguous fp16 [B*HW][C]
+ */
+typedef struct pv_groupnorm_params {
+    const void* x0; const void* x1;  /* fp16 sources; x1 may be NULL */
+    int32_t c0, c1, ld0, ld1;
+    int32_t batch, hw, groups;
+    int32_t splits;                  /* S: pixel splits per image */
+    float* partial;                  /* [B][S][G][2] fp32 workspace */
+    const float* gamma; const float* beta;
+    float eps;
+    int32_t act;                     /* PV_ACT_NONE or PV_ACT_SILU */
+    void* y;                         /* fp16 [B*HW][c0+c1] */
+} pv_groupnorm_params;
+int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream);
+int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream);
+
+/* LayerNorm over the last dim of fp16 rows (BasicTransformerBlock.norm1-3, CLIP layer norms,
+ * adapters.py:15,18 with LeakyReLU fused).  y = act(gamma*(x-mean)*rstd+beta) */
+typedef struct pv_layernorm_params {
+    const void* x; int32_t ldx;
+    void* y; int32_t ldy;
+    const float* gamma; const float* beta;
+    int32_t rows, cols;              /* cols % 8 == 0, cols <= 4096 */
+    float eps;
+    int32_t act;
+} pv_layernorm_params;
+int pv_layernorm(const pv_layernorm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash-style self attention (stock AttnProcessor2_0 on attn1, unet.py:20-24; CLIP encoder
+ * self-attention).  q,k,v are column slices of one fp16 buffer (fused QKV GEMM output):
+ * head h uses columns [h*d,(h+1)*d) of each.  softmax scale = 1/sqrt(d).  d in {40,64,80,160}.
+ */
+typedef struct pv_attn_params {
+    const void* q; const void* k; const void* v;
+    int32_t ldq, ldk, ldv;
+    void* out; int32_t ldo;
+    int32_t batch, heads, nq, nk, d;
+    int32_t causal;
+} pv_attn_params;
+int pv_attention(const pv_attn_params* p, void* stream);
+
+/* Fused dual-branch cross attention = the SDPA part of PhotoVerseAttnProcessor2_0.__call__
+ * (attention_processor.py:307-322 text branch, :392-420 image-token branch and fusion):
+ *   out = w_text * softmax(q Kt^T / sqrt(d)) Vt  +  w_ip * softmax(q Kip^T / sqrt(d)) Vip
+ * with two INDEPENDENT softmaxes.  (w_text,w_ip) = (1,1) under no_grad (:411-412); the
+ * grad-mode fusion rule (:413-420) selects (2,0), (0,2) or (1,1).
+ * Also emits to_v_ip_norm[b][h][p] = ||Vip[b,p,h,:]||_2 (:397) when vnorm != NULL.
+ * nt <= 77+..., nt + nip <= 96.
+ */
+typedef struct pv_xattn_params {
+    const void* q; int32_t ldq;
+    const void* kt; const void* vt; int32_t ldkt, ldvt;   /* text K/V rows [B*nt] */
+    const void* kip; const void* vip; int32_t ldkip, ldvip; /* image-token K/V rows [B*nip] */
+    void* out; int32_t ldo;
+    float* vnorm;                                          /* [B][H][nip] or NULL */
+    int32_t batch, heads, nq, nt, nip, d;
+    float w_text, w_ip;
+} pv_xattn_params;
+int pv_cross_attention(const pv_xattn_params* p, void* stream);
+
+/* GEGLU gate (diffusers GEGLU, exact-erf GELU): out[m][j] = x[m][j] * gelu(x[m][n+j]) */
+int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, int32_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step-state driven pieces of the denoising loop (infer.py:98-119).  `state` is a small device
+ * block: int32 step index at state[0]; tables are indexed with it so that ONE captured HIP
+ * graph can be replayed for every step.
+ */
+/* sinusoidal timestep embedding (flip_sin_to_cos, shift 0) -> fp16 [rows][dim];
+ * t taken from timesteps[state ? *state : 0 ... ] : rows>1 => per-row timesteps[row] */
+int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t rows, int32_t dim,
+                          void* out, void* stream);
+/* conv_in: NCHW fp32 latents (B,cin,H,W) -> NHWC fp16 (B,H,W,cout), 3x3 pad 1; w fp32 [cout][cin][3][3] */
+int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin,
+               int32_t h, int32_t wd, int32_t cout, void* stream);
+/* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin] */
+int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin,
+                int32_t h, int32_t wd, int32_t cout, void* stream);
+/* CFG combine (infer.py:116) + DPM-Solver++(2M) update (infer.py:119) on fp32 NCHW latents.
+ * coef[step][4] = {c_x, c_eps, c_x0, c_x0prev}:  x0 = inv_alpha*x - sig_over_alpha*eps ... see
+ * photoverse_amd/scheduler.py; advances nothing (pv_step_advance does). */
+int pv_cfg_dpm_step(const float* eps_uncond, const float* eps_cond, float* latents, float* x0_prev,
+                    const float* coef, const int32_t* state, float guidance, int64_t n, void* stream);
+int pv_step_advance(int32_t* state, void* stream);
+
+/* small helpers */
+int pv_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+int pv_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* mean over `count` consecutive rows: x fp16 [groups*count][cols] -> y fp16 [groups][cols]
+ * (adapters.py:36 mean over the 256 patch tokens); y may be accumulated (+=) when accumulate!=0 */
+int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t cols,
+                 int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHOTOVERSE_HIP_H */

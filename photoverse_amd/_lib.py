@@ -1,0 +1,97 @@
+"""ctypes binding of ``libphotoverse_hip.so`` (C-ABI declared in ``include/photoverse_hip.h``).
+
+The product path has NO fallback: if the library is missing or fails to load, importing any op
+raises.  ``photoverse_amd.build.build_lib()`` (or ``__graft_entry__.build()``) creates it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB
+
+c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("c0", c_int), ("c1", c_int), ("lda0", c_int), ("lda1", c_int),
+                ("w", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p), ("rowadd_ld", c_int), ("residual", c_void_p),
+                ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
+                ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
+                ("upsample", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int), ("zero_page", c_void_p)]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("c0", c_int), ("c1", c_int), ("ld0", c_int), ("ld1", c_int),
+                ("batch", c_int), ("hw", c_int), ("groups", c_int), ("splits", c_int), ("partial", c_void_p),
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("act", c_int), ("y", c_void_p)]
+
+
+class LayerNormParams(C.Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int), ("y", c_void_p), ("ldy", c_int), ("gamma", c_void_p), ("beta", c_void_p),
+                ("rows", c_int), ("cols", c_int), ("eps", c_float), ("act", c_int)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("ldq", c_int), ("ldk", c_int), ("ldv", c_int),
+                ("out", c_void_p), ("ldo", c_int), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nk", c_int),
+                ("d", c_int), ("causal", c_int)]
+
+
+class XAttnParams(C.Structure):
+    _fields_ = [("q", c_void_p), ("ldq", c_int), ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int),
+                ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int), ("out", c_void_p), ("ldo", c_int),
+                ("vnorm", c_void_p), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nt", c_int), ("nip", c_int),
+                ("d", c_int), ("w_text", c_float), ("w_ip", c_float)]
+
+
+#: every symbol ``include/photoverse_hip.h`` declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "pv_abi_version": (c_int, []),
+    "pv_device_count": (c_int, []),
+    "pv_gemm_conv": (c_int, [C.POINTER(GemmParams), c_void_p]),
+    "pv_groupnorm_stats": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
+    "pv_groupnorm_apply": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
+    "pv_layernorm": (c_int, [C.POINTER(LayerNormParams), c_void_p]),
+    "pv_attention": (c_int, [C.POINTER(AttnParams), c_void_p]),
+    "pv_cross_attention": (c_int, [C.POINTER(XAttnParams), c_void_p]),
+    "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pv_conv_in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_cfg_dpm_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "pv_step_advance": (c_int, [c_void_p, c_void_p]),
+    "pv_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pv_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pv_rows_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library.  Raises ``HipExtensionMissing`` - never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise HipExtensionMissing(
+            f"{LIB} not found: build it with `python -m photoverse_amd.build` (needs hipcc). "
+            "photoverse_amd has no CPU / eager fallback.")
+    try:
+        lib = C.CDLL(LIB)
+    except OSError as e:  # pragma: no cover
+        raise HipExtensionMissing(f"cannot load {LIB}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pv_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing(f"{LIB} has ABI {lib.pv_abi_version()}, expected {ABI_VERSION}: rebuild it")
+    _lib = lib
+    return lib

@@ -1,0 +1,433 @@
+// Flash-style attention kernels for gfx950:
+//   pv_attention        self attention (UNet attn1, CLIP encoders), online softmax over 64-key tiles
+//   pv_cross_attention  PhotoVerse dual-branch cross attention: text keys + image-token keys in ONE
+//                       96-row K/V image, two independent softmaxes, one P.V pass
+//
+// Wave-level scheme (both kernels): a wave owns 32 query rows (2 fragments of 16).  Scores are
+// computed TRANSPOSED, S^T[key][q] = K . Q^T with v_mfma_f32_16x16x32_f16 (K rows as MFMA-A from LDS,
+// Q as MFMA-B from registers), so a lane holds 4 consecutive keys x its own query column: row max /
+// row sum are 15 in-register ops + two cross-lane steps.  The exponentiated scores are already laid
+// out as the B operand of the second product O^T[dv][q] = V^T . P^T (k order permuted identically on
+// both operands), whose A operand V^T is read straight from the row-major V tile with the gfx950
+// transposing LDS read ds_read_b64_tr_b16.  No P round trip through LDS.
+#include "pv_common.h"
+
+namespace {
+
+template <int D>
+struct ACfg {
+    static constexpr int DK = (D + 31) / 32 * 32;  // contraction length of Q.K^T padded to the MFMA K
+    static constexpr int KSTEPS = DK / 32;
+    static constexpr int DVF = (D + 15) / 16;      // 16-wide output fragments of P.V
+    static constexpr int KS = DK + 8;              // LDS row strides in halfs (+16 B pad)
+    static constexpr int VS = DVF * 16 + 8;
+    static constexpr int CH = D / 8;               // 16-byte chunks per row
+};
+
+__device__ __forceinline__ half8_t zero8() { return half8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// V^T fragment (MFMA-A) for output rows dv0..dv0+15 and the 8 keys {key0+4fq..+3, key0+16+4fq..+3}
+__device__ __forceinline__ half8_t vt_frag(const half_t* sV, int VS, int key0, int dv0, int fr, int fq) {
+    const half_t* a = sV + (key0 + fq * 4 + (fr >> 2)) * VS + dv0 + (fr & 3) * 4;
+    const fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
+    const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * VS));
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (half_t)t1[j];
+        r[j + 4] = (half_t)t2[j];
+    }
+    return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
+    using C = ACfg<D>;
+    constexpr int KB = 64;
+    constexpr int NCHUNK = KB * C::CH;
+    constexpr int KPT = (NCHUNK + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sK = reinterpret_cast<half_t*>(smem);
+    half_t* sV = sK + KB * C::KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
+    const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
+
+    // zero the K pad columns [D, KS) once: the contraction runs over DK >= D
+    {
+        constexpr int NPC = (C::KS - D) / 8;
+        for (int i = tid; i < KB * NPC; i += 256) {
+            const int r = i / NPC, c = i - r * NPC;
+            *reinterpret_cast<half8_t*>(sK + r * C::KS + D + c * 8) = zero8();
+        }
+    }
+
+    half8_t qf[2][C::KSTEPS];
+    int qrow[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
+        const int rc = min(qrow[qi], p.nq - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+        }
+    }
+
+    half8_t kreg[KPT], vreg[KPT];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * 256;
+            const int key = idx / C::CH, c = idx - key * C::CH;
+            const int gk = t * KB + key;
+            if (idx < NCHUNK && gk < p.nk) {
+                kreg[i] = *reinterpret_cast<const half8_t*>(Kg + (size_t)gk * p.ldk + c * 8);
+                vreg[i] = *reinterpret_cast<const half8_t*>(Vg + (size_t)gk * p.ldv + c * 8);
+            } else {
+                kreg[i] = zero8();
+                vreg[i] = zero8();
+            }
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * 256;
+            const int key = idx / C::CH, c = idx - key * C::CH;
+            if (idx < NCHUNK) {
+                *reinterpret_cast<half8_t*>(sK + key * C::KS + c * 8) = kreg[i];
+                *reinterpret_cast<half8_t*>(sV + key * C::VS + c * 8) = vreg[i];
+            }
+        }
+    };
+
+    float4_t o[C::DVF][2];
+#pragma unroll
+    for (int f = 0; f < C::DVF; ++f)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+
+    int ntiles = (p.nk + KB - 1) / KB;
+    if (p.causal) ntiles = min(ntiles, (min(qt * 128 + 127, p.nq - 1)) / KB + 1);
+    gload(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();  // previous tile fully consumed
+        swrite();
+        __syncthreads();
+        if (t + 1 < ntiles) gload(t + 1);
+
+        float4_t s[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) s[kb][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::KS + (ks * 4 + fq) * 8);
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+            }
+
+        const bool need_mask = p.causal || (t + 1) * KB > p.nk;
+        half8_t pb[2][2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * KB + kb * 16 + fq * 4 + r;
+                        if (key >= p.nk || (p.causal && key > qrow[qi])) s[kb][qi][r] = -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qi][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qi], mx * sc);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = exp2f(m_run[qi] - m_use);
+            m_run[qi] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(fmaf(s[kb][qi][r], sc, -m_use));
+                    rs += e;
+                    s[kb][qi][r] = e;
+                }
+            l_run[qi] = l_run[qi] * alpha + rs;
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pb[s2][qi][r] = (half_t)s[2 * s2][qi][r];
+                    pb[s2][qi][r + 4] = (half_t)s[2 * s2 + 1][qi][r];
+                }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) {
+                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
+            }
+    }
+
+    half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (qrow[qi] < p.nq) {
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) {
+                const int dv = f * 16 + fq * 4;
+                if (dv < D) {
+                    half4_t ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[f][qi][r] * inv);
+                    *reinterpret_cast<half4_t*>(O + (size_t)qrow[qi] * p.ldo + dv) = ov;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dual-branch cross attention.  K/V image rows: [0,nt) text, [IP0, IP0+nip) image tokens, rest zero.
+constexpr int XKEYS = 96;
+constexpr int IP0 = 80;
+
+template <int D>
+__global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
+    using C = ACfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sK = reinterpret_cast<half_t*>(smem);
+    half_t* sV = sK + XKEYS * C::KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+
+    // stage K and V (zero-filled pads)
+    {
+        constexpr int KC = C::KS / 8, VC = C::VS / 8;
+        for (int i = tid; i < XKEYS * KC; i += 256) {
+            const int r = i / KC, c = i - r * KC;
+            half8_t v = zero8();
+            if (c < C::CH) {
+                if (r < p.nt)
+                    v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.kt) + ((size_t)b * p.nt + r) * p.ldkt + h * D + c * 8);
+                else if (r >= IP0 && r < IP0 + p.nip)
+                    v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.kip) + ((size_t)b * p.nip + (r - IP0)) * p.ldkip + h * D + c * 8);
+            }
+            *reinterpret_cast<half8_t*>(sK + r * C::KS + c * 8) = v;
+        }
+        for (int i = tid; i < XKEYS * VC; i += 256) {
+            const int r = i / VC, c = i - r * VC;
+            half8_t v = zero8();
+            if (c < C::CH) {
+                if (r < p.nt)
+                    v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.vt) + ((size_t)b * p.nt + r) * p.ldvt + h * D + c * 8);
+                else if (r >= IP0 && r < IP0 + p.nip)
+                    v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.vip) + ((size_t)b * p.nip + (r - IP0)) * p.ldvip + h * D + c * 8);
+            }
+            *reinterpret_cast<half8_t*>(sV + r * C::VS + c * 8) = v;
+        }
+    }
+
+    half8_t qf[2][C::KSTEPS];
+    int qrow[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
+        const int rc = min(qrow[qi], p.nq - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+        }
+    }
+    __syncthreads();
+
+    // to_v_ip_norm (attention_processor.py:397): ||Vip[b,p,h,:]||_2, once per (b,h)
+    if (p.vnorm && qt == 0 && tid < p.nip) {
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float v = (float)sV[(IP0 + tid) * C::VS + d];
+            a += v * v;
+        }
+        p.vnorm[((size_t)b * p.heads + h) * p.nip + tid] = sqrtf(a);
+    }
+
+    constexpr int NKB = XKEYS / 16;
+    float4_t s[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) s[kb][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::KS + (ks * 4 + fq) * 8);
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+        }
+
+    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+    half8_t pb[NKB / 2][2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        float mt = -INFINITY, mi = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb * 16 + fq * 4 + r;
+                const float v = s[kb][qi][r];
+                if (key < p.nt) mt = fmaxf(mt, v);
+                if (key >= IP0 && key < IP0 + p.nip) mi = fmaxf(mi, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mi = fmaxf(mi, __shfl_xor(mi, 16, 64));
+        mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
+        float lt = 0.f, li = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb * 16 + fq * 4 + r;
+                const bool is_t = key < p.nt;
+                const bool is_i = key >= IP0 && key < IP0 + p.nip;
+                float e = 0.f;
+                if (is_t) {
+                    e = exp2f((s[kb][qi][r] - mt) * sc);
+                    lt += e;
+                } else if (is_i) {
+                    e = exp2f((s[kb][qi][r] - mi) * sc);
+                    li += e;
+                }
+                s[kb][qi][r] = e;
+            }
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        li += __shfl_xor(li, 16, 64);
+        li += __shfl_xor(li, 32, 64);
+        const float ft = p.w_text / lt, fi = p.w_ip / li;
+#pragma unroll
+        for (int s2 = 0; s2 < NKB / 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = (2 * s2) * 16 + fq * 4 + r, k1 = k0 + 16;
+                pb[s2][qi][r] = (half_t)(s[2 * s2][qi][r] * (k0 < IP0 ? ft : fi));
+                pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * (k1 < IP0 ? ft : fi));
+            }
+    }
+
+    float4_t o[C::DVF][2];
+#pragma unroll
+    for (int f = 0; f < C::DVF; ++f)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < NKB / 2; ++s2)
+#pragma unroll
+        for (int f = 0; f < C::DVF; ++f) {
+            const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
+        }
+
+    half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        if (qrow[qi] < p.nq) {
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) {
+                const int dv = f * 16 + fq * 4;
+                if (dv < D) {
+                    half4_t ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[f][qi][r];
+                    *reinterpret_cast<half4_t*>(O + (size_t)qrow[qi] * p.ldo + dv) = ov;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn(const pv_attn_params& p, hipStream_t s) {
+    using C = ACfg<D>;
+    constexpr int smem = 64 * (C::KS + C::VS) * 2;
+    hipLaunchKernelGGL(attn_kernel<D>, dim3((p.nq + 127) / 128, p.heads, p.batch), dim3(256), smem, s, p);
+    return PV_CHECK_LAUNCH();
+}
+
+template <int D>
+int launch_xattn(const pv_xattn_params& p, hipStream_t s) {
+    using C = ACfg<D>;
+    constexpr int smem = XKEYS * (C::KS + C::VS) * 2;
+    static bool attr_set = false;
+    if (smem > 48 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(xattn_kernel<D>, dim3((p.nq + 127) / 128, p.heads, p.batch), dim3(256), smem, s, p);
+    return PV_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int pv_attention(const pv_attn_params* p, void* stream) {
+    if (!p->q || !p->k || !p->v || !p->out || p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nk <= 0 || (p->ldq % 8) ||
+        (p->ldk % 8) || (p->ldv % 8) || (p->ldo % 4))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->d) {
+        case 40: return launch_attn<40>(*p, s);
+        case 64: return launch_attn<64>(*p, s);
+        case 80: return launch_attn<80>(*p, s);
+        case 160: return launch_attn<160>(*p, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+extern "C" int pv_cross_attention(const pv_xattn_params* p, void* stream) {
+    if (!p->q || !p->kt || !p->vt || !p->kip || !p->vip || !p->out || p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nt <= 0 ||
+        p->nt > IP0 || p->nip <= 0 || p->nip > XKEYS - IP0 || (p->ldq % 8) || (p->ldkt % 8) || (p->ldvt % 8) || (p->ldkip % 8) ||
+        (p->ldvip % 8) || (p->ldo % 4))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->d) {
+        case 40: return launch_xattn<40>(*p, s);
+        case 80: return launch_xattn<80>(*p, s);
+        case 160: return launch_xattn<160>(*p, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 kernels of libphotoverse_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/photoverse_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#define PV_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PV_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define PV_CHECK_LAUNCH() ((int)hipGetLastError())
+
+__device__ __forceinline__ int pv_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int pv_lane_id() { return (int)(threadIdx.x & 63); }
+
+// 16-byte async global -> LDS copy (LDS-DMA).  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void pv_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(PV_GLOBAL_PTR(gsrc), PV_LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float pv_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float pv_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float pv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float pv_apply_act(float x, int act) {
+    switch (act) {
+        case PV_ACT_SILU: return pv_silu(x);
+        case PV_ACT_QUICK_GELU: return pv_quick_gelu(x);
+        case PV_ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
+        case PV_ACT_GELU: return pv_gelu_erf(x);
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float pv_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float pv_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): consecutive remapped ids share an XCD/L2.
+__device__ __forceinline__ int pv_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}

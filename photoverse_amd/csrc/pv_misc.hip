@@ -1,0 +1,251 @@
+// Small HBM-bound kernels around the UNet: timestep embedding, conv_in / conv_out (layout change
+// fused), GEGLU gate, CFG + DPM-Solver++ update, casts, patch-token mean.
+#include "pv_common.h"
+
+extern "C" int pv_abi_version(void) { return PV_ABI_VERSION; }
+
+extern "C" int pv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+namespace {
+
+// [EXT] diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void timestep_embedding_kernel(const float* timesteps, const int32_t* state, int rows, int dim, half_t* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * dim) return;
+    const int row = idx / dim, i = idx - row * dim;
+    const int half = dim >> 1;
+    const float t = state ? timesteps[state[0]] : timesteps[row];
+    const int k = i < half ? i : i - half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+    const float a = t * freq;
+    out[idx] = (half_t)(i < half ? cosf(a) : sinf(a));
+}
+
+// conv_in: NCHW fp32 -> NHWC fp16, 3x3 pad 1.  One thread = one pixel x 8 output channels.
+__global__ void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                               half_t* __restrict__ out, int batch, int cin, int h, int wd, int cout) {
+    extern __shared__ float sw[];  // [cin*9][cout]
+    const int ktot = cin * 9;
+    for (int i = threadIdx.x; i < ktot * cout; i += blockDim.x) {
+        const int co = i / ktot, k = i - co * ktot;  // w is [cout][cin][3][3]
+        sw[k * cout + co] = w[i];
+    }
+    __syncthreads();
+    const int nchunk = cout >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)batch * h * wd * nchunk;
+    if (idx >= total) return;
+    const int chunk = (int)(idx % nchunk);
+    const long pix = idx / nchunk;
+    const int b = (int)(pix / (h * wd));
+    const int rem = (int)(pix - (long)b * h * wd);
+    const int y = rem / wd, xx = rem - y * wd;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[chunk * 8 + j] : 0.f;
+    for (int ci = 0; ci < cin; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xx + kx - 1;
+                if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+                const float v = x[(((long)b * cin + ci) * h + iy) * wd + ix];
+                const float* ww = sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v * ww[j];
+            }
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+    *reinterpret_cast<half8_t*>(out + pix * cout + chunk * 8) = o;
+}
+
+// conv_out: NHWC fp16 -> NCHW fp32, 3x3 pad 1, cout <= 8.  One wave = one output pixel.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int batch, int cin,
+                                                       int h, int wd) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long)batch * h * wd) return;
+    const int b = (int)(pix / (h * wd));
+    const int rem = (int)(pix - (long)b * h * wd);
+    const int y = rem / wd, xx = rem - y * wd;
+    const int nchunk = cin >> 3;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = y + tap / 3 - 1, ix = xx + tap % 3 - 1;
+        if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;  // wave-uniform
+        const half_t* xr = x + ((long)(b * h + iy) * wd + ix) * cin;
+        for (int ch = lane; ch < nchunk; ch += 64) {
+            const half8_t v = *reinterpret_cast<const half8_t*>(xr + ch * 8);
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                const half8_t ww = *reinterpret_cast<const half8_t*>(w + ((long)c * 9 + tap) * cin + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c] += (float)v[j] * (float)ww[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = pv_wave_sum(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) out[(((long)b * COUT + c) * h + y) * wd + xx] = acc[c] + (bias ? bias[c] : 0.f);
+    }
+}
+
+__global__ void geglu_kernel(const half_t* x, int ldx, half_t* out, int ldo, int rows, int n) {
+    const int nchunk = n >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * nchunk) return;
+    const int ch = (int)(idx % nchunk);
+    const long r = idx / nchunk;
+    const half8_t a = *reinterpret_cast<const half8_t*>(x + r * ldx + ch * 8);
+    const half8_t g = *reinterpret_cast<const half8_t*>(x + r * ldx + n + ch * 8);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] * pv_gelu_erf((float)g[j]));
+    *reinterpret_cast<half8_t*>(out + r * ldo + ch * 8) = o;
+}
+
+// coef row (8 floats): {ca, cb, cx, c0, c1, -, -, -}
+//   eps = eps_u + g (eps_c - eps_u)              infer.py:116
+//   x0  = ca*x + cb*eps                          epsilon -> data prediction
+//   x'  = cx*x + c0*x0 + c1*x0_prev              DPM-Solver++ 1st / 2nd order (midpoint)
+__global__ void cfg_dpm_step_kernel(const float* eu, const float* ec, float* lat, float* x0p, const float* coef,
+                                    const int32_t* state, float g, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* c = coef + (long)state[0] * 8;
+    const float ca = c[0], cb = c[1], cx = c[2], c0 = c[3], c1 = c[4];
+    const float4_t u = *reinterpret_cast<const float4_t*>(eu + i);
+    const float4_t cc = *reinterpret_cast<const float4_t*>(ec + i);
+    float4_t x = *reinterpret_cast<const float4_t*>(lat + i);
+    float4_t xp = *reinterpret_cast<const float4_t*>(x0p + i);
+    float4_t x0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float e = u[j] + g * (cc[j] - u[j]);
+        x0[j] = ca * x[j] + cb * e;
+        x[j] = cx * x[j] + c0 * x0[j] + c1 * xp[j];
+    }
+    *reinterpret_cast<float4_t*>(lat + i) = x;
+    *reinterpret_cast<float4_t*>(x0p + i) = x0;
+}
+
+__global__ void step_advance_kernel(int32_t* state) { state[0] += 1; }
+
+__global__ void cast_f32_f16_kernel(const float* x, half_t* y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (half_t)x[i];
+}
+__global__ void cast_f16_f32_kernel(const half_t* x, float* y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+
+__global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, int groups, int count, int cols, int accumulate) {
+    const int nchunk = cols >> 3;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= groups * nchunk) return;
+    const int g = idx / nchunk, ch = idx - g * nchunk;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int r = 0; r < count; ++r) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(x + ((long)g * count + r) * ldx + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+    half_t* yo = y + (long)g * ldy + ch * 8;
+    half8_t o;
+    half8_t prev = accumulate ? *reinterpret_cast<const half8_t*>(yo) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] / (float)count + (float)prev[j]);
+    *reinterpret_cast<half8_t*>(yo) = o;
+}
+
+}  // namespace
+
+extern "C" int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t rows, int32_t dim, void* out,
+                                     void* stream) {
+    if (rows <= 0 || dim <= 0 || (dim & 1) || !timesteps || !out) return (int)hipErrorInvalidValue;
+    const int n = rows * dim;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timesteps, state, rows,
+                       dim, reinterpret_cast<half_t*>(out));
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin, int32_t h,
+                          int32_t wd, int32_t cout, void* stream) {
+    if (batch <= 0 || cin <= 0 || (cout % 8) || cin * 9 * cout * 4 > 64 * 1024 || !x || !w || !out) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * h * wd * (cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), cin * 9 * cout * sizeof(float),
+                       (hipStream_t)stream, x, w, bias, reinterpret_cast<half_t*>(out), batch, cin, h, wd, cout);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t h,
+                           int32_t wd, int32_t cout, void* stream) {
+    if (batch <= 0 || (cin % 8) || cout != 4 || !x || !w || !out) return (int)hipErrorInvalidValue;
+    const long pix = (long)batch * h * wd;
+    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, int32_t n, void* stream) {
+    if (rows <= 0 || n <= 0 || (n % 8) || !x || !out) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (n / 8);
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<half_t*>(out), ldo, rows, n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_cfg_dpm_step(const float* eps_uncond, const float* eps_cond, float* latents, float* x0_prev, const float* coef,
+                               const int32_t* state, float guidance, int64_t n, void* stream) {
+    if (n <= 0 || (n % 4) || !eps_uncond || !eps_cond || !latents || !x0_prev || !coef || !state) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cfg_dpm_step_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps_uncond,
+                       eps_cond, latents, x0_prev, coef, state, guidance, (long)n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_step_advance(int32_t* state, void* stream) {
+    if (!state) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+    if (n <= 0 || !x || !y) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<half_t*>(y), (long)n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+    if (n <= 0 || !x || !y) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(x), y, (long)n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t cols,
+                            int32_t accumulate, void* stream) {
+    if (groups <= 0 || count <= 0 || cols <= 0 || (cols % 8) || !x || !y) return (int)hipErrorInvalidValue;
+    const int total = groups * (cols / 8);
+    hipLaunchKernelGGL(rows_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<half_t*>(y), ldy, groups, count, cols, accumulate);
+    return PV_CHECK_LAUNCH();
+}

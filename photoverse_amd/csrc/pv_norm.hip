@@ -1,0 +1,211 @@
+// GroupNorm (NHWC, optional two-source channel concat) and LayerNorm for gfx950.  HBM-bound:
+// 16-byte vector loads/stores, fp32 statistics.
+#include "pv_common.h"
+
+namespace {
+
+// thread t owns 16-byte channel chunk (t % nchunk) of pixel rows (t / nchunk), (t / nchunk) + R, ...
+__device__ __forceinline__ half8_t gn_load(const pv_groupnorm_params& p, size_t row, int chunk) {
+    const int c = chunk * 8;
+    if (c < p.c0) return *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.x0) + row * p.ld0 + c);
+    return *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.x1) + row * p.ld1 + (c - p.c0));
+}
+
+__global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass) {
+    extern __shared__ float sh[];  // [2][C]
+    const int C = p.c0 + p.c1;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    const int chunk = tid % nchunk, r = tid / nchunk;
+    const int pps = p.hw / p.splits;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = sq[j] = 0.f;
+    const size_t row0 = (size_t)b * p.hw + (size_t)s * pps;
+    for (int px = r; px < pps; px += rows_per_pass) {
+        const half8_t v = gn_load(p, row0 + px, chunk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j];
+            sum[j] += f;
+            sq[j] += f * f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sh[chunk * 8 + j], sum[j]);
+        atomicAdd(&sh[C + chunk * 8 + j], sq[j]);
+    }
+    __syncthreads();
+    if (tid < p.groups) {
+        const int cpg = C / p.groups;
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += sh[c];
+            q += sh[C + c];
+        }
+        float* out = p.partial + (((size_t)b * p.splits + s) * p.groups + tid) * 2;
+        out[0] = a;
+        out[1] = q;
+    }
+}
+
+__global__ void gn_apply_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass, const int px_per_block) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = p.c0 + p.c1;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < p.groups) {
+        float a = 0.f, q = 0.f;
+        const float* part = p.partial + ((size_t)b * p.splits * p.groups + tid) * 2;
+        for (int s = 0; s < p.splits; ++s) {
+            a += part[(size_t)s * p.groups * 2];
+            q += part[(size_t)s * p.groups * 2 + 1];
+        }
+        const float n = (float)(C / p.groups) * (float)p.hw;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int chunk = tid % nchunk, r = tid / nchunk;
+    const int cpg = C / p.groups;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        const int g = c / cpg;
+        const float a = p.gamma[c] * s_rstd[g];
+        sc[j] = a;
+        sf[j] = p.beta[c] - s_mean[g] * a;
+    }
+    const int px0 = blockIdx.x * px_per_block;
+    const int px1 = min(px0 + px_per_block, p.hw);
+    half_t* y = reinterpret_cast<half_t*>(p.y);
+    for (int px = px0 + r; px < px1; px += rows_per_pass) {
+        const size_t row = (size_t)b * p.hw + px;
+        const half8_t v = gn_load(p, row, chunk);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * sc[j] + sf[j];
+            if (p.act == PV_ACT_SILU) f = pv_silu(f);
+            o[j] = (half_t)f;
+        }
+        *reinterpret_cast<half8_t*>(y + row * C + chunk * 8) = o;
+    }
+}
+
+// one wave per row; lane owns chunks lane, lane+64, ...
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const pv_layernorm_params p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nchunk = p.cols >> 3;
+    const half_t* x = reinterpret_cast<const half_t*>(p.x) + (size_t)row * p.ldx;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const half8_t h = *reinterpret_cast<const half8_t*>(x + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = (float)h[j];
+                sum += v[i][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = pv_wave_sum(sum) / (float)p.cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(pv_wave_sum(sq) / (float)p.cols + p.eps);
+    half_t* y = reinterpret_cast<half_t*>(p.y) + (size_t)row * p.ldy;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const float4_t g0 = *reinterpret_cast<const float4_t*>(p.gamma + ch * 8);
+            const float4_t g1 = *reinterpret_cast<const float4_t*>(p.gamma + ch * 8 + 4);
+            const float4_t b0 = *reinterpret_cast<const float4_t*>(p.beta + ch * 8);
+            const float4_t b1 = *reinterpret_cast<const float4_t*>(p.beta + ch * 8 + 4);
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = j < 4 ? g0[j] : g1[j - 4];
+                const float bb = j < 4 ? b0[j] : b1[j - 4];
+                o[j] = (half_t)pv_apply_act((v[i][j] - mean) * rstd * g + bb, p.act);
+            }
+            *reinterpret_cast<half8_t*>(y + ch * 8) = o;
+        }
+    }
+}
+
+bool gn_geometry(const pv_groupnorm_params& p, int& nchunk, int& threads, int& rpp) {
+    const int C = p.c0 + p.c1;
+    if (C <= 0 || (C % 8) || (p.c0 % 8) || p.groups <= 0 || p.groups > 64 || (C % p.groups) || p.splits <= 0 || (p.hw % p.splits))
+        return false;
+    nchunk = C / 8;
+    if (nchunk > 1024) return false;
+    rpp = 256 / nchunk;
+    if (rpp < 1) rpp = 1;
+    threads = nchunk * rpp;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream) {
+    int nchunk, threads, rpp;
+    if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->x0) return (int)hipErrorInvalidValue;
+    const int C = p->c0 + p->c1;
+    if (threads < p->groups) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(p->splits, p->batch), dim3(threads), 2 * C * sizeof(float), (hipStream_t)stream, *p,
+                       nchunk, rpp);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream) {
+    int nchunk, threads, rpp;
+    if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->x0 || !p->y || !p->gamma || !p->beta)
+        return (int)hipErrorInvalidValue;
+    if (threads < p->groups) return (int)hipErrorInvalidValue;
+    const int px_per_block = 64;
+    const int gx = (p->hw + px_per_block - 1) / px_per_block;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, p->batch), dim3(threads), 0, (hipStream_t)stream, *p, nchunk, rpp, px_per_block);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_layernorm(const pv_layernorm_params* p, void* stream) {
+    if (p->rows <= 0 || p->cols <= 0 || (p->cols % 8) || p->cols > 4096 || !p->x || !p->y || !p->gamma || !p->beta)
+        return (int)hipErrorInvalidValue;
+    const int nch = (p->cols / 8 + 63) / 64;
+    const dim3 grid((p->rows + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, *p); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, *p); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, *p); break;
+        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, *p); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, *p); break;
+    }
+    return PV_CHECK_LAUNCH();
+}

@@ -1,0 +1,230 @@
+"""Host-side launch recorder over the C-ABI of ``libphotoverse_hip.so``.
+
+A ``Recorder`` turns high-level op calls on torch device tensors into a flat list of
+``(c_function, params_struct)`` launches with static buffers.  ``run()`` enqueues the list on the
+current HIP stream; because every launch is allocation-free and sync-free the same list can be
+captured into a HIP graph (``torch.cuda.CUDAGraph``) and replayed.
+
+torch is used for device memory and streams only; every arithmetic op is a HIP kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AttnParams, GemmParams, GroupNormParams, LayerNormParams, XAttnParams
+
+ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
+
+
+class HipLaunchError(RuntimeError):
+    pass
+
+
+def require_cuda(t: torch.Tensor, what: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"photoverse_amd: {what} must live on a HIP device (got {t.device}); there is no CPU path")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t: torch.Tensor) -> Tuple[int, int]:
+    """(row stride in elements, columns) of a 2-D row view with unit column stride."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    return t.stride(0), t.shape[1]
+
+
+def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Reorder GEGLU ``proj`` rows so that every 128-row weight tile holds, per wave half, alternating
+    16-row fragments [value | gate] of the same 16 output columns (see pv_gemm.hip, GEGLU epilogue).
+    weight [2*n, k] -> packed [2*n, k]; packed row p maps to source row:
+        t = p // 128; wn = (p % 128) // 64; ni = (p % 64) // 16; e = p % 16
+        j = t*64 + wn*32 + (ni//2)*16 + e;  src = j + (ni & 1) * n
+    """
+    n2 = weight.shape[0]
+    n = n2 // 2
+    assert n2 % 128 == 0
+    p = torch.arange(n2, device=weight.device)
+    t, wn, ni, e = p // 128, (p % 128) // 64, (p % 64) // 16, p % 16
+    src = t * 64 + wn * 32 + (ni // 2) * 16 + e + (ni & 1) * n
+    return weight[src].contiguous(), (None if bias is None else bias[src].contiguous())
+
+
+class Recorder:
+    def __init__(self, device: torch.device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("photoverse_amd: a HIP device is required; there is no CPU path")
+        self.calls: List[tuple] = []
+        self.keep: List[object] = []       # tensors / structs referenced by raw pointer
+        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        self.bytes_allocated = 0
+
+    # ------------------------------------------------------------------ memory
+    def empty(self, shape, dtype=torch.float16) -> torch.Tensor:
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        self.bytes_allocated += t.numel() * t.element_size()
+        self.keep.append(t)
+        return t
+
+    def hold(self, t):
+        self.keep.append(t)
+        return t
+
+    # ------------------------------------------------------------------ execution
+    def _add(self, fn, *args):
+        self.keep.extend(a for a in args if isinstance(a, C.Structure))
+        self.calls.append((fn, tuple(C.byref(a) if isinstance(a, C.Structure) else a for a in args)))
+
+    def run(self, stream: Optional[int] = None):
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        for fn, args in self.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                raise HipLaunchError(f"{fn.__name__} failed with hipError {rc}")
+
+    def __len__(self):
+        return len(self.calls)
+
+    # ------------------------------------------------------------------ ops
+    def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
+             rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
+             out_f32=False, geglu=False, conv: Optional[dict] = None) -> torch.Tensor:
+        """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin]."""
+        lda0, c0 = _rows(a)
+        lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
+        taps = 9 if conv is not None else 1
+        N = w.shape[0]
+        assert w.shape[1] == taps * (c0 + c1) and w.is_contiguous() and w.dtype == torch.float16, (w.shape, taps, c0, c1)
+        if conv is not None:
+            M = conv["batch"] * conv["hout"] * conv["wout"]
+            geo = (conv["batch"], conv["hin"], conv["win"], conv["hout"], conv["wout"], conv.get("stride", 1), conv.get("upsample", 0))
+        else:
+            M = a.shape[0]
+            geo = (1, 1, 1, rows_per_image or M, 1, 1, 0)
+        n_out = N // 2 if geglu else N
+        if out is None:
+            out = self.empty((M, n_out), torch.float32 if out_f32 else torch.float16)
+        ldc, oc = _rows(out)
+        assert oc == n_out and out.shape[0] == M
+        ldr = 0
+        if residual is not None:
+            ldr, rc = _rows(residual)
+            assert rc == n_out and residual.shape[0] == M
+        p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), _ptr(self.zero_page))
+        self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
+        self._add(self.lib.pv_gemm_conv, p)
+        return out
+
+    def groupnorm(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5,
+                  act=ACT_NONE, groups=32) -> torch.Tensor:
+        ld0, c0 = _rows(x)
+        ld1, c1 = _rows(x1) if x1 is not None else (0, 0)
+        splits = 64
+        while splits > 1 and (hw % splits or hw // splits < 16):
+            splits //= 2
+        partial = self.empty((batch, splits, groups, 2), torch.float32)
+        y = self.empty((batch * hw, c0 + c1), torch.float16)
+        p = GroupNormParams(_ptr(x), _ptr(x1), c0, c1, ld0, ld1, batch, hw, groups, splits, _ptr(partial), _ptr(gamma), _ptr(beta),
+                            float(eps), act, _ptr(y))
+        self.keep.extend(t for t in (x, x1, gamma, beta) if t is not None)
+        self._add(self.lib.pv_groupnorm_stats, p)
+        self._add(self.lib.pv_groupnorm_apply, p)
+        return y
+
+    def layernorm(self, x: torch.Tensor, gamma, beta, *, eps=1e-5, act=ACT_NONE, out=None) -> torch.Tensor:
+        ldx, cols = _rows(x)
+        if out is None:
+            out = self.empty((x.shape[0], cols), torch.float16)
+        ldy, _ = _rows(out)
+        p = LayerNormParams(_ptr(x), ldx, _ptr(out), ldy, _ptr(gamma), _ptr(beta), x.shape[0], cols, float(eps), act)
+        self.keep.extend((x, gamma, beta, out))
+        self._add(self.lib.pv_layernorm, p)
+        return out
+
+    def attention(self, q, k, v, *, batch, heads, nq, nk, d, causal=False, out=None) -> torch.Tensor:
+        ldq, _ = _rows(q)
+        ldk, _ = _rows(k)
+        ldv, _ = _rows(v)
+        if out is None:
+            out = self.empty((batch * nq, heads * d), torch.float16)
+        ldo, _ = _rows(out)
+        p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal))
+        self.keep.extend((q, k, v, out))
+        self._add(self.lib.pv_attention, p)
+        return out
+
+    def cross_attention(self, q, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, vnorm=None, out=None):
+        if out is None:
+            out = self.empty((batch * nq, heads * d), torch.float16)
+        p = XAttnParams(_ptr(q), _rows(q)[0], _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0],
+                        _rows(vip)[0], _ptr(out), _rows(out)[0], _ptr(vnorm), batch, heads, nq, nt, nip, d, float(w_text), float(w_ip))
+        self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm) if t is not None)
+        self._add(self.lib.pv_cross_attention, p)
+        return out, p
+
+    def geglu(self, x, out=None):
+        ldx, n2 = _rows(x)
+        n = n2 // 2
+        if out is None:
+            out = self.empty((x.shape[0], n), torch.float16)
+        self.keep.extend((x, out))
+        self._add(self.lib.pv_geglu, _ptr(x), ldx, _ptr(out), _rows(out)[0], x.shape[0], n)
+        return out
+
+    def timestep_embedding(self, timesteps, state, rows, dim):
+        out = self.empty((rows, dim), torch.float16)
+        self.keep.extend(t for t in (timesteps, state) if t is not None)
+        self._add(self.lib.pv_timestep_embedding, _ptr(timesteps), _ptr(state), rows, dim, _ptr(out))
+        return out
+
+    def conv_in(self, x, w, bias, *, batch, cin, h, wd, cout):
+        out = self.empty((batch * h * wd, cout), torch.float16)
+        self.keep.extend((x, w, bias))
+        self._add(self.lib.pv_conv_in, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, h, wd, cout)
+        return out
+
+    def conv_out(self, x, w, bias, *, batch, cin, h, wd, cout, out=None):
+        if out is None:
+            out = self.empty((batch, cout, h, wd), torch.float32)
+        self.keep.extend((x, w, bias, out))
+        self._add(self.lib.pv_conv_out, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, h, wd, cout)
+        return out
+
+    def cast_to_f16(self, x, out=None):
+        if out is None:
+            out = self.empty(tuple(x.shape), torch.float16)
+        self.keep.extend((x, out))
+        self._add(self.lib.pv_cast_f32_to_f16, _ptr(x), _ptr(out), x.numel())
+        return out
+
+    def cast_to_f32(self, x, out=None):
+        if out is None:
+            out = self.empty(tuple(x.shape), torch.float32)
+        self.keep.extend((x, out))
+        self._add(self.lib.pv_cast_f16_to_f32, _ptr(x), _ptr(out), x.numel())
+        return out
+
+    def rows_mean(self, x, *, groups, count, out=None, accumulate=False):
+        ldx, cols = _rows(x)
+        if out is None:
+            out = self.empty((groups, cols), torch.float16)
+        self.keep.extend((x, out))
+        self._add(self.lib.pv_rows_mean, _ptr(x), ldx, _ptr(out), _rows(out)[0], groups, count, cols, int(accumulate))
+        return out
+
+    def cfg_dpm_step(self, eps_u, eps_c, latents, x0_prev, coef, state, guidance):
+        self.keep.extend((eps_u, eps_c, latents, x0_prev, coef, state))
+        self._add(self.lib.pv_cfg_dpm_step, _ptr(eps_u), _ptr(eps_c), _ptr(latents), _ptr(x0_prev), _ptr(coef), _ptr(state),
+                  float(guidance), latents.numel())
+
+    def step_advance(self, state):
+        self.keep.append(state)
+        self._add(self.lib.pv_step_advance, _ptr(state))

@@ -1,0 +1,467 @@
+"""SD-v1.5 ``UNet2DConditionModel`` executed by hand-written HIP kernels (gfx950).
+
+Interface mirrored from what the reference uses of diffusers' UNet
+(``/root/reference/models/infer.py:54,103-114``, ``models/unet.py:8-53``,
+``models/modeling_utils.py:24,33,70``): ``unet(sample, t, encoder_hidden_states=(text, ip)).sample``,
+``unet.config.{in_channels,cross_attention_dim,block_out_channels}``, ``unet.attn_processors``,
+``unet.set_attn_processor``, diffusers-compatible ``state_dict`` names (checkpoint layout of
+``save_progress``, ``modeling_utils.py:29-50``).
+
+The ``nn.Module`` tree below only HOLDS parameters (same names / shapes / default init as diffusers);
+none of its modules has an eager ``forward``.  Execution is a static launch plan (``UNetEngine``) over
+NHWC fp16 buffers built once per input shape; see DESIGN.md.  No CPU path exists.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .attention_processor import AttnProcessor2_0, PhotoVerseAttnProcessor2_0
+from .ops import ACT_NONE, ACT_SILU, Recorder, pack_geglu
+
+SD15_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5,
+)
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise NotImplementedError(f"{type(self).__name__} only holds parameters; the HIP engine executes the UNet")
+
+
+class Attention(_Holder):
+    """Parameter holder with the attribute surface PhotoVerse processors read from diffusers' ``Attention``
+    (``attention_processor.py:275-433``)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.inner_dim, self.query_dim = heads, inner, query_dim
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.is_cross_attention = cross_attention_dim is not None
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection, self.rescale_output_factor = False, 1.0
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(self.cross_attention_dim, inner, bias=False)
+        self.to_v = nn.Linear(self.cross_attention_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.processor = AttnProcessor2_0()
+
+    def set_processor(self, processor):
+        if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        # diffusers' Attention.forward: delegate to the installed processor (HIP-backed, standalone path)
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
+
+
+class GEGLU(_Holder):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(_Holder):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
+
+
+class BasicTransformerBlock(_Holder):
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+
+class Transformer2DModel(_Holder):
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups=32):
+        super().__init__()
+        inner = heads * dim_head
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+
+
+class ResnetBlock2D(_Holder):
+    def __init__(self, cin, cout, temb, groups=32, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+
+class Downsample2D(_Holder):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+
+
+class Upsample2D(_Holder):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+
+class DownBlock(_Holder):
+    def __init__(self, cin, cout, temb, layers, heads, xdim, groups, has_attn, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
+        self.has_attn = has_attn
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(heads, cout // heads, cout, xdim, groups) for _ in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
+
+
+class MidBlock(_Holder):
+    def __init__(self, ch, temb, heads, xdim, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb, groups), ResnetBlock2D(ch, ch, temb, groups)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, ch // heads, ch, xdim, groups)])
+
+
+class UpBlock(_Holder):
+    def __init__(self, cin, cout, cprev, temb, layers, heads, xdim, groups, has_attn, add_up):
+        super().__init__()
+        res = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rin = cprev if i == 0 else cout
+            res.append(ResnetBlock2D(rin + skip, cout, temb, groups))
+        self.resnets = nn.ModuleList(res)
+        self.has_attn = has_attn
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(heads, cout // heads, cout, xdim, groups) for _ in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
+
+
+class TimestepEmbedding(_Holder):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(dim, dim)
+
+
+def _f16(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float16).contiguous()
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _conv3_w(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> fp16 [Cout, 3*3*Cin] (tap-major, channel-minor: the implicit-GEMM K order)."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+def _conv1_w(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+class UNetEngine:
+    """Static launch plan of one UNet forward for a fixed (batch, height, width, ip tokens, timestep rows)."""
+
+    def __init__(self, unet: "UNet2DConditionModel", batch: int, h: int, w: int, n_ip: int, t_rows: int, device,
+                 timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
+                 latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
+                 ip: Optional[torch.Tensor] = None):
+        self.unet, self.B, self.H, self.W, self.P, self.NT = unet, batch, h, w, n_ip, n_text
+        cfg = unet.config
+        rec = self.rec = Recorder(device)
+        dev = rec.device
+        xdim = cfg.cross_attention_dim
+        self.x_in = latents_in if latents_in is not None else rec.empty((batch, cfg.in_channels, h, w), torch.float32)
+        self.text = text if text is not None else rec.empty((batch * n_text, xdim))
+        self.ip = ip if ip is not None else rec.empty((batch * n_ip, xdim))
+        self.timesteps = timesteps if timesteps is not None else rec.empty((t_rows,), torch.float32)
+        self.state = state
+        self.t_rows = t_rows
+        self.vnorms: Dict[str, torch.Tensor] = {}
+        self.xattn_params: Dict[str, object] = {}   # per-layer launch records: (w_text, w_ip) are patched per call in grad mode
+        self._build()
+
+    # ------------------------------------------------------------------ blocks
+    def _resnet(self, m: ResnetBlock2D, x, x1, b, h, w, temb_all, toff):
+        rec = self.rec
+        cout = m.conv1.out_channels
+        hn = rec.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=b, hw=h * w, x1=x1, eps=m.norm1.eps, act=ACT_SILU)
+        geo = dict(batch=b, hin=h, win=w, hout=h, wout=w)
+        h1 = rec.gemm(hn, _conv3_w(m.conv1.weight), bias=_f32(m.conv1.bias), rowadd=temb_all[:, toff:toff + cout],
+                      rowadd_ld=(temb_all.stride(0) if self.t_rows > 1 else 0), conv=geo)
+        h2 = rec.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=b, hw=h * w, eps=m.norm2.eps, act=ACT_SILU)
+        if m.conv_shortcut is not None:
+            sc = rec.gemm(x, _conv1_w(m.conv_shortcut.weight), a1=x1, bias=_f32(m.conv_shortcut.bias), rows_per_image=h * w)
+        else:
+            assert x1 is None
+            sc = x
+        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo)
+
+    def _transformer(self, name: str, m: Transformer2DModel, x, b, h, w):
+        rec = self.rec
+        n = h * w
+        blk = m.transformer_blocks[0]
+        C = m.proj_in.out_channels
+        heads = blk.attn1.heads
+        d = C // heads
+        g = rec.groupnorm(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=b, hw=n, eps=m.norm.eps, act=ACT_NONE)
+        hs = rec.gemm(g, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), rows_per_image=n)
+        # --- attn1 (stock AttnProcessor2_0, models/unet.py:20-24) ---
+        a1 = blk.attn1
+        n1 = rec.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
+        wqkv = torch.cat([_f16(a1.to_q.weight), _f16(a1.to_k.weight), _f16(a1.to_v.weight)], 0).contiguous()
+        qkv = rec.gemm(n1, wqkv, rows_per_image=n)
+        sa = rec.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=b, heads=heads, nq=n, nk=n, d=d)
+        hs = rec.gemm(sa, _f16(a1.to_out[0].weight), bias=_f32(a1.to_out[0].bias), residual=hs, rows_per_image=n)
+        # --- attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435) ---
+        a2 = blk.attn2
+        proc = a2.processor
+        n2 = rec.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
+        q = rec.gemm(n2, _f16(a2.to_q.weight), rows_per_image=n)
+        wkv = torch.cat([_f16(a2.to_k.weight), _f16(a2.to_v.weight)], 0).contiguous()
+        kvt = rec.gemm(self.text, wkv, rows_per_image=self.NT)
+        wkvip = torch.cat([_f16(proc.to_k_ip[0].weight), _f16(proc.to_v_ip[0].weight)], 0).contiguous()
+        kvip = rec.gemm(self.ip, wkvip, rows_per_image=self.P)
+        vnorm = rec.empty((b, heads, self.P), torch.float32)
+        self.vnorms[name] = vnorm
+        xa, xp = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n, nt=self.NT,
+                                     nip=self.P, d=d, vnorm=vnorm)
+        self.xattn_params[name] = xp
+        hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
+        # --- GEGLU feed-forward ---
+        n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
+        wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
+        gg = rec.gemm(n3, wg, bias=bg, geglu=True, rows_per_image=n)
+        hs = rec.gemm(gg, _f16(blk.ff.net[2].weight), bias=_f32(blk.ff.net[2].bias), residual=hs, rows_per_image=n)
+        return rec.gemm(hs, _conv1_w(m.proj_out.weight), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n)
+
+    # ------------------------------------------------------------------ plan
+    def _build(self):
+        u, rec, B = self.unet, self.rec, self.B
+        cfg = u.config
+        h, w = self.H, self.W
+        c0 = cfg.block_out_channels[0]
+        # time embedding: sinusoid -> linear_1+SiLU -> linear_2 (+SiLU, the only consumer is time_emb_proj(silu(emb)))
+        te = rec.timestep_embedding(self.timesteps, self.state, self.t_rows, c0)
+        e1 = rec.gemm(te, _f16(u.time_embedding.linear_1.weight), bias=_f32(u.time_embedding.linear_1.bias), act=ACT_SILU)
+        e2 = rec.gemm(e1, _f16(u.time_embedding.linear_2.weight), bias=_f32(u.time_embedding.linear_2.bias), act=ACT_SILU)
+        resnets = [m for m in u.modules() if isinstance(m, ResnetBlock2D)]
+        toffs, off = {}, 0
+        for m in resnets:
+            toffs[id(m)] = off
+            off += m.conv1.out_channels
+        pad = (-off) % 160
+        wt = torch.cat([_f16(m.time_emb_proj.weight) for m in resnets] +
+                       ([torch.zeros(pad, resnets[0].time_emb_proj.in_features, dtype=torch.float16, device=rec.device)] if pad else []), 0)
+        bt = torch.cat([_f32(m.time_emb_proj.bias) for m in resnets] + ([torch.zeros(pad, device=rec.device)] if pad else []), 0)
+        temb_all = rec.gemm(e2, wt.contiguous(), bias=bt.contiguous(), out_f32=True)
+
+        x = rec.conv_in(self.x_in, _f32(u.conv_in.weight), _f32(u.conv_in.bias), batch=B, cin=cfg.in_channels, h=h, wd=w, cout=c0)
+        skips = [(x, h, w)]
+        for bi, blk in enumerate(u.down_blocks):
+            for i, res in enumerate(blk.resnets):
+                x = self._resnet(res, x, None, B, h, w, temb_all, toffs[id(res)])
+                if blk.has_attn:
+                    x = self._transformer(f"down_blocks.{bi}.attentions.{i}", blk.attentions[i], x, B, h, w)
+                skips.append((x, h, w))
+            if blk.downsamplers is not None:
+                conv = blk.downsamplers[0].conv
+                x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
+                             conv=dict(batch=B, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2))
+                h, w = h // 2, w // 2
+                skips.append((x, h, w))
+        mb = u.mid_block
+        x = self._resnet(mb.resnets[0], x, None, B, h, w, temb_all, toffs[id(mb.resnets[0])])
+        x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, B, h, w)
+        x = self._resnet(mb.resnets[1], x, None, B, h, w, temb_all, toffs[id(mb.resnets[1])])
+        for bi, blk in enumerate(u.up_blocks):
+            for i, res in enumerate(blk.resnets):
+                sk, sh, sw = skips.pop()
+                assert (sh, sw) == (h, w)
+                x = self._resnet(res, x, sk, B, h, w, temb_all, toffs[id(res)])   # channel concat [x | skip] is never materialised
+                if blk.has_attn:
+                    x = self._transformer(f"up_blocks.{bi}.attentions.{i}", blk.attentions[i], x, B, h, w)
+            if blk.upsamplers is not None:
+                conv = blk.upsamplers[0].conv
+                x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
+                             conv=dict(batch=B, hin=h, win=w, hout=h * 2, wout=w * 2, upsample=1))
+                h, w = h * 2, w * 2
+        xn = rec.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w,
+                           eps=u.conv_norm_out.eps, act=ACT_SILU)
+        wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
+        self.out = rec.conv_out(xn, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels)
+
+    def run(self):
+        self.rec.run()
+        return self.out
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, **overrides):
+        super().__init__()
+        cfg = dict(SD15_CONFIG)
+        cfg.update(overrides)
+        self.config = SimpleNamespace(**cfg)
+        boc = tuple(cfg["block_out_channels"])
+        heads, xdim, groups, layers = cfg["attention_head_dim"], cfg["cross_attention_dim"], cfg["norm_num_groups"], cfg["layers_per_block"]
+        temb = boc[0] * 4
+        self.conv_in = nn.Conv2d(cfg["in_channels"], boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        self.down_blocks = nn.ModuleList()
+        cout = boc[0]
+        for i, kind in enumerate(cfg["down_block_types"]):
+            cin, cout = cout, boc[i]
+            self.down_blocks.append(DownBlock(cin, cout, temb, layers, heads, xdim, groups, kind.startswith("CrossAttn"), i != len(boc) - 1))
+        self.mid_block = MidBlock(boc[-1], temb, heads, xdim, groups)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        cout = rev[0]
+        for i, kind in enumerate(cfg["up_block_types"]):
+            cprev, cout = cout, rev[i]
+            cin = rev[min(i + 1, len(boc) - 1)]
+            self.up_blocks.append(UpBlock(cin, cout, cprev, temb, layers + 1, heads, xdim, groups, kind.startswith("CrossAttn"), i != len(boc) - 1))
+        self.conv_norm_out = nn.GroupNorm(groups, boc[0], eps=cfg["norm_eps"])
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, padding=1)
+        self._engines: Dict[tuple, UNetEngine] = {}
+
+    # ---- diffusers processor plumbing (models/unet.py:8-47) ----
+    @property
+    def attn_processors(self) -> Dict[str, object]:
+        return {f"{n}.processor": m.get_processor() for n, m in self.named_modules() if isinstance(m, Attention)}
+
+    def set_attn_processor(self, processor):
+        for n, m in self.named_modules():
+            if isinstance(m, Attention):
+                m.set_processor(processor[f"{n}.processor"] if isinstance(processor, dict) else processor)
+        self.repack()
+
+    def repack(self):
+        """Drop cached launch plans (call after changing weights / processors)."""
+        self._engines.clear()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.repack()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._engines = {}
+        return r
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def engine(self, batch, h, w, n_ip, t_rows, **kw) -> UNetEngine:
+        """Launch plan for one input shape.  With ``kw`` (caller-owned static buffers: ``latents_in``, ``text``, ``ip``,
+        ``timesteps``, ``state``) a private, uncached engine is built - used by the graph-captured denoise loop."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("photoverse_amd.UNet2DConditionModel runs on a HIP device only (no CPU path): call .to('cuda')")
+        for proc in self.attn_processors.values():
+            if not isinstance(proc, (AttnProcessor2_0, PhotoVerseAttnProcessor2_0)):
+                raise TypeError(f"unsupported attention processor {type(proc).__name__}")
+        if kw:
+            return UNetEngine(self, batch, h, w, n_ip, t_rows, dev, **kw)
+        key = (batch, h, w, n_ip, t_rows)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = UNetEngine(self, batch, h, w, n_ip, t_rows, dev)
+        return eng
+
+    def _set_fusion(self, eng: UNetEngine):
+        """Per-layer branch weights: (1,1) under no_grad (attention_processor.py:411-412); in grad mode every cross-attn
+        layer draws its own u~U(0,1) per call (:413-420) - host-side, like the reference's ``torch.rand(1).item()``."""
+        for name, m in self.named_modules():
+            if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0):
+                xp = eng.xattn_params[name.rsplit(".transformer_blocks", 1)[0]]
+                xp.w_text, xp.w_ip = m.processor.branch_weights()
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states=None):
+        ops.require_cuda(sample, "sample")
+        if not isinstance(encoder_hidden_states, tuple):
+            raise TypeError("encoder_hidden_states must be the (text, ip) tuple of attention_processor.py:258-262")
+        text, ip = encoder_hidden_states
+        if isinstance(ip, list):
+            ip = ip[0]
+        B, _, h, w = sample.shape
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+        t = t.reshape(-1).to(device=sample.device, dtype=torch.float32)
+        eng = self.engine(B, h, w, ip.shape[1], t.numel())
+        if eng.NT != text.shape[1]:
+            raise ValueError(f"text sequence length {text.shape[1]} != {eng.NT}")
+        eng.x_in.copy_(sample)
+        eng.text.copy_(text.reshape(-1, text.shape[-1]))
+        eng.ip.copy_(ip.reshape(-1, ip.shape[-1]))
+        eng.timesteps.copy_(t)
+        self._set_fusion(eng)
+        out = eng.run()
+        # side output of the PhotoVerse processors (attention_processor.py:397)
+        for name, m in self.named_modules():
+            if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0):
+                key = name.rsplit(".transformer_blocks", 1)[0]
+                m.processor.to_v_ip_norm = eng.vnorms[key].view(B, m.heads, -1, 1)
+        return SimpleNamespace(sample=out.clone().to(sample.dtype))
+
+
+def set_visual_cross_attention_adapter(unet, num_tokens=(5,)):
+    """Same contract as ``/root/reference/models/unet.py:8-35``: attn1 -> stock processor, attn2 ->
+    PhotoVerse processor sized from the block name."""
+    procs = {}
+    boc = unet.config.block_out_channels
+    for name in unet.attn_processors.keys():
+        cross_attention_dim = None if name.endswith("attn1.processor") else unet.config.cross_attention_dim
+        if name.startswith("mid_block"):
+            hidden_size = boc[-1]
+        elif name.startswith("up_blocks"):
+            hidden_size = list(reversed(boc))[int(name[len("up_blocks.")])]
+        elif name.startswith("down_blocks"):
+            hidden_size = boc[int(name[len("down_blocks.")])]
+        if cross_attention_dim is None:
+            procs[name] = AttnProcessor2_0()
+        else:
+            procs[name] = PhotoVerseAttnProcessor2_0(cross_attention_dim=cross_attention_dim, hidden_size=hidden_size, num_tokens=num_tokens)
+    unet.set_attn_processor(procs)
+    dev = unet.device
+    for p in procs.values():
+        if isinstance(p, nn.Module):
+            p.to(dev)
+    return unet
+
+
+def get_visual_cross_attention_values_norm(unet):
+    """``/root/reference/models/unet.py:38-47``."""
+    vals = [p.to_v_ip_norm for n, p in unet.attn_processors.items() if not n.endswith("attn1.processor")]
+    out = torch.stack(vals, dim=1)
+    return out.view(out.shape[0], -1)
+
+
+def set_cross_attention_layers_to_train(unet):
+    """``/root/reference/models/unet.py:50-53``."""
+    for name, module in unet.named_modules():
+        if "attn2" in name:
+            module.train()

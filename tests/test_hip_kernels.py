@@ -1,0 +1,270 @@
+"""GPU parity of every HIP kernel (through the C-ABI) against a plain PyTorch fp32 reference of the same op,
+evaluated on the SAME fp16-rounded inputs.  Tolerances: fp16 storage of the result (2^-11 relative) plus fp32
+accumulation-order noise; stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rec_cls():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from photoverse_amd.ops import Recorder
+    return Recorder
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def h16(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 640, 768), (16, 1280, 1280), (130, 128, 64), (128, 1024, 4096)])
+def test_gemm_bias_residual_act(rec_cls, M, N, K):
+    from photoverse_amd import ops
+    a, w, res = h16(M, K, seed=1), h16(N, K, scale=K ** -0.5, seed=2), h16(M, N, seed=3)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(4))
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_SILU, F.silu), (ops.ACT_QUICK_GELU, lambda x: x * torch.sigmoid(1.702 * x)),
+                    (ops.ACT_LEAKY_RELU, lambda x: F.leaky_relu(x, 0.01))):
+        rec = rec_cls("cuda")
+        out = rec.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), act=act)
+        out32 = rec.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), out_f32=True)
+        rec.run()
+        torch.cuda.synchronize()
+        ref = fn(a.float() @ w.float().t() + bias) + res.float()
+        assert rel_l2(out, ref) < 1e-3
+        assert rel_l2(out32, a.float() @ w.float().t() + bias) < 2e-5     # fp32 store: accumulation noise only
+
+
+def test_gemm_dual_source_and_strided(rec_cls):
+    M, c0, c1, N = 300, 320, 640, 320
+    big0, big1 = h16(M, c0 + 64, seed=5).cuda(), h16(M, c1 + 128, seed=6).cuda()
+    a0, a1 = big0[:, :c0], big1[:, 128:]                      # strided row views
+    w = h16(N, c0 + c1, scale=0.03, seed=7)
+    outbuf = torch.zeros(M, N + 160, dtype=torch.float16, device="cuda")
+    rec = rec_cls("cuda")
+    rec.gemm(a0, w.cuda(), a1=a1, out=outbuf[:, 160:])
+    rec.run()
+    torch.cuda.synchronize()
+    ref = torch.cat([a0.float().cpu(), a1.float().cpu()], 1) @ w.float().t()
+    assert rel_l2(outbuf[:, 160:], ref) < 1e-3
+    assert outbuf[:, :160].abs().max().item() == 0.0
+
+
+def test_gemm_geglu_fused_matches_unfused(rec_cls):
+    from photoverse_amd.ops import pack_geglu
+    M, C = 200, 320
+    x, w = h16(M, C, seed=8), h16(8 * C, C, scale=C ** -0.5, seed=9)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(10))
+    wp, bp = pack_geglu(w.cuda(), b.cuda())
+    rec = rec_cls("cuda")
+    fused = rec.gemm(x.cuda(), wp, bias=bp, geglu=True)
+    proj = rec.gemm(x.cuda(), w.cuda(), bias=b.cuda())
+    unf = rec.geglu(proj)
+    rec.run()
+    torch.cuda.synchronize()
+    h, g = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    ref = h * F.gelu(g)
+    assert rel_l2(fused, ref) < 1e-3
+    assert rel_l2(unf, ref) < 2e-3          # extra fp16 rounding of the projection
+
+
+@pytest.mark.parametrize("cin,cout,h,stride,ups", [(320, 320, 16, 1, 0), (640, 320, 8, 1, 0), (320, 320, 16, 2, 0), (320, 640, 8, 1, 1),
+                                                   (64, 128, 5, 1, 0)])
+def test_conv3x3(rec_cls, cin, cout, h, stride, ups):
+    B = 2
+    x = h16(B, cin, h, h, seed=11)
+    w = h16(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=12)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(13))
+    temb = torch.randn(B, cout, generator=torch.Generator().manual_seed(14))
+    ho = h * 2 if ups else (h // 2 if stride == 2 else h)
+    res = h16(B * ho * ho, cout, seed=15)
+    xin = x.permute(0, 2, 3, 1).reshape(B * h * h, cin).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    rec = rec_cls("cuda")
+    out = rec.gemm(xin, wp, bias=bias.cuda(), rowadd=temb.cuda(), rowadd_ld=cout, residual=res.cuda(),
+                   conv=dict(batch=B, hin=h, win=h, hout=ho, wout=ho, stride=stride, upsample=ups))
+    rec.run()
+    torch.cuda.synchronize()
+    xr = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1) + temb[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * ho * ho, cout) + res.float()
+    assert rel_l2(out, ref) < 1e-3
+
+
+def test_conv3x3_dual_source(rec_cls):
+    B, c0, c1, cout, h = 2, 320, 640, 320, 8
+    x0, x1 = h16(B, c0, h, h, seed=16), h16(B, c1, h, h, seed=17)
+    w = h16(cout, c0 + c1, 3, 3, scale=0.01, seed=18)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * h * h, -1).contiguous().cuda()
+    rec = rec_cls("cuda")
+    out = rec.gemm(rows(x0), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), a1=rows(x1),
+                   conv=dict(batch=B, hin=h, win=h, hout=h, wout=h))
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(torch.cat([x0, x1], 1).float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(B * h * h, cout)
+    assert rel_l2(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize("c0,c1,hw,act", [(320, 0, 64 * 64, 1), (640, 320, 16 * 16, 1), (1280, 1280, 64, 0), (2560, 0, 64, 1), (64, 0, 25, 0)])
+def test_groupnorm(rec_cls, c0, c1, hw, act):
+    B = 2
+    C = c0 + c1
+    x = h16(B, hw, C, seed=19) * 2 + 0.5
+    gamma = torch.randn(C, generator=torch.Generator().manual_seed(20))
+    beta = torch.randn(C, generator=torch.Generator().manual_seed(21))
+    xr = x.reshape(B * hw, C).cuda()
+    rec = rec_cls("cuda")
+    y = rec.groupnorm(xr[:, :c0], gamma.cuda(), beta.cuda(), batch=B, hw=hw, x1=(xr[:, c0:] if c1 else None), eps=1e-5, act=act)
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    if act:
+        ref = F.silu(ref)
+    assert rel_l2(y, ref.reshape(B * hw, C)) < 1e-3
+
+
+@pytest.mark.parametrize("cols", [320, 640, 768, 1024, 1280])
+def test_layernorm(rec_cls, cols):
+    rows = 77
+    x = h16(rows, cols, seed=22) * 3 + 1
+    gamma = torch.randn(cols, generator=torch.Generator().manual_seed(23))
+    beta = torch.randn(cols, generator=torch.Generator().manual_seed(24))
+    rec = rec_cls("cuda")
+    y = rec.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), eps=1e-5)
+    y2 = rec.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), eps=1e-5, act=3)
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.float(), (cols,), gamma, beta, 1e-5)
+    assert rel_l2(y, ref) < 1e-3
+    assert rel_l2(y2, F.leaky_relu(ref, 0.01)) < 1e-3
+
+
+@pytest.mark.parametrize("d,n,causal", [(40, 1024, False), (80, 256, False), (160, 64, False), (160, 256, False), (64, 257, False),
+                                         (64, 77, True), (40, 100, False)])
+def test_self_attention(rec_cls, d, n, causal):
+    B, H = 2, 8
+    C = H * d
+    qkv = h16(B * n, 3 * C, seed=25)
+    dev = qkv.cuda()
+    rec = rec_cls("cuda")
+    out = rec.attention(dev[:, :C], dev[:, C:2 * C], dev[:, 2 * C:], batch=B, heads=H, nq=n, nk=n, d=d, causal=causal)
+    rec.run()
+    torch.cuda.synchronize()
+    q, k, v = [t.float().view(B, n, H, d).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B * n, C)
+    assert rel_l2(out, ref) < 2e-3           # P is rounded to fp16 before the second product
+
+
+def test_self_attention_spiky_rows(rec_cls):
+    """Forces the online-softmax rescale: one key far above the rest, late in the sequence."""
+    B, H, d, n = 1, 8, 40, 512
+    C = H * d
+    qkv = h16(B * n, 3 * C, seed=26)
+    qkv[300, C:2 * C] *= 12.0
+    dev = qkv.cuda()
+    rec = rec_cls("cuda")
+    out = rec.attention(dev[:, :C], dev[:, C:2 * C], dev[:, 2 * C:], batch=B, heads=H, nq=n, nk=n, d=d)
+    rec.run()
+    torch.cuda.synchronize()
+    q, k, v = [t.float().view(B, n, H, d).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * n, C)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("d,n,p,wt,wi", [(40, 4096, 1, 1.0, 1.0), (80, 1024, 5, 1.0, 1.0), (160, 256, 6, 1.0, 1.0), (160, 64, 1, 2.0, 0.0),
+                                          (40, 200, 5, 0.0, 2.0), (80, 64, 16, 1.0, 1.0)])
+def test_cross_attention_dual_branch(rec_cls, d, n, p, wt, wi):
+    B, H, NT = 2, 8, 77
+    C = H * d
+    q, kvt, kvip = h16(B * n, C, seed=27), h16(B * NT, 2 * C, seed=28), h16(B * p, 2 * C, seed=29)
+    dq, dt, di = q.cuda(), kvt.cuda(), kvip.cuda()
+    vn = torch.zeros(B, H, p, device="cuda")
+    rec = rec_cls("cuda")
+    out, _ = rec.cross_attention(dq, dt[:, :C], dt[:, C:], di[:, :C], di[:, C:], batch=B, heads=H, nq=n, nt=NT, nip=p, d=d,
+                                 w_text=wt, w_ip=wi, vnorm=vn)
+    rec.run()
+    torch.cuda.synchronize()
+    hv = lambda t, m: t.float().view(B, m, H, d).transpose(1, 2)
+    qq = hv(q, n)
+    ot = F.scaled_dot_product_attention(qq, hv(kvt[:, :C], NT), hv(kvt[:, C:], NT))
+    vip = hv(kvip[:, C:], p)
+    oi = F.scaled_dot_product_attention(qq, hv(kvip[:, :C], p), vip)
+    ref = (wt * ot + wi * oi).transpose(1, 2).reshape(B * n, C)
+    assert rel_l2(out, ref) < 2e-3
+    torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
+
+
+def test_conv_in_out_timestep(rec_cls):
+    B, h = 2, 16
+    x = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(30))
+    w = torch.randn(320, 4, 3, 3, generator=torch.Generator().manual_seed(31)) * 0.2
+    b = torch.randn(320, generator=torch.Generator().manual_seed(32))
+    rec = rec_cls("cuda")
+    y = rec.conv_in(x.cuda(), w.cuda(), b.cuda(), batch=B, cin=4, h=h, wd=h, cout=320)
+    xo = h16(B, 320, h, h, seed=33)
+    wo = h16(4, 320, 3, 3, scale=0.02, seed=34)
+    bo = torch.randn(4, generator=torch.Generator().manual_seed(35))
+    z = rec.conv_out(xo.permute(0, 2, 3, 1).reshape(-1, 320).contiguous().cuda(), wo.permute(0, 2, 3, 1).reshape(4, -1).contiguous().cuda(),
+                     bo.cuda(), batch=B, cin=320, h=h, wd=h, cout=4)
+    ts = torch.tensor([951.0, 20.0, 500.0])
+    te = rec.timestep_embedding(ts.cuda(), None, 3, 320)
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
+    assert rel_l2(y, ref) < 5e-4
+    refo = F.conv2d(xo.float(), wo.float(), bo, padding=1)
+    assert rel_l2(z, refo) < 1e-5
+    half = 160
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    emb = ts[:, None] * freq[None]
+    reft = torch.cat([emb.cos(), emb.sin()], -1)
+    assert (te.float().cpu() - reft).abs().max().item() < 2e-3      # fp16 output of values in [-1,1]
+
+
+def test_cfg_dpm_step_kernel(rec_cls):
+    n = 2 * 4 * 16 * 16
+    g = torch.Generator().manual_seed(36)
+    eu, ec, x, xp = [torch.randn(n, generator=g) for _ in range(4)]
+    coef = torch.randn(3, 8, generator=g)
+    state = torch.tensor([1], dtype=torch.int32)
+    dx, dxp, dstate = x.cuda(), xp.cuda(), state.cuda()
+    rec = rec_cls("cuda")
+    rec.cfg_dpm_step(eu.cuda(), ec.cuda(), dx, dxp, coef.cuda(), dstate, 7.5)
+    rec.step_advance(dstate)
+    rec.run()
+    torch.cuda.synchronize()
+    e = eu + 7.5 * (ec - eu)
+    ca, cb, cx, c0, c1 = coef[1, :5]
+    x0 = ca * x + cb * e
+    torch.testing.assert_close(dxp.cpu(), x0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx.cpu(), cx * x + c0 * x0 + c1 * xp, rtol=1e-5, atol=1e-5)
+    assert dstate.item() == 2
+
+
+def test_rows_mean(rec_cls):
+    x = h16(3 * 256, 768, seed=37)
+    rec = rec_cls("cuda")
+    y = rec.rows_mean(x.cuda(), groups=3, count=256)
+    rec.run()
+    torch.cuda.synchronize()
+    assert rel_l2(y, x.float().view(3, 256, 768).mean(1)) < 1e-3
+
+
+def test_bad_arguments_fail_loudly(rec_cls):
+    from photoverse_amd.ops import HipLaunchError
+    rec = rec_cls("cuda")
+    a, w = h16(64, 100).cuda(), h16(128, 100).cuda()     # K not a multiple of 64
+    rec.gemm(a, w)
+    with pytest.raises(HipLaunchError):
+        rec.run()

@@ -1,0 +1,96 @@
+"""GPU parity of the HIP UNet / processors against the CPU oracle (same weights via state_dict, same inputs)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+@pytest.fixture(scope="module")
+def tiny_pair():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.unet_ref import TINY_CONFIG, UNet2DConditionModelRef, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    ref = UNet2DConditionModelRef(**TINY_CONFIG).eval()
+    set_visual_cross_attention_adapter_ref(ref, (5,))
+    hip = UNet2DConditionModel(**TINY_CONFIG)
+    set_visual_cross_attention_adapter(hip, (5,))
+    missing = hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.to("cuda")
+    return ref, hip
+
+
+# fp16-storage tolerance for ONE UNet forward vs the fp32 oracle (measured ~2e-3 on random-init weights)
+TOL_FWD = 5e-3
+
+
+@pytest.mark.parametrize("B,hw,P,t", [(1, 16, 1, 500), (2, 16, 5, 981), (2, 32, 1, 20)])
+def test_tiny_unet_forward_matches_oracle(tiny_pair, B, hw, P, t):
+    ref, hip = tiny_pair
+    g = torch.Generator().manual_seed(100 + B + P)
+    x = torch.randn(B, 4, hw, hw, generator=g)
+    text, ip = torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g)
+    with torch.no_grad():
+        exp = ref(x, torch.tensor(t), encoder_hidden_states=(text, ip)).sample
+        got = hip(x.cuda(), torch.tensor(t), encoder_hidden_states=(text.cuda(), ip.cuda())).sample
+    assert got.shape == exp.shape and got.dtype == torch.float32
+    assert rel_l2(got, exp) < TOL_FWD
+    # side output of the 4 PhotoVerse processors (models/unet.py:38-47)
+    from oracle.unet_ref import get_visual_cross_attention_values_norm_ref
+    from photoverse_amd.unet import get_visual_cross_attention_values_norm
+    assert rel_l2(get_visual_cross_attention_values_norm(hip), get_visual_cross_attention_values_norm_ref(ref)) < 2e-3
+
+
+def test_per_sample_timesteps(tiny_pair):
+    ref, hip = tiny_pair
+    g = torch.Generator().manual_seed(7)
+    x, text, ip = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 768, generator=g), torch.randn(2, 5, 768, generator=g)
+    t = torch.tensor([10, 900])
+    with torch.no_grad():
+        exp = ref(x, t, encoder_hidden_states=(text, ip)).sample
+        got = hip(x.cuda(), t.cuda(), encoder_hidden_states=(text.cuda(), ip.cuda())).sample
+    assert rel_l2(got, exp) < TOL_FWD
+
+
+def test_processor_protocol_standalone(tiny_pair):
+    """attention-processor seam: processor(attn, hidden_states, encoder_hidden_states=(text, ip))."""
+    ref, hip = tiny_pair
+    name = "mid_block.attentions.0.transformer_blocks.0.attn2"
+    ra, ha = dict(ref.named_modules())[name], dict(hip.named_modules())[name]
+    g = torch.Generator().manual_seed(8)
+    h, text, ip = torch.randn(2, 64, 640, generator=g), torch.randn(2, 77, 768, generator=g), torch.randn(2, 5, 768, generator=g)
+    with torch.no_grad():
+        exp = ra(h, encoder_hidden_states=(text, ip))
+        got = ha(h.cuda(), encoder_hidden_states=(text.cuda(), ip.cuda()))
+        assert rel_l2(got, exp) < 2e-3
+        assert rel_l2(ha.processor.to_v_ip_norm, ra.processor.to_v_ip_norm) < 1e-3
+        got_list = ha(h.cuda(), encoder_hidden_states=(text.cuda(), [ip.cuda()]))
+        assert torch.equal(got_list, got)
+        got_cat = ha(h.cuda(), encoder_hidden_states=torch.cat([text, ip], 1).cuda())     # deprecated bare-tensor form
+        assert torch.equal(got_cat, got)
+    # grad-mode fusion rule (attention_processor.py:413-420), forced seeds
+    for seed in (0.1, 0.5, 0.9):
+        ra.processor.forced_fusion_seed = ha.processor.forced_fusion_seed = seed
+        exp = ra(h, encoder_hidden_states=(text, ip)).detach()
+        got = ha(h.cuda(), encoder_hidden_states=(text.cuda(), ip.cuda()))
+        assert rel_l2(got, exp) < 2e-3
+    ra.processor.forced_fusion_seed = ha.processor.forced_fusion_seed = None
+    # stock self-attention processor
+    name1 = "mid_block.attentions.0.transformer_blocks.0.attn1"
+    ra1, ha1 = dict(ref.named_modules())[name1], dict(hip.named_modules())[name1]
+    with torch.no_grad():
+        assert rel_l2(ha1(h.cuda()), ra1(h)) < 2e-3
+
+
+def test_cpu_tensor_is_refused(tiny_pair):
+    _, hip = tiny_pair
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        hip(torch.randn(1, 4, 16, 16), torch.tensor(1), encoder_hidden_states=(torch.randn(1, 77, 768), torch.randn(1, 1, 768)))
