@@ -62,6 +62,7 @@ class Recorder:
         if self.device.type != "cuda":
             raise RuntimeError("photoverse_amd: a HIP device is required; there is no CPU path")
         self.calls: List[tuple] = []
+        self.tags: List[tuple] = []        # per call: (kernel name, algorithmic flops, algorithmic bytes)
         self.keep: List[object] = []       # tensors / structs referenced by raw pointer
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
         self.bytes_allocated = 0
@@ -78,9 +79,19 @@ class Recorder:
         return t
 
     # ------------------------------------------------------------------ execution
-    def _add(self, fn, *args):
+    def _add(self, fn, *args, tag=None):
         self.keep.extend(a for a in args if isinstance(a, C.Structure))
         self.calls.append((fn, tuple(C.byref(a) if isinstance(a, C.Structure) else a for a in args)))
+        self.tags.append(tag if tag is not None else (fn.__name__, 0, 0))
+
+    def subset(self, pred) -> "Recorder":
+        """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
+        r = Recorder.__new__(Recorder)
+        r.lib, r.device, r.zero_page, r.keep, r.bytes_allocated = self.lib, self.device, self.zero_page, self.keep, 0
+        sel = [i for i, t in enumerate(self.tags) if pred(t)]
+        r.calls = [self.calls[i] for i in sel]
+        r.tags = [self.tags[i] for i in sel]
+        return r
 
     def run(self, stream: Optional[int] = None):
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
@@ -120,7 +131,10 @@ class Recorder:
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
                        _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), _ptr(self.zero_page))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
-        self._add(self.lib.pv_gemm_conv, p)
+        nf = 4 if geglu else (5 if N % 160 == 0 else 4)
+        kdim = taps * (c0 + c1)
+        name = f"gemm_conv_kernel<{nf},{'true' if conv is not None else 'false'},{'true' if geglu else 'false'}>"
+        self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 
     def groupnorm(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5,

@@ -1,0 +1,121 @@
+"""Graph-captured denoising loop (the hot loop of ``/root/reference/models/infer.py:98-119``) and its batch sharding.
+
+One denoising step = UNet(uncond) + UNet(cond) at batch B (two sequential forwards, ``infer.py:103-114``) + CFG combine
+(``:116``) + ``scheduler.step`` (``:119``).  All of it is a fixed list of allocation-free launches over static buffers,
+so ONE step is captured into a HIP graph and replayed ``T`` times; the per-step scalars (timestep, solver coefficients)
+are read on the device through a step counter the graph itself advances.
+
+Multi-GPU (new - the reference has none): samples are independent, so the batch is sharded over ranks
+with no communication inside the loop; final latents are collected with ONE ``all_gather`` over RCCL.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .ops import Recorder, require_cuda
+from .scheduler import DPMSolverMultistepScheduler
+
+
+class DenoiseLoop:
+    def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
+                 scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True):
+        dev = unet.device
+        if dev.type != "cuda":
+            raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
+        self.unet, self.B, self.S, self.P, self.T = unet, batch, latent_size, n_ip, num_steps
+        self.guidance = float(guidance_scale)
+        sch = scheduler if scheduler is not None else DPMSolverMultistepScheduler()
+        sch.set_timesteps(num_steps)
+        self.scheduler = sch
+        cfg = unet.config
+        xdim = cfg.cross_attention_dim
+        f32, f16 = torch.float32, torch.float16
+        self.latents = torch.zeros((batch, cfg.in_channels, latent_size, latent_size), dtype=f32, device=dev)
+        self.x0_prev = torch.zeros_like(self.latents)
+        self.timesteps = sch.timesteps.to(device=dev, dtype=f32)
+        self.coef = sch.coefficient_table().to(dev)
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.text_c = torch.zeros((batch * n_text, xdim), dtype=f16, device=dev)
+        self.text_u = torch.zeros_like(self.text_c)
+        self.ip_c = torch.zeros((batch * n_ip, xdim), dtype=f16, device=dev)
+        self.ip_u = torch.zeros_like(self.ip_c)
+        kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents, n_text=n_text)
+        self.eng_u = unet.engine(batch, latent_size, latent_size, n_ip, 1, text=self.text_u, ip=self.ip_u, **kw)
+        self.eng_c = unet.engine(batch, latent_size, latent_size, n_ip, 1, text=self.text_c, ip=self.ip_c, **kw)
+        self.tail = Recorder(dev)
+        self.tail.cfg_dpm_step(self.eng_u.out, self.eng_c.out, self.latents, self.x0_prev, self.coef, self.state, self.guidance)
+        self.tail.step_advance(self.state)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = use_graph
+        self.launches_per_step = len(self.eng_u.rec) + len(self.eng_c.rec) + len(self.tail)
+
+    # ------------------------------------------------------------------
+    def set_conditioning(self, cond: Tuple[torch.Tensor, torch.Tensor], uncond: Tuple[torch.Tensor, torch.Tensor]):
+        """cond / uncond = (text (B,77,768), ip (B,P,768)) - the tuples of ``infer.py:106,113``."""
+        for (text, ip), (dt, di) in ((cond, (self.text_c, self.ip_c)), (uncond, (self.text_u, self.ip_u))):
+            require_cuda(text, "text embeddings")
+            dt.copy_(text.reshape(dt.shape))
+            di.copy_(ip.reshape(di.shape))
+
+    def reset(self, noise: torch.Tensor):
+        """latents = noise * init_noise_sigma (``infer.py:70``); step counter to 0."""
+        self.latents.copy_(noise.to(self.latents.device) * self.scheduler.init_noise_sigma)
+        self.x0_prev.zero_()
+        self.state.zero_()
+
+    def _step_eager(self):
+        self.eng_u.rec.run()
+        self.eng_c.rec.run()
+        self.tail.run()
+
+    def capture(self):
+        """Capture one step into a HIP graph.  The capture itself does not execute the step."""
+        if self.graph is not None:
+            return
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream(device=self.latents.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):      # warm the kernels (lazy module load, hipFuncSetAttribute) outside capture
+            keep = (self.latents.clone(), self.x0_prev.clone(), self.state.clone())
+            self._step_eager()
+            self.latents.copy_(keep[0]); self.x0_prev.copy_(keep[1]); self.state.copy_(keep[2])
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_eager()
+        self.graph = g
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._step_eager()
+
+    def run(self, steps: Optional[int] = None) -> torch.Tensor:
+        for _ in range(self.T if steps is None else steps):
+            self.step()
+        return self.latents
+
+
+def shard_batch(total: int, rank: int, world: int) -> slice:
+    """Contiguous, even split of the global batch (ranks must divide it)."""
+    if total % world:
+        raise ValueError(f"global batch {total} is not divisible by world size {world}")
+    per = total // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def gather_latents(local: torch.Tensor, world: int) -> torch.Tensor:
+    """The single collective of the multi-GPU path: all_gather of the final latents (RCCL over xGMI on GPUs,
+    gloo in the CPU tests).  Rank order == batch order, so the result equals the 1-GPU run sample for sample."""
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
