@@ -156,18 +156,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qi][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = pv_quad_max(mx);
             const float m_new = fmaxf(m_run[qi], mx * sc);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run[qi] - m_use);
+            const float alpha = PV_EXP2(m_run[qi] - m_use);
             m_run[qi] = m_new;
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(fmaf(s[kb][qi][r], sc, -m_use));
+                    const float e = PV_EXP2(fmaf(s[kb][qi][r], sc, -m_use));
                     rs += e;
                     s[kb][qi][r] = e;
                 }
@@ -195,10 +194,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
     half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        float l = l_run[qi];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / pv_quad_sum(l_run[qi]);
         if (qrow[qi] < p.nq) {
 #pragma unroll
             for (int f = 0; f < C::DVF; ++f) {
@@ -311,10 +307,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
                 if (key < p.nt) mt = fmaxf(mt, v);
                 if (key >= IP0 && key < IP0 + p.nip) mi = fmaxf(mi, v);
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        mi = fmaxf(mi, __shfl_xor(mi, 16, 64));
-        mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
+        mt = pv_quad_max(mt);
+        mi = pv_quad_max(mi);
         float lt = 0.f, li = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -325,18 +319,16 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
                 const bool is_i = key >= IP0 && key < IP0 + p.nip;
                 float e = 0.f;
                 if (is_t) {
-                    e = exp2f((s[kb][qi][r] - mt) * sc);
+                    e = PV_EXP2((s[kb][qi][r] - mt) * sc);
                     lt += e;
                 } else if (is_i) {
-                    e = exp2f((s[kb][qi][r] - mi) * sc);
+                    e = PV_EXP2((s[kb][qi][r] - mi) * sc);
                     li += e;
                 }
                 s[kb][qi][r] = e;
             }
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
-        li += __shfl_xor(li, 16, 64);
-        li += __shfl_xor(li, 32, 64);
+        lt = pv_quad_sum(lt);
+        li = pv_quad_sum(li);
         const float ft = p.w_text / lt, fi = p.w_ip / li;
 #pragma unroll
         for (int s2 = 0; s2 < NKB / 2; ++s2)

@@ -25,6 +25,11 @@ __device__ __forceinline__ void pv_glds16(const void* gsrc, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds(PV_GLOBAL_PTR(gsrc), PV_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+#ifdef PV_SLOW_EXP
+#define PV_EXP2(x) exp2f(x)
+#else
+#define PV_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 __device__ __forceinline__ float pv_silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float pv_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float pv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -47,6 +52,39 @@ __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Reductions across the 4 lanes {l, l^16, l^32, l^48} that share (lane & 15), as pure VALU lane swaps
+// (v_permlane16_swap / v_permlane32_swap) - no LDS round trip like ds_bpermute.
+// NOTE: the two results are copied into scalars before the bit cast: __builtin_bit_cast applied directly to an
+// element expression of the builtin's vector result (a[1]) reads element 0 (clang 22 / ROCm 7.2).
+__device__ __forceinline__ void pv_swap16(float v, float& x, float& y) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    x = __builtin_bit_cast(float, a0);
+    y = __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ void pv_swap32(float v, float& x, float& y) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    x = __builtin_bit_cast(float, a0);
+    y = __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ float pv_quad_max(float v) {
+    float x, y;
+    pv_swap16(v, x, y);
+    v = fmaxf(x, y);
+    pv_swap32(v, x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float pv_quad_sum(float v) {
+    float x, y;
+    pv_swap16(v, x, y);
+    v = x + y;
+    pv_swap32(v, x, y);
+    return x + y;
 }
 
 // XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): consecutive remapped ids share an XCD/L2.

@@ -15,19 +15,38 @@
 // barrier per K-step, 2 workgroups per CU.
 #include "pv_common.h"
 
+#ifndef PV_ABLATE
+#define PV_ABLATE 0   // 1/2/3: timing-only builds (wrong results), see tools/ablate.sh
+#endif
+#ifndef PV_FORCE_WM
+#define PV_FORCE_WM 0 // 2 or 4: force the tile variant (experiments)
+#endif
+
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
 
-template <int NF>
+// kernel-side parameter block: the C-ABI struct + byte extents of the three buffer descriptors
+struct pv_gemm_params_dev : pv_gemm_params {
+    uint32_t a0_bytes, a1_bytes, w_bytes;
+};
+
+// WM = waves along M (each wave owns 64 rows): WM=2 -> 128-row tile, 4 waves, 2 LDS stages, 2 workgroups / CU
+//                                              WM=4 -> 256-row tile, 8 waves, 3 LDS stages (prefetch distance 2), 1 / CU
+template <int NF, int WM>
 struct TileCfg {
+    static constexpr int BM = WM * 64;
     static constexpr int BN = NF * 32;
+    static constexpr int NWAVES = WM * 2;
+    static constexpr int THREADS = NWAVES * 64;
+    static constexpr int STAGES = WM == 4 ? 3 : 2;
     static constexpr int A_BYTES = BM * ROW_BYTES;
     static constexpr int B_BYTES = BN * ROW_BYTES;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+    static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int B_PIECES = NF * 4;                                   // 8-row LDS-DMA pieces of the weight tile
+    static constexpr int B_PER_WAVE = (B_PIECES + NWAVES - 1) / NWAVES;       // max pieces any wave issues
 };
 
 // activations allowed in the GEMM epilogue (erf-GELU only exists in the GEGLU instantiation)
@@ -42,10 +61,23 @@ __device__ __forceinline__ half8_t lds_frag(const char* base, int row, int chunk
     return *reinterpret_cast<const half8_t*>(base + row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
 }
 
-template <int NF, bool CONV, bool GEGLU>
-__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params p, const int tiles_n, const int nblk,
-                                                            const int m_fast) {
-    using Cfg = TileCfg<NF>;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else static_assert(N < 0, "add the immediate");
+}
+
+template <int NF, int WM, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
+                                                                              const int nblk, const int m_fast) {
+    using Cfg = TileCfg<NF, WM>;
+    constexpr int BM = Cfg::BM;
+    constexpr int NW = Cfg::NWAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = pv_lane_id();
@@ -60,69 +92,97 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params 
     const int cin = p.c0 + p.c1;
     const int K = p.taps * cin;
     const int nk = K / BK;
-    const int cpt = cin / BK;  // K-chunks per tap
 
     // ---- per-thread staging geometry ------------------------------------------------------
+    // All global->LDS traffic is `buffer_load_dwordx4 ... lds` through raw buffer descriptors: a lane whose source is
+    // padding (out-of-image filter tap, M tail) gets an out-of-range offset and the hardware range check writes
+    // zeros - no branches, no zero page, and the per-K-step address math is one add + one select per piece.
     const int lrow = lane >> 3;                 // row inside the 8-row piece
     const int src_chunk = (lane & 7) ^ lrow;    // swizzled source chunk (row & 7 == lrow)
-    // A: 4 pieces per wave; row r = (wave*4+i)*8 + lrow
-    int a_b[4], a_y[4], a_x[4];
-    bool a_ok[4];
+    const int lane_cc2 = src_chunk * 16;        // byte offset of this lane's 16-B chunk inside the 64-channel slab
+    constexpr unsigned OOB = 0x80000000u;       // >= num_records of every descriptor (launcher checks sizes < 2 GiB)
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int hw_out = p.hout * p.wout;
+    const bool fast_conv = CONV && p.stride == 1 && !p.upsample;
+    const int hl = p.upsample ? p.hin * 2 : p.hin;
+    const int wl = p.upsample ? p.win * 2 : p.win;
+    // A: 4 pieces per wave; piece j = wave + i*NW covers tile rows [8j, 8j+8)
+    unsigned a_off0[4], a_off1[4];   // byte offset of the row (centre pixel for convs) in source 0 / 1, + lane chunk
+    unsigned a_mask[4];              // conv: bit t set <=> filter tap t reads inside the image
+    int a_b[4], a_y[4], a_x[4];      // generic (strided / upsampled) conv path only
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (wave * 4 + i) * 8 + lrow;
-        a_ok[i] = m < p.M;
+        const int m = m0 + (wave + i * NW) * 8 + lrow;
+        const bool ok = m < p.M;
         if (CONV) {
             const int b = m / hw_out;
             const int rem = m - b * hw_out;
-            a_b[i] = b;
-            a_y[i] = rem / p.wout;
-            a_x[i] = rem - a_y[i] * p.wout;
+            const int y = rem / p.wout, x = rem - y * p.wout;
+            a_b[i] = b; a_y[i] = y * p.stride; a_x[i] = x * p.stride;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = a_y[i] + t / 3 - 1, ix = a_x[i] + t % 3 - 1;
+                if (ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl) mask |= 1u << t;
+            }
+            a_mask[i] = mask;
+            const unsigned pix = (unsigned)((b * p.hin + y) * p.win + x);     // centre pixel (fast path: hin==hout)
+            a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
+            a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
         } else {
-            a_b[i] = m;
-            a_y[i] = 0;
-            a_x[i] = 0;
+            a_mask[i] = ok ? 1u : 0u;
+            a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
+            a_off1[i] = ok ? (unsigned)m * (unsigned)(p.lda1 * 2) + lane_cc2 : OOB;
+            a_b[i] = a_y[i] = a_x[i] = 0;
         }
     }
-    const half_t* wrow[NF];
+    // B: piece j = wave + i*NW < B_PIECES covers weight-tile rows [8j, 8j+8)
+    unsigned w_off[Cfg::B_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int n = n0 + (wave * NF + i) * 8 + lrow;
-        wrow[i] = reinterpret_cast<const half_t*>(p.w) + (size_t)n * K + src_chunk * 8;
+    for (int i = 0; i < Cfg::B_PER_WAVE; ++i) {
+        const int n = n0 + min(wave + i * NW, Cfg::B_PIECES - 1) * 8 + lrow;
+        w_off[i] = (unsigned)n * (unsigned)(K * 2) + lane_cc2;
     }
-    const half_t* zero = reinterpret_cast<const half_t*>(p.zero_page) + src_chunk * 8;
-    const int hl = p.upsample ? p.hin * 2 : p.hin;
-    const int wl = p.upsample ? p.win * 2 : p.win;
+    // number of LDS-DMA instructions this wave issues per stage (for the counted vmcnt)
+    const bool b_full = (Cfg::B_PIECES % NW == 0) || (wave + (Cfg::B_PER_WAVE - 1) * NW < Cfg::B_PIECES);
 
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * Cfg::STAGE_BYTES;
         char* sb = sa + Cfg::A_BYTES;
-        const int tap = CONV ? kt / cpt : 0;
-        const int c = (kt - tap * cpt) * BK;          // channel offset inside the (concatenated) input
+        // K order: channel-chunk major, filter-tap minor.  The 9 taps of one 64-channel slab re-read (shifted) the same
+        // input rows in consecutive K-steps, so the im2col re-reads hit L1/L2 instead of going back to HBM/MALL.
+        const int chunk = CONV ? kt / 9 : kt;
+        const int tap = CONV ? kt - chunk * 9 : 0;
+        const int c = chunk * BK;                     // channel offset inside the (concatenated) input
         const bool first = c < p.c0;
-        const half_t* src = reinterpret_cast<const half_t*>(first ? p.a0 : p.a1);
-        const int ld = first ? p.lda0 : p.lda1;
-        const int cc = (first ? c : c - p.c0) + src_chunk * 8;
+        const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
+        const int ld2 = (first ? p.lda0 : p.lda1) * 2;
+        const int sc2 = (first ? c : c - p.c0) * 2;   // scalar byte offset of the slab inside the source row
         const int ky = tap / 3, kx = tap - ky * 3;
+        const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;   // fast path: centre pixel -> tap pixel
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const half_t* g;
-            if (CONV) {
-                const int iy = a_y[i] * p.stride + ky - 1;
-                const int ix = a_x[i] * p.stride + kx - 1;
-                const bool ok = a_ok[i] && iy >= 0 && iy < hl && ix >= 0 && ix < wl;
-                const int py = p.upsample ? iy >> 1 : iy;
-                const int px = p.upsample ? ix >> 1 : ix;
-                const size_t pix = (size_t)(a_b[i] * p.hin + py) * p.win + px;
-                g = ok ? src + pix * ld + cc : zero;
+            unsigned off;
+            if (!CONV) {
+                off = (first ? a_off0[i] : a_off1[i]) + (unsigned)sc2;   // OOB rows stay out of range (sc2 < 2^16)
+            } else if (fast_conv) {
+                off = ((a_mask[i] >> tap) & 1u) ? (first ? a_off0[i] : a_off1[i]) + (unsigned)tap_delta : OOB;
             } else {
-                g = a_ok[i] ? src + (size_t)a_b[i] * ld + cc : zero;
+                const int iy = a_y[i] + ky - 1, ix = a_x[i] + kx - 1;
+                const int py = p.upsample ? iy >> 1 : iy, px = p.upsample ? ix >> 1 : ix;
+                const unsigned pix = (unsigned)((a_b[i] * p.hin + py) * p.win + px);
+                off = ((a_mask[i] >> tap) & 1u) ? pix * (unsigned)ld2 + (unsigned)(sc2 + lane_cc2) : OOB;
             }
-            pv_glds16(g, sa + (wave * 4 + i) * 8 * ROW_BYTES);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * NW) * 8 * ROW_BYTES), 16, (int)off, 0, 0, 0);
         }
+        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) pv_glds16(wrow[i] + (size_t)kt * BK, sb + (wave * NF + i) * 8 * ROW_BYTES);
+        for (int i = 0; i < Cfg::B_PER_WAVE; ++i) {
+            if (i < Cfg::B_PER_WAVE - 1 || b_full)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + i * NW) * 8 * ROW_BYTES), 16, (int)(w_off[i] + wk2), 0, 0, 0);
+        }
     };
 
     // ---- accumulators: acc[ni][mi], D[i = n][j = m] ----------------------------------------
@@ -135,15 +195,34 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params 
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    constexpr int PRE = Cfg::STAGES - 1;  // prefetch distance in K-steps
+#pragma unroll
+    for (int s = 0; s < PRE; ++s)
+        if (s < nk) stage(s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const char* sa = smem + cur * Cfg::STAGE_BYTES;
+        // stage kt has landed once at most the loads of the (PRE-1) younger stages are still outstanding
+        if (PRE == 1 || kt + 1 >= nk) {
+            wait_vmcnt<0>();
+        } else if (b_full) {
+            wait_vmcnt<(4 + Cfg::B_PER_WAVE) * (PRE - 1)>();
+        } else {
+            wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1) * (PRE - 1)>();
+        }
+        // one barrier per K-step: (a) every wave's pieces of stage kt are visible, (b) every wave has finished reading the
+        // buffer of step kt-1, which the prefetch below overwrites.  Raw s_barrier: __syncthreads() would drain vmcnt.
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if PV_ABLATE == 2   // timing experiment: no global->LDS traffic after the prologue
+        if (kt + PRE < nk && kt < 0) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
+#else
+        if (kt + PRE < nk) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
+#endif
+        const char* sa = smem + (kt % Cfg::STAGES) * Cfg::STAGE_BYTES;
         const char* sb = sa + Cfg::A_BYTES;
+#if PV_ABLATE == 3   // timing experiment: DMA only
+        if (kt >= 0) continue;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8_t xa[4], wb[NF];
@@ -151,14 +230,19 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params 
             for (int mi = 0; mi < 4; ++mi) xa[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, ks * 4 + fq);
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
+#if PV_ABLATE == 1   // timing experiment: LDS reads without the MFMAs
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa[mi]));
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb[ni]));
+#else
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+#endif
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -214,42 +298,61 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params 
     }
 }
 
-template <int NF, bool CONV, bool GEGLU>
-int launch(const pv_gemm_params& p, hipStream_t stream) {
-    using Cfg = TileCfg<NF>;
+template <int NF, int WM, bool CONV, bool GEGLU>
+int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
+    using Cfg = TileCfg<NF, WM>;
     static bool attr_set = false;
-    auto kern = gemm_conv_kernel<NF, CONV, GEGLU>;
+    auto kern = gemm_conv_kernel<NF, WM, CONV, GEGLU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = p.N / Cfg::BN;
     const int nblk = tiles_m * tiles_n;
     // XCD footprint heuristic: walk M fastest when the weight panel is too big to sit in every XCD's L2
     const size_t wbytes = (size_t)p.N * p.taps * (p.c0 + p.c1) * 2;
     const int m_fast = (wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
     return PV_CHECK_LAUNCH();
+}
+
+// Tile choice.  Measured on MI355X (profiles/r01_ablate_gemm.txt): the 128-row / 4-wave / 2-workgroups-per-CU variant
+// beats the 256-row / 8-wave / 3-stage one on every UNet shape (two independent workgroups de-synchronise and overlap
+// each other's DMA waits; eight lock-stepped waves do not), so the 256-row instantiation is kept for experiments only.
+template <int NF, bool CONV, bool GEGLU>
+int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
+    if (PV_FORCE_WM == 4) return launch<NF, 4, CONV, GEGLU>(p, stream);
+    return launch<NF, 2, CONV, GEGLU>(p, stream);
 }
 
 }  // namespace
 
 extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
-    const pv_gemm_params& p = *pp;
+    pv_gemm_params_dev p;
+    static_cast<pv_gemm_params&>(p) = *pp;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int cin = p.c0 + p.c1;
-    if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || !p.zero_page || p.act == PV_ACT_GELU ||
+    if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU ||
         !p.a0 || !p.w || !p.out || (p.c1 && !p.a1) || p.hout * p.wout <= 0)
         return (int)hipErrorInvalidValue;
+    {
+        const size_t a_rows = p.taps == 9 ? (size_t)p.batch * p.hin * p.win : (size_t)p.M;
+        const size_t b0 = ((a_rows - 1) * p.lda0 + p.c0) * 2, b1 = p.c1 ? ((a_rows - 1) * p.lda1 + p.c1) * 2 : 0;
+        const size_t bw = (size_t)p.N * p.taps * cin * 2;
+        if (b0 >= (1ull << 31) || b1 >= (1ull << 31) || bw >= (1ull << 31)) return (int)hipErrorInvalidValue;
+        p.a0_bytes = (uint32_t)b0;
+        p.a1_bytes = (uint32_t)b1;
+        p.w_bytes = (uint32_t)bw;
+    }
     if (p.geglu) {
         if (p.taps != 1 || (p.N % 128)) return (int)hipErrorInvalidValue;
-        return launch<4, false, true>(p, stream);
+        return dispatch<4, false, true>(p, stream);
     }
     const bool conv = p.taps == 9;
-    if (p.N % 160 == 0) return conv ? launch<5, true, false>(p, stream) : launch<5, false, false>(p, stream);
-    if (p.N % 128 == 0) return conv ? launch<4, true, false>(p, stream) : launch<4, false, false>(p, stream);
+    if (p.N % 160 == 0) return conv ? dispatch<5, true, false>(p, stream) : dispatch<5, false, false>(p, stream);
+    if (p.N % 128 == 0) return conv ? dispatch<4, true, false>(p, stream) : dispatch<4, false, false>(p, stream);
     return (int)hipErrorInvalidValue;
 }

@@ -12,12 +12,10 @@ __device__ __forceinline__ half8_t gn_load(const pv_groupnorm_params& p, size_t 
 }
 
 __global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass) {
-    extern __shared__ float sh[];  // [2][C]
+    extern __shared__ float sh[];  // [rows_per_pass][2][C] per-thread partials, reduced in a fixed order (deterministic)
     const int C = p.c0 + p.c1;
     const int b = blockIdx.y, s = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
-    __syncthreads();
     const int chunk = tid % nchunk, r = tid / nchunk;
     const int pps = p.hw / p.splits;
     float sum[8], sq[8];
@@ -33,18 +31,22 @@ __global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, c
             sq[j] += f * f;
         }
     }
+    float* mine = sh + (size_t)r * 2 * C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        atomicAdd(&sh[chunk * 8 + j], sum[j]);
-        atomicAdd(&sh[C + chunk * 8 + j], sq[j]);
+        mine[chunk * 8 + j] = sum[j];
+        mine[C + chunk * 8 + j] = sq[j];
     }
     __syncthreads();
     if (tid < p.groups) {
         const int cpg = C / p.groups;
         float a = 0.f, q = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            a += sh[c];
-            q += sh[C + c];
+        for (int rr = 0; rr < rows_per_pass; ++rr) {
+            const float* src = sh + (size_t)rr * 2 * C;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                a += src[c];
+                q += src[C + c];
+            }
         }
         float* out = p.partial + (((size_t)b * p.splits + s) * p.groups + tid) * 2;
         out[0] = a;
@@ -178,7 +180,7 @@ extern "C" int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream) {
     if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->x0) return (int)hipErrorInvalidValue;
     const int C = p->c0 + p->c1;
     if (threads < p->groups) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(p->splits, p->batch), dim3(threads), 2 * C * sizeof(float), (hipStream_t)stream, *p,
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(p->splits, p->batch), dim3(threads), (size_t)rpp * 2 * C * sizeof(float), (hipStream_t)stream, *p,
                        nchunk, rpp);
     return PV_CHECK_LAUNCH();
 }

@@ -28,7 +28,9 @@ def h16(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).half()
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 640, 768), (16, 1280, 1280), (130, 128, 64), (128, 1024, 4096)])
+# the last three shapes give >= 256 tiles of 256 rows and take the 8-wave / 3-stage instantiation (incl. an M tail)
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 640, 768), (16, 1280, 1280), (130, 128, 64), (128, 1024, 4096),
+                                   (16384, 640, 640), (32700, 320, 64), (8192, 1024, 128)])
 def test_gemm_bias_residual_act(rec_cls, M, N, K):
     from photoverse_amd import ops
     a, w, res = h16(M, K, seed=1), h16(N, K, scale=K ** -0.5, seed=2), h16(M, N, seed=3)
@@ -78,10 +80,10 @@ def test_gemm_geglu_fused_matches_unfused(rec_cls):
     assert rel_l2(unf, ref) < 2e-3          # extra fp16 rounding of the projection
 
 
-@pytest.mark.parametrize("cin,cout,h,stride,ups", [(320, 320, 16, 1, 0), (640, 320, 8, 1, 0), (320, 320, 16, 2, 0), (320, 640, 8, 1, 1),
-                                                   (64, 128, 5, 1, 0)])
-def test_conv3x3(rec_cls, cin, cout, h, stride, ups):
-    B = 2
+@pytest.mark.parametrize("cin,cout,h,stride,ups,B", [(320, 320, 16, 1, 0, 2), (640, 320, 8, 1, 0, 2), (320, 320, 16, 2, 0, 2),
+                                                     (320, 640, 8, 1, 1, 2), (64, 128, 5, 1, 0, 2),
+                                                     (64, 320, 64, 1, 0, 8), (128, 128, 32, 1, 1, 4)])   # 256-row tile path
+def test_conv3x3(rec_cls, cin, cout, h, stride, ups, B):
     x = h16(B, cin, h, h, seed=11)
     w = h16(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=12)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(13))

@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark (HIP events on the launch stream) over the shapes of the bs=16, 64x64 UNet.
+Usage on the GPU box: python tools/kbench.py [filter]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from photoverse_amd.ops import Recorder, pack_geglu  # noqa: E402
+
+dev = torch.device("cuda")
+B = 16
+
+
+def h16(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).half()
+
+
+def timeit(rec, reps=10):
+    rec.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rec.run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+cases = []
+
+
+def conv(name, cin, cout, hw, c1=0, stride=1, ups=0):
+    def f():
+        rec = Recorder(dev)
+        x = h16(B * hw * hw, cin)
+        x1 = h16(B * hw * hw, c1) if c1 else None
+        w = h16(cout, 9 * (cin + c1), scale=0.02)
+        ho = hw * 2 if ups else hw // stride
+        rec.gemm(x, w, a1=x1, bias=torch.zeros(cout, device=dev), conv=dict(batch=B, hin=hw, win=hw, hout=ho, wout=ho, stride=stride, upsample=ups))
+        return rec, 2.0 * B * ho * ho * cout * 9 * (cin + c1), 0
+    cases.append((name, f))
+
+
+def gemm(name, M, K, N, geglu=False, res=True):
+    def f():
+        rec = Recorder(dev)
+        x, w = h16(M, K), h16(N, K, scale=0.02)
+        b = torch.zeros(N, device=dev)
+        if geglu:
+            w, b = pack_geglu(w, b)
+        r = h16(M, N) if (res and not geglu) else None
+        rec.gemm(x, w, bias=b, residual=r, geglu=geglu)
+        byts = 2.0 * (M * K + N * K + M * (N // 2 if geglu else N) * (2 if r is not None else 1))
+        return rec, 2.0 * M * N * K, byts
+    cases.append((name, f))
+
+
+def attn(name, d, n):
+    def f():
+        rec = Recorder(dev)
+        C = 8 * d
+        qkv = h16(B * n, 3 * C)
+        rec.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=B, heads=8, nq=n, nk=n, d=d)
+        return rec, 4.0 * B * n * n * C, 0
+    cases.append((name, f))
+
+
+def xattn(name, d, n, p=1):
+    def f():
+        rec = Recorder(dev)
+        C = 8 * d
+        q, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
+        rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, nq=n, nt=77, nip=p, d=d)
+        return rec, 4.0 * B * n * (77 + p) * C, 2.0 * 2 * B * n * C
+    cases.append((name, f))
+
+
+def gn(name, c, hw):
+    def f():
+        rec = Recorder(dev)
+        x = h16(B * hw * hw, c)
+        rec.groupnorm(x, torch.ones(c, device=dev), torch.zeros(c, device=dev), batch=B, hw=hw * hw, act=1)
+        return rec, 0, 2.0 * 3 * B * hw * hw * c
+    cases.append((name, f))
+
+
+def ln(name, c, rows):
+    def f():
+        rec = Recorder(dev)
+        x = h16(rows, c)
+        rec.layernorm(x, torch.ones(c, device=dev), torch.zeros(c, device=dev))
+        return rec, 0, 2.0 * 2 * rows * c
+    cases.append((name, f))
+
+
+conv("conv3 320->320 @64", 320, 320, 64)
+conv("conv3 640+320->320 @64 (dual)", 640, 320, 64, c1=320)
+conv("conv3 320->320 @64 s2", 320, 320, 64, stride=2)
+conv("conv3 640->640 @32", 640, 640, 32)
+conv("conv3 320->640 @32", 320, 640, 32)
+conv("conv3 640->640 @32 up", 640, 640, 32, ups=1)
+conv("conv3 1280->1280 @16", 1280, 1280, 16)
+conv("conv3 1280+1280->1280 @16", 1280, 1280, 16, c1=1280)
+conv("conv3 1280->1280 @8", 1280, 1280, 8)
+conv("conv3 1280+1280->1280 @8", 1280, 1280, 8, c1=1280)
+gemm("gemm 65536x320->320", 65536, 320, 320)
+gemm("gemm 65536x320->960 (qkv)", 65536, 320, 960, res=False)
+gemm("gemm 65536x1280->320 (ff2)", 65536, 1280, 320)
+gemm("geglu 65536x320->2560", 65536, 320, 2560, geglu=True)
+gemm("gemm 16384x640->640", 16384, 640, 640)
+gemm("geglu 16384x640->5120", 16384, 640, 5120, geglu=True)
+gemm("gemm 16384x2560->640 (ff2)", 16384, 2560, 640)
+gemm("gemm 4096x1280->1280", 4096, 1280, 1280)
+gemm("geglu 4096x1280->10240", 4096, 1280, 10240, geglu=True)
+gemm("gemm 4096x5120->1280 (ff2)", 4096, 5120, 1280)
+gemm("gemm 1232x768->640 (text kv)", 1232, 768, 640, res=False)
+attn("attn d40 n4096", 40, 4096)
+attn("attn d80 n1024", 80, 1024)
+attn("attn d160 n256", 160, 256)
+xattn("xattn d40 n4096", 40, 4096)
+xattn("xattn d80 n1024", 80, 1024)
+gn("gn+silu 320 @64", 320, 64)
+gn("gn+silu 1280 @16", 1280, 16)
+ln("ln 320 x65536", 320, 65536)
+
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+print(f"{'case':40s} {'us':>10s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+for name, f in cases:
+    if flt and flt not in name:
+        continue
+    rec, flops, byts = f()
+    us = timeit(rec)
+    print(f"{name:40s} {us:10.1f} {flops / us / 1e6:9.1f} {byts / us / 1e3:9.1f}")
+    del rec
+    torch.cuda.empty_cache()
