@@ -169,9 +169,27 @@ int pv_step_advance(int32_t* state, void* stream);
 int pv_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 int pv_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
 /* mean over `count` consecutive rows: x fp16 [groups*count][cols] -> y fp16 [groups][cols]
- * (adapters.py:36 mean over the 256 patch tokens); y may be accumulated (+=) when accumulate!=0 */
-int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t cols,
-                 int32_t accumulate, void* stream);
+ * (adapters.py:36 mean over the 256 patch tokens); group g starts at row g*group_rows (group_rows >= count);
+ * y may be accumulated (+=) when accumulate!=0 */
+int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t group_rows,
+                 int32_t cols, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pre-loop conditioning front ends (infer.py:76-96).
+ */
+/* CLIP ViT patch embedding input: NCHW fp32 pixels -> fp16 rows [B*(img/patch)^2][kpad], one patch per row in
+ * (channel, py, px) order = the flattened Conv2d(3,dim,patch,stride=patch) weight order, zero padded to kpad
+ * (kpad % 64 == 0) so the patch embedding is a pv_gemm_conv call.  [EXT transformers CLIPVisionEmbeddings] */
+int pv_patchify(const float* x, void* out, int32_t batch, int32_t ch, int32_t img, int32_t patch, int32_t kpad, void* stream);
+/* out[b][0] = cls + pos[0]; out[b][1+i] = patches[b][i] + pos[1+i]  (fp16 rows [B*ntok][dim]) */
+int pv_clip_vision_embed(const void* patches, const float* cls, const float* pos, void* out, int32_t batch, int32_t ntok,
+                         int32_t dim, void* stream);
+/* Token + position embedding of the CLIP text encoder with PhotoVerse's concept injection fused
+ * (models/clip.py:17-24 _inject_concept_embeddings, :57-63): per row the placeholder position
+ * placeholder_idx[b] is overwritten by n_concept concept embeddings and the tail is shifted right by
+ * n_concept-1 (truncated).  n_concept == 0: stock embedding.  ids/placeholder_idx int64, tok/pos fp32, out fp16. */
+int pv_clip_text_embed(const int64_t* ids, const float* tok, const float* pos, const void* concept, const int64_t* placeholder_idx,
+                       int32_t n_concept, void* out, int32_t batch, int32_t seq, int32_t dim, void* stream);
 
 #ifdef __cplusplus
 }

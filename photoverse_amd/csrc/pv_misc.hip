@@ -155,7 +155,8 @@ __global__ void cast_f16_f32_kernel(const half_t* x, float* y, long n) {
     if (i < n) y[i] = (float)x[i];
 }
 
-__global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, int groups, int count, int cols, int accumulate) {
+__global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, int groups, int count, int group_rows, int cols,
+                                 int accumulate) {
     const int nchunk = cols >> 3;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= groups * nchunk) return;
@@ -164,7 +165,7 @@ __global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     for (int r = 0; r < count; ++r) {
-        const half8_t v = *reinterpret_cast<const half8_t*>(x + ((long)g * count + r) * ldx + ch * 8);
+        const half8_t v = *reinterpret_cast<const half8_t*>(x + ((long)g * group_rows + r) * ldx + ch * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
     }
@@ -176,7 +177,88 @@ __global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, i
     *reinterpret_cast<half8_t*>(yo) = o;
 }
 
+// CLIP ViT patchify: NCHW fp32 pixels -> fp16 rows [B*gh*gw][kpad], row = one patch flattened (c, py, px), zero padded
+__global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int batch, int ch, int img, int patch, int kpad) {
+    const int g = img / patch;
+    const long total = (long)batch * g * g * kpad;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % kpad);
+    const long row = idx / kpad;
+    float v = 0.f;
+    if (k < ch * patch * patch) {
+        const int c = k / (patch * patch), r = k - c * patch * patch;
+        const int py = r / patch, px = r - py * patch;
+        const int b = (int)(row / (g * g)), pr = (int)(row - (long)b * g * g);
+        const int gy = pr / g, gx = pr - gy * g;
+        v = x[(((long)b * ch + c) * img + gy * patch + py) * img + gx * patch + px];
+    }
+    out[idx] = (half_t)v;
+}
+
+// CLIP vision embeddings: out[b][0] = cls + pos[0]; out[b][1+i] = patch[b][i] + pos[1+i]     (fp16 rows, fp32 params)
+__global__ void vision_embed_kernel(const half_t* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
+                                    half_t* __restrict__ out, int batch, int ntok, int dim) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * ntok * dim) return;
+    const int d = (int)(idx % dim);
+    const long row = idx / dim;
+    const int t = (int)(row % ntok), b = (int)(row / ntok);
+    const float v = t == 0 ? cls[d] : (float)patches[((long)b * (ntok - 1) + (t - 1)) * dim + d];
+    out[idx] = (half_t)(v + pos[(long)t * dim + d]);
+}
+
+// CLIP text embeddings with PhotoVerse concept injection (models/clip.py:17-24,57-63), one thread per element:
+//   j <  idx       : tok[ids[b][j]]
+//   idx<=j<idx+E   : concept[b][j-idx]
+//   j >= idx+E     : tok[ids[b][j-E+1]]          (tail shifted right by E-1, truncated)
+// then + pos[j].  E == 0 (no concept) is the stock embedding.
+__global__ void text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                  const half_t* __restrict__ concept, const int64_t* __restrict__ pidx, int E, half_t* __restrict__ out,
+                                  int batch, int seq, int dim) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * seq * dim) return;
+    const int d = (int)(i % dim);
+    const long row = i / dim;
+    const int j = (int)(row % seq), b = (int)(row / seq);
+    float v;
+    const int idx = E > 0 ? (int)pidx[b] : seq;
+    if (j < idx) v = tok[ids[(long)b * seq + j] * dim + d];
+    else if (j < idx + E) v = (float)concept[((long)b * E + (j - idx)) * dim + d];
+    else v = tok[ids[(long)b * seq + (j - E + 1)] * dim + d];
+    out[i] = (half_t)(v + pos[(long)j * dim + d]);
+}
+
 }  // namespace
+
+extern "C" int pv_patchify(const float* x, void* out, int32_t batch, int32_t ch, int32_t img, int32_t patch, int32_t kpad, void* stream) {
+    if (batch <= 0 || ch <= 0 || img <= 0 || patch <= 0 || (img % patch) || kpad < ch * patch * patch || !x || !out)
+        return (int)hipErrorInvalidValue;
+    const long total = (long)batch * (img / patch) * (img / patch) * kpad;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<half_t*>(out), batch, ch, img, patch, kpad);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_clip_vision_embed(const void* patches, const float* cls, const float* pos, void* out, int32_t batch, int32_t ntok,
+                                    int32_t dim, void* stream) {
+    if (batch <= 0 || ntok <= 1 || dim <= 0 || !patches || !cls || !pos || !out) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * ntok * dim;
+    hipLaunchKernelGGL(vision_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(patches), cls, pos, reinterpret_cast<half_t*>(out), batch, ntok, dim);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_clip_text_embed(const int64_t* ids, const float* tok, const float* pos, const void* concept, const int64_t* placeholder_idx,
+                                  int32_t n_concept, void* out, int32_t batch, int32_t seq, int32_t dim, void* stream) {
+    if (batch <= 0 || seq <= 0 || dim <= 0 || n_concept < 0 || n_concept > seq || !ids || !tok || !pos || !out ||
+        (n_concept > 0 && (!concept || !placeholder_idx)))
+        return (int)hipErrorInvalidValue;
+    const long total = (long)batch * seq * dim;
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, tok, pos,
+                       reinterpret_cast<const half_t*>(concept), placeholder_idx, n_concept, reinterpret_cast<half_t*>(out), batch, seq, dim);
+    return PV_CHECK_LAUNCH();
+}
 
 extern "C" int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t rows, int32_t dim, void* out,
                                      void* stream) {
@@ -241,11 +323,11 @@ extern "C" int pv_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stre
     return PV_CHECK_LAUNCH();
 }
 
-extern "C" int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t cols,
-                            int32_t accumulate, void* stream) {
-    if (groups <= 0 || count <= 0 || cols <= 0 || (cols % 8) || !x || !y) return (int)hipErrorInvalidValue;
+extern "C" int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t groups, int32_t count, int32_t group_rows,
+                            int32_t cols, int32_t accumulate, void* stream) {
+    if (groups <= 0 || count <= 0 || group_rows < count || cols <= 0 || (cols % 8) || !x || !y) return (int)hipErrorInvalidValue;
     const int total = groups * (cols / 8);
     hipLaunchKernelGGL(rows_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<half_t*>(y), ldy, groups, count, cols, accumulate);
+                       reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<half_t*>(y), ldy, groups, count, group_rows, cols, accumulate);
     return PV_CHECK_LAUNCH();
 }

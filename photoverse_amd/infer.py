@@ -1,0 +1,83 @@
+"""``run_inference`` with the reference's signature (``/root/reference/models/infer.py:7-123``).
+
+Conditioning runs once per call on HIP kernels (CLIP ViT x2, adapters x3, text encoder x2, ``infer.py:76-96``); the
+denoising loop (``:98-119``) is the graph-captured ``DenoiseLoop``.  VAE encode / decode (``:62-68,121-123``) is outside
+this build's scope: with ``vae=None`` the function returns the final LATENTS (the value of ``latents`` after
+``:119``); a caller-supplied ``vae`` object with ``.decode`` / ``.config.scaling_factor`` is used as in ``:121-123``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .pipeline import DenoiseLoop
+from .scheduler import DPMSolverMultistepScheduler
+
+
+def _loop_for(unet, batch, latent_size, n_ip, steps, guidance, scheduler) -> DenoiseLoop:
+    cache = unet.__dict__.setdefault("_denoise_loops", {})
+    key = (batch, latent_size, n_ip, steps, float(guidance))
+    loop = cache.get(key)
+    if loop is None or loop.unet_version != unet.__dict__.get("_pack_version", 0):
+        loop = DenoiseLoop(unet, batch, latent_size, n_ip, steps, guidance, scheduler=scheduler)
+        loop.unet_version = unet.__dict__.get("_pack_version", 0)
+        cache[key] = loop
+    return loop
+
+
+def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, scheduler,
+                  device, image_encoder_layers_idx, latent_size=64, guidance_scale=1, timesteps=100, token_index=0,
+                  disable_tqdm=False, seed=None, from_noised_image=False, training_mode=False):
+    if training_mode:
+        raise NotImplementedError("training_mode (grad through the last step, infer.py:99) belongs to the training row (SURVEY 8f-3)")
+    device = torch.device(device)
+    # infer.py:39-40 - the sampler is rebuilt from the loaded scheduler's config on every call
+    sch = DPMSolverMultistepScheduler.from_config(scheduler.config)
+    batch = example["pixel_values"].shape[0] if "pixel_values" in example else example["pixel_values_clip"].shape[0]
+
+    uncond_input_ids = example.get("negative_text_input_ids", None)                      # :43-49
+    if uncond_input_ids is None:
+        uncond_input_ids = tokenizer([""] * batch, padding="max_length", max_length=tokenizer.model_max_length,
+                                     return_tensors="pt").input_ids
+
+    shape = (batch, unet.config.in_channels, latent_size, latent_size)                    # :52-59 noise on CPU, then moved
+    if seed is None:
+        noise = torch.randn(shape).to(device)
+    else:
+        generator = torch.manual_seed(seed)
+        noise = torch.randn(shape, generator=generator).to(device)
+
+    if from_noised_image:                                                                 # :62-65
+        if vae is None:
+            raise NotImplementedError("from_noised_image needs vae.encode; the VAE is outside this build's scope (SURVEY 8f-1)")
+        latents0 = vae.encode(example["pixel_values"].to(device)).latent_dist.sample().detach() * vae.config.scaling_factor
+        sch.set_timesteps(timesteps)
+        acp = torch.from_numpy(sch.alphas_cumprod).to(device)[sch.timesteps[:1].to(device)]
+        noise = acp.sqrt() * latents0 + (1 - acp).sqrt() * noise      # scheduler.add_noise at the first timestep
+
+    placeholder_idx = example["concept_placeholder_idx"].to(device)                       # :72-73
+    pixel_values_clip = example["pixel_values_clip"].to(device)
+
+    image_features = image_encoder(pixel_values_clip, output_hidden_states=True)          # :76-78
+    uncond_image_features = image_encoder(torch.zeros_like(pixel_values_clip), output_hidden_states=True)
+    image_embeddings = [image_features[0]] + [image_features[2][i] for i in image_encoder_layers_idx if i < len(image_features[2])]
+    uncond_image_emmbedings = [uncond_image_features[0]] + [uncond_image_features[2][i] for i in image_encoder_layers_idx
+                                                            if i < len(uncond_image_features[2])]
+
+    concept_text_embeddings = text_adapter(image_embeddings, token_index=token_index)     # :89-91
+    encoder_hidden_states_image = image_adapter(image_embeddings, token_index=token_index)
+    uncond_encoder_hidden_states_image = image_adapter(uncond_image_emmbedings, token_index=token_index)
+
+    uncond_embeddings = text_encoder({"text_input_ids": uncond_input_ids.to(device)})[0]  # :93-96
+    encoder_hidden_states = text_encoder({"text_input_ids": example["text_input_ids"].to(device),
+                                          "concept_text_embeddings": concept_text_embeddings,
+                                          "concept_placeholder_idx": placeholder_idx})[0]
+
+    loop = _loop_for(unet, batch, latent_size, encoder_hidden_states_image.shape[1], timesteps, guidance_scale, sch)   # :98-119
+    loop.set_conditioning((encoder_hidden_states, encoder_hidden_states_image), (uncond_embeddings, uncond_encoder_hidden_states_image))
+    loop.reset(noise)
+    latents = loop.run().clone()
+
+    if vae is None:
+        return latents
+    _latents = 1 / vae.config.scaling_factor * latents.clone()                            # :121-123
+    return vae.decode(_latents).sample.clamp(-1, 1)

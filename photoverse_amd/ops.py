@@ -226,12 +226,31 @@ class Recorder:
         self._add(self.lib.pv_cast_f16_to_f32, _ptr(x), _ptr(out), x.numel())
         return out
 
-    def rows_mean(self, x, *, groups, count, out=None, accumulate=False):
+    def rows_mean(self, x, *, groups, count, group_rows=None, out=None, accumulate=False):
         ldx, cols = _rows(x)
         if out is None:
             out = self.empty((groups, cols), torch.float16)
         self.keep.extend((x, out))
-        self._add(self.lib.pv_rows_mean, _ptr(x), ldx, _ptr(out), _rows(out)[0], groups, count, cols, int(accumulate))
+        self._add(self.lib.pv_rows_mean, _ptr(x), ldx, _ptr(out), _rows(out)[0], groups, count, group_rows or count, cols, int(accumulate))
+        return out
+
+    def patchify(self, pixels, *, batch, ch, img, patch, kpad):
+        out = self.empty((batch * (img // patch) ** 2, kpad), torch.float16)
+        self.keep.append(pixels)
+        self._add(self.lib.pv_patchify, _ptr(pixels), _ptr(out), batch, ch, img, patch, kpad)
+        return out
+
+    def clip_vision_embed(self, patches, cls, pos, *, batch, ntok, dim):
+        out = self.empty((batch * ntok, dim), torch.float16)
+        self.keep.extend((patches, cls, pos))
+        self._add(self.lib.pv_clip_vision_embed, _ptr(patches), _ptr(cls), _ptr(pos), _ptr(out), batch, ntok, dim)
+        return out
+
+    def clip_text_embed(self, ids, tok, pos, concept, placeholder_idx, *, n_concept, batch, seq, dim):
+        out = self.empty((batch * seq, dim), torch.float16)
+        self.keep.extend(t for t in (ids, tok, pos, concept, placeholder_idx) if t is not None)
+        self._add(self.lib.pv_clip_text_embed, _ptr(ids), _ptr(tok), _ptr(pos), _ptr(concept), _ptr(placeholder_idx), n_concept,
+                  _ptr(out), batch, seq, dim)
         return out
 
     def cfg_dpm_step(self, eps_u, eps_c, latents, x0_prev, coef, state, guidance):

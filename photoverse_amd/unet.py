@@ -361,6 +361,8 @@ class UNet2DConditionModel(nn.Module):
     def repack(self):
         """Drop cached launch plans (call after changing weights / processors)."""
         self._engines.clear()
+        self.__dict__["_pack_version"] = self.__dict__.get("_pack_version", 0) + 1
+        self.__dict__.pop("_denoise_loops", None)
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -370,6 +372,8 @@ class UNet2DConditionModel(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._engines = {}
+        self.__dict__["_pack_version"] = self.__dict__.get("_pack_version", 0) + 1
+        self.__dict__.pop("_denoise_loops", None)
         return r
 
     @property

@@ -1,0 +1,269 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host logic (scheduler tables, weight
+packing, tokenizer, checkpoint layout, LoRA naming, loaders), the product path refuses to run without a HIP device,
+and the N>1 sharding / gather path under gloo (world_size 2)."""
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+            attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5)
+VIS = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=1, image_size=56, patch_size=14)
+TXT = dict(vocab_size=1000, hidden_size=768, num_attention_heads=12, intermediate_size=256, num_hidden_layers=1)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from photoverse_amd.build import build_lib
+    build_lib(verbose=False)              # hipcc cross-compiles gfx950 without a GPU
+    from photoverse_amd import _lib
+    return _lib.load()
+
+
+def test_cabi_exports_every_declared_symbol(lib):
+    from photoverse_amd import _lib
+    header = open(os.path.join(ROOT, "include", "photoverse_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(pv_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.pv_abi_version() == 1
+    assert lib.pv_device_count() in (-1, 0) or torch.cuda.is_available()
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of the parameter structs: field names and order equal the header's."""
+    from photoverse_amd import _lib
+    header = open(os.path.join(ROOT, "include", "photoverse_hip.h")).read()
+    for cname, cls in (("pv_gemm_params", _lib.GemmParams), ("pv_groupnorm_params", _lib.GroupNormParams),
+                       ("pv_layernorm_params", _lib.LayerNormParams), ("pv_attn_params", _lib.AttnParams),
+                       ("pv_xattn_params", _lib.XAttnParams)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.split(",")
+            names.append(re.findall(r"(\w+)\s*$", parts[0].strip())[0])
+            names += [re.findall(r"(\w+)\s*$", p.strip())[0] for p in parts[1:]]
+        assert names == [f[0] for f in cls._fields_], (cname, names)
+
+
+def test_product_refuses_cpu():
+    from photoverse_amd.ops import Recorder
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Recorder("cpu")
+    u = UNet2DConditionModel(**TINY)
+    set_visual_cross_attention_adapter(u, (5,))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        u(torch.randn(1, 4, 16, 16), torch.tensor(3), encoder_hidden_states=(torch.randn(1, 77, 768), torch.randn(1, 1, 768)))
+    with pytest.raises(NotImplementedError):
+        u.conv_in  # holders exist ...
+        u.mid_block(torch.zeros(1))   # ... but have no eager forward
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reach into oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "photoverse_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    for f in ("generate.py",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_unet_state_dict_names_and_processors():
+    from oracle.unet_ref import UNet2DConditionModelRef, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.attention_processor import AttnProcessor2_0, PhotoVerseAttnProcessor2_0
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    with torch.device("meta"):
+        ref = UNet2DConditionModelRef()
+        hip = UNet2DConditionModel()
+    set_visual_cross_attention_adapter_ref(ref, (5,))
+    set_visual_cross_attention_adapter(hip, (5,))
+    a, b = ref.state_dict(), hip.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(a[k].shape == b[k].shape for k in a)
+    assert sum(p.numel() for n, p in hip.named_parameters() if "processor" not in n) == 859_520_964
+    procs = hip.attn_processors
+    assert len(procs) == 32
+    assert sum(isinstance(p, PhotoVerseAttnProcessor2_0) for p in procs.values()) == 16
+    assert all(isinstance(p, AttnProcessor2_0) for n, p in procs.items() if n.endswith("attn1.processor"))
+    sizes = {n: p.hidden_size for n, p in procs.items() if isinstance(p, PhotoVerseAttnProcessor2_0)}
+    assert sizes["down_blocks.0.attentions.0.transformer_blocks.0.attn2.processor"] == 320
+    assert sizes["mid_block.attentions.0.transformer_blocks.0.attn2.processor"] == 1280
+    assert sizes["up_blocks.3.attentions.2.transformer_blocks.0.attn2.processor"] == 320
+    for bad in (dict(fusion_rules=(0.5, 0.6)), dict(fusion_rules=[1 / 3, 2 / 3]), dict(scale=[1.0, 2.0])):
+        with pytest.raises(ValueError):
+            PhotoVerseAttnProcessor2_0(320, 768, **bad)
+    p = PhotoVerseAttnProcessor2_0(320, 768)
+    with torch.no_grad():
+        assert p.branch_weights() == (1.0, 1.0)
+    for seed, exp in ((0.1, (2.0, 0.0)), (0.9, (0.0, 2.0)), (0.5, (1.0, 1.0))):
+        p.forced_fusion_seed = seed
+        assert p.branch_weights() == exp
+
+
+def test_scheduler_table_reproduces_oracle_stepping():
+    from oracle.scheduler_ref import DPMSolverMultistepRef
+    from photoverse_amd.scheduler import DPMSolverMultistepScheduler
+    for n in (2, 7, 25, 50):
+        s = DPMSolverMultistepScheduler.from_config(DPMSolverMultistepScheduler().config)
+        s.set_timesteps(n)
+        tab = s.coefficient_table().double()
+        r = DPMSolverMultistepRef()
+        r.set_timesteps(n)
+        assert torch.equal(s.timesteps, r.timesteps) and tab.shape == (n, 8)
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(256, generator=g, dtype=torch.float64)
+        xr, xp = x.clone(), torch.zeros_like(x)
+        for i, t in enumerate(r.timesteps):
+            eps = torch.randn(256, generator=g, dtype=torch.float64)
+            xr = r.step(eps, t, xr)
+            ca, cb, cx, c0, c1 = tab[i, :5]
+            x0 = ca * x + cb * eps
+            x, xp = cx * x + c0 * x0 + c1 * xp, x0
+            assert ((x - xr).norm() / xr.norm()).item() < 1e-6
+
+
+def test_pack_geglu_is_a_permutation_with_paired_fragments():
+    from photoverse_amd.ops import pack_geglu
+    n, k = 1280, 8
+    w = torch.arange(2 * n, dtype=torch.float32)[:, None].repeat(1, k)
+    wp, bp = pack_geglu(w, torch.arange(2 * n, dtype=torch.float32))
+    src = wp[:, 0].long()
+    assert torch.equal(torch.sort(src).values, torch.arange(2 * n)) and torch.equal(bp.long(), src)
+    # every 32 packed rows hold 16 value rows j..j+15 followed by their 16 gate rows n+j..n+j+15
+    blk = src.view(-1, 2, 16)
+    assert torch.equal(blk[:, 1], blk[:, 0] + n)
+    assert torch.equal(blk[:, 0, 0], torch.arange(0, n, 16))
+
+
+def test_tokenizer_uncond_ids():
+    from photoverse_amd.tokenizer import SyntheticCLIPTokenizer
+    tok = SyntheticCLIPTokenizer()
+    ids = tok([""] * 3, padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
+    assert ids.shape == (3, 77) and ids.dtype == torch.int64
+    assert ids[0, 0].item() == 49406 and (ids[:, 1:] == 49407).all()
+    ids2 = tok("a photo of a *").input_ids
+    assert ids2[0, 0].item() == 49406 and ids2[0, 6].item() == 49407 and ids2.max().item() < 49408
+
+
+def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
+    """save_progress / load_photoverse_model keep the reference layout (modeling_utils.py:13-50)."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_models, load_photoverse_model, save_progress
+    tok, te, vae, unet, ie, ia, ta, sch, _ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=1)
+    save_progress(ia, ta, unet, None, str(tmp_path), step=42)
+    f = tmp_path / "photoverse_000042.pt"
+    assert f.exists()
+    ck = torch.load(str(f))
+    assert set(ck) == {"image_adapter", "text_adapter", "cross_attention_adapter"}
+    keys = list(ck["cross_attention_adapter"])
+    assert len(keys) == 4 * 5                       # 4 cross-attn layers x (to_q, to_k, to_v, to_k_ip, to_v_ip)
+    assert "mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_k_ip.0.weight" in keys
+    assert not any("to_out" in k for k in keys)
+    assert set(ck["image_adapter"]) == {f"mapping{p}_{i}.{j}.{w}" for p in ("", "_patch") for i in range(2) for j, ws in
+                                        ((0, "wb"), (1, "wb"), (3, "wb"), (4, "wb"), (6, "wb")) for w in ("weight", "bias")}
+    # load into a differently seeded model: adapters + cross-attention subset become equal, the rest stays
+    tok2, te2, vae2, unet2, ie2, ia2, ta2, sch2, lc = load_models(None, 1, str(f), unet_config=TINY, vision_config=VIS, text_config=TXT, seed=2)
+    assert lc is None
+    for k in keys:
+        assert torch.equal(unet2.state_dict()[k], unet.state_dict()[k])
+    assert not torch.equal(unet2.conv_in.weight, unet.conv_in.weight)
+    assert all(torch.equal(a, b) for a, b in zip(ia2.state_dict().values(), ia.state_dict().values()))
+    # LoRA: peft-style names, config stored, re-injected on load BEFORE the weights
+    cfg = LoraConfig(r=4, lora_alpha=8)
+    tok3, te3, vae3, unet3, *_rest = load_models(None, 1, use_lora=True, lora_config=cfg, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=1)
+    k3 = list(unet3.state_dict())
+    base = "mid_block.attentions.0.transformer_blocks.0.attn2.to_q."
+    assert base + "base_layer.weight" in k3 and base + "lora_A.default.weight" in k3 and base + "lora_B.default.weight" in k3
+    assert unet3.state_dict()[base + "lora_A.default.weight"].shape == (4, 640)
+    q = dict(unet3.named_modules())[base[:-1]]
+    nn.init.normal_(q.lora_B["default"].weight)
+    merged = q.base_layer.weight + 2.0 * q.lora_B["default"].weight @ q.lora_A["default"].weight
+    assert torch.allclose(q.weight, merged)
+    save_progress(ia, ta, unet3, None, str(tmp_path), lora_config=cfg, optimizer=torch.optim.AdamW(ia.parameters()))
+    ck3 = torch.load(str(tmp_path / "photoverse.pt"))
+    assert {"optimizer", "lora_config"} <= set(ck3) and ck3["lora_config"]["r"] == 4
+    assert any(k.endswith("to_q.lora_B.default.weight") for k in ck3["cross_attention_adapter"])
+    *_x, unet4, _ie, _ia, _ta, _s, lc4 = load_models(None, 1, str(tmp_path / "photoverse.pt"), unet_config=TINY, vision_config=VIS, text_config=TXT, seed=5)
+    assert lc4 is not None and lc4.r == 4
+    assert torch.equal(unet4.state_dict()[base + "lora_B.default.weight"], unet3.state_dict()[base + "lora_B.default.weight"])
+    with pytest.raises(AssertionError):
+        load_models(None, 1, use_lora=True, unet_config=TINY, vision_config=VIS, text_config=TXT)     # modeling_utils.py:87
+    with pytest.raises(FileNotFoundError):
+        load_models("runwayml/stable-diffusion-v1-5", 1)                                              # no network here
+
+
+def test_load_models_from_local_hf_layout(tmp_path):
+    from safetensors.torch import save_file
+    from photoverse_amd.modeling_utils import load_models
+    tok, te, vae, unet, ie, *_ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=7)
+    (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "image_encoder").mkdir()
+    plain = {k: v.contiguous() for k, v in unet.state_dict().items() if "processor" not in k}
+    save_file(plain, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    save_file({k: v.contiguous() for k, v in te.state_dict().items()}, str(tmp_path / "text_encoder" / "model.safetensors"))
+    save_file({k: v.contiguous() for k, v in ie.state_dict().items()}, str(tmp_path / "image_encoder" / "model.safetensors"))
+    tok2, te2, vae2, unet2, ie2, *_ = load_models(str(tmp_path), 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=8)
+    assert all(torch.equal(unet2.state_dict()[k], v) for k, v in plain.items())
+    assert all(torch.equal(a, b) for a, b in zip(te2.state_dict().values(), te.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(ie2.state_dict().values(), ie.state_dict().values()))
+    assert not any(p.requires_grad for p in unet2.conv_in.parameters())                # frozen (modeling_utils.py:63-66)
+    assert all(p.requires_grad for n, p in unet2.named_parameters() if "processor" in n)   # created after the freeze
+
+
+def test_adapter_default_init_equals_real_reference(golden_dir):
+    """Product adapter built under the golden seed holds the REAL reference's weights (checksums from make_golden.py)."""
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    g = torch.load(os.path.join(golden_dir, "adapter_golden.pt"))
+    torch.manual_seed(g["weights_seed"])
+    sd = PhotoVerseAdapter(1024, 768, num_tokens=2).state_dict()
+    assert set(sd) == set(g["weight_checksums"])
+    for k, (s1, s2, head) in g["weight_checksums"].items():
+        assert sd[k].double().sum().item() == pytest.approx(s1, rel=1e-12, abs=1e-12) and torch.equal(sd[k].flatten()[:4], head)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from photoverse_amd.pipeline import gather_latents, shard_batch
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(8, 4, 16, 16, generator=g)          # global batch drawn identically on every rank (infer.py:52-59 semantics)
+    sl = shard_batch(8, rank, world)
+    local = noise[sl] * 2.0 + 1.0                            # stands for the rank's independent denoise of its shard
+    full = gather_latents(local, world)
+    ok = torch.equal(full, noise * 2.0 + 1.0)
+    q.put((rank, ok, tuple(full.shape)))
+    dist.destroy_process_group()
+
+
+def test_batch_shard_and_single_gather_gloo_world2():
+    import torch.multiprocessing as mp
+    from photoverse_amd.pipeline import shard_batch
+    assert shard_batch(128, 3, 8) == slice(48, 64)
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, (8, 4, 16, 16)), (1, True, (8, 4, 16, 16))]
