@@ -212,6 +212,11 @@ class CLIPTextModel(_CachedPlans):
         require_cuda(ids, "text_input_ids")
         ids = ids.view(-1, ids.shape[-1])
         B, S = ids.shape
+        if S > self.config.max_position_embeddings:
+            raise IndexError(f"sequence length {S} exceeds max_position_embeddings {self.config.max_position_embeddings}")
+        lo, hi = int(ids.min()), int(ids.max())       # one host sync, pre-loop; nn.Embedding would raise / device-assert here
+        if lo < 0 or hi >= self.config.vocab_size:
+            raise IndexError(f"token id out of range [0, {self.config.vocab_size})")
         E = 0 if concept is None else concept.shape[1]
         key = (B, S, E, ids.device)
         plan = self._plans.get(key)

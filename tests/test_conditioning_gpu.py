@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 VIS = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3, image_size=56, patch_size=14)
-TXT = dict(vocab_size=1000, hidden_size=768, num_attention_heads=12, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=77)
+TXT = dict(vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=77)
 
 
 def rel_l2(a, b):
@@ -61,6 +61,8 @@ def test_clip_text_with_injection_matches_oracle(need_gpu):
             assert rel_l2(got, exp) < 3e-3
     with pytest.raises(ValueError):
         hip(None)
+    with pytest.raises(IndexError):
+        hip({"text_input_ids": torch.full((1, 77), 49408).cuda()})          # out-of-vocabulary id fails loudly
     with pytest.raises(TypeError):
         patch_clip_text_transformer(torch.nn.Linear(2, 2))
 
