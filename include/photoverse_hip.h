@@ -47,7 +47,7 @@ int pv_device_count(void);
  *   A may come from two tensors concatenated along channels (skip connections): channels
  *   [0,c0) from a0 and [c0,c0+c1) from a1; c0, c1 multiples of 64.
  *   epilogue: (+bias[n]) (+rowadd[img][n]) act (+residual[m][n]) -> fp16 (or fp32) store.
- *   Requirements: N % 128 == 0 or N % 160 == 0; (c0+c1) % 64 == 0; pointers 16-byte aligned.
+ *   Requirements: N % 128 == 0 or N % 160 == 0; (c0+c1) % 64 == 0; pointers 16-byte aligned; each operand < 2 GiB.
  */
 typedef struct pv_gemm_params {
     const void* a0;        /* fp16 */
@@ -70,7 +70,9 @@ typedef struct pv_gemm_params {
     int32_t act;           /* enum pv_act */
     int32_t out_f32;
     int32_t geglu;         /* 1 => W rows are tile-interleaved (value|gate); out[M][N/2] = value*gelu(gate) */
-    const void* zero_page; /* >= 256 bytes of zeros (padding taps / M tail) */
+    const void* zero_page; /* unused since ABI 1 (padding is produced by the buffer range check); may be NULL */
+    int32_t splitk;        /* > 1: split the K loop over this many workgroups per tile (small-M layers); needs splitk_ws */
+    float* splitk_ws;      /* fp32 workspace [splitk][M][N] for the partial slabs, reduced in fixed order */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 

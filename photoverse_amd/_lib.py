@@ -18,7 +18,8 @@ class GemmParams(C.Structure):
                 ("w", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p), ("rowadd_ld", c_int), ("residual", c_void_p),
                 ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
                 ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
-                ("upsample", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int), ("zero_page", c_void_p)]
+                ("upsample", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int), ("zero_page", c_void_p),
+                ("splitk", c_int), ("splitk_ws", c_void_p)]
 
 
 class GroupNormParams(C.Structure):

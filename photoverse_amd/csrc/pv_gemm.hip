@@ -91,7 +91,11 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
 
     const int cin = p.c0 + p.c1;
     const int K = p.taps * cin;
-    const int nk = K / BK;
+    // split-K: blockIdx.y owns K-steps [k_begin, k_begin + nk) and writes an fp32 partial slab (reduced by splitk_reduce_kernel)
+    const int nk_total = K / BK;
+    const int nk_per = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_begin = (int)blockIdx.y * nk_per;
+    const int nk = max(0, min(nk_total, k_begin + nk_per) - k_begin);
 
     // ---- per-thread staging geometry ------------------------------------------------------
     // All global->LDS traffic is `buffer_load_dwordx4 ... lds` through raw buffer descriptors: a lane whose source is
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     // number of LDS-DMA instructions this wave issues per stage (for the counted vmcnt)
     const bool b_full = (Cfg::B_PIECES % NW == 0) || (wave + (Cfg::B_PER_WAVE - 1) * NW < Cfg::B_PIECES);
 
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](int kt_local, int buf) {
+        const int kt = k_begin + kt_local;
         char* sa = smem + buf * Cfg::STAGE_BYTES;
         char* sb = sa + Cfg::A_BYTES;
         // K order: channel-chunk major, filter-tap minor.  The 9 taps of one 64-channel slab re-read (shifted) the same
@@ -213,39 +218,67 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
         // buffer of step kt-1, which the prefetch below overwrites.  Raw s_barrier: __syncthreads() would drain vmcnt.
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const char* sa = smem + (kt % Cfg::STAGES) * Cfg::STAGE_BYTES;
+        const char* sb = sa + Cfg::A_BYTES;
+        // Explicit software pipeline (hipcc otherwise re-uses one fragment register per weight fragment and serialises
+        // "ds_read -> wait -> 4 MFMA"): issue ALL fragment reads of the K-step (2 x (4 + NF) ds_read_b128) up front, put the
+        // next stage's LDS-DMA issue between the two read groups, then run the 8*NF MFMAs back to back.
+        half8_t xa0[4], wb0[NF], xa1[4], wb1[NF];
+#if PV_ABLATE != 3
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xa0[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, fq);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) wb0[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, fq);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
 #if PV_ABLATE == 2   // timing experiment: no global->LDS traffic after the prologue
         if (kt + PRE < nk && kt < 0) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
 #else
         if (kt + PRE < nk) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
 #endif
-        const char* sa = smem + (kt % Cfg::STAGES) * Cfg::STAGE_BYTES;
-        const char* sb = sa + Cfg::A_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
 #if PV_ABLATE == 3   // timing experiment: DMA only
         if (kt >= 0) continue;
 #endif
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8_t xa[4], wb[NF];
+        for (int mi = 0; mi < 4; ++mi) xa1[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, 4 + fq);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) xa[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, ks * 4 + fq);
-#pragma unroll
-            for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
+        for (int ni = 0; ni < NF; ++ni) wb1[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, 4 + fq);
+        __builtin_amdgcn_sched_barrier(0);
 #if PV_ABLATE == 1   // timing experiment: LDS reads without the MFMAs
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa[mi]));
+        for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa0[mi]), "v"(xa1[mi]));
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb[ni]));
+        for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb0[ni]), "v"(wb1[ni]));
 #else
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni)
+        for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[ni], xa0[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[ni], xa1[mi], acc[ni][mi], 0, 0, 0);
 #endif
-        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+    if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
+        float* slab = p.splitk_ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) {
+                const int n = n0 + wn * (NF * 16) + ni * 16 + fq * 4;
+                *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + n) = acc[ni][mi];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
@@ -298,6 +331,35 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     }
 }
 
+// sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue
+__global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int splits) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = p.N >> 2;
+    if (idx >= (long)p.M * nq) return;
+    const int m = (int)(idx / nq), n = (int)(idx - (long)m * nq) * 4;
+    float4_t v = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const float4_t*>(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
+    if (p.bias) v += *reinterpret_cast<const float4_t*>(p.bias + n);
+    if (p.rowadd) v += *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(m / (p.hout * p.wout)) * p.rowadd_ld + n);
+    if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
+    }
+    if (p.residual) {
+        const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+    } else {
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+    }
+}
+
 template <int NF, int WM, bool CONV, bool GEGLU>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = TileCfg<NF, WM>;
@@ -315,7 +377,12 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     // XCD footprint heuristic: walk M fastest when the weight panel is too big to sit in every XCD's L2
     const size_t wbytes = (size_t)p.N * p.taps * (p.c0 + p.c1) * 2;
     const int m_fast = (wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
+    const int splits = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
+    hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
+    if (splits > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
+    }
     return PV_CHECK_LAUNCH();
 }
 
@@ -335,7 +402,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     static_cast<pv_gemm_params&>(p) = *pp;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int cin = p.c0 + p.c1;
-    if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU ||
+    if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU || p.splitk < 0 || p.splitk > 16 ||
         !p.a0 || !p.w || !p.out || (p.c1 && !p.a1) || p.hout * p.wout <= 0)
         return (int)hipErrorInvalidValue;
     {

@@ -36,36 +36,41 @@ __global__ void conv_in_kernel(const float* __restrict__ x, const float* __restr
     }
     __syncthreads();
     const int nchunk = cout >> 3;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)batch * h * wd * nchunk;
-    if (idx >= total) return;
-    const int chunk = (int)(idx % nchunk);
-    const long pix = idx / nchunk;
-    const int b = (int)(pix / (h * wd));
-    const int rem = (int)(pix - (long)b * h * wd);
-    const int y = rem / wd, xx = rem - y * wd;
-    float acc[8];
+    // grid-stride: each workgroup stages the weights in LDS once and walks many (pixel, 8-channel chunk) items
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int chunk = (int)(idx % nchunk);
+        const long pix = idx / nchunk;
+        const int b = (int)(pix / (h * wd));
+        const int rem = (int)(pix - (long)b * h * wd);
+        const int y = rem / wd, xx = rem - y * wd;
+        float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[chunk * 8 + j] : 0.f;
-    for (int ci = 0; ci < cin; ++ci) {
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[chunk * 8 + j] : 0.f;
+        for (int ci = 0; ci < cin; ++ci) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = y + ky - 1;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = y + ky - 1;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = xx + kx - 1;
-                if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
-                const float v = x[(((long)b * cin + ci) * h + iy) * wd + ix];
-                const float* ww = sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = xx + kx - 1;
+                    if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+                    const float v = x[(((long)b * cin + ci) * h + iy) * wd + ix];
+                    const float4_t w0 = *reinterpret_cast<const float4_t*>(sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8);
+                    const float4_t w1 = *reinterpret_cast<const float4_t*>(sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8 + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v * ww[j];
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] += v * w0[j];
+                        acc[j + 4] += v * w1[j];
+                    }
+                }
             }
         }
-    }
-    half8_t o;
+        half8_t o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-    *reinterpret_cast<half8_t*>(out + pix * cout + chunk * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+        *reinterpret_cast<half8_t*>(out + pix * cout + chunk * 8) = o;
+    }
 }
 
 // conv_out: NHWC fp16 -> NCHW fp32, 3x3 pad 1, cout <= 8.  One wave = one output pixel.
@@ -273,7 +278,8 @@ extern "C" int pv_conv_in(const float* x, const float* w, const float* bias, voi
                           int32_t wd, int32_t cout, void* stream) {
     if (batch <= 0 || cin <= 0 || (cout % 8) || cin * 9 * cout * 4 > 64 * 1024 || !x || !w || !out) return (int)hipErrorInvalidValue;
     const long total = (long)batch * h * wd * (cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), cin * 9 * cout * sizeof(float),
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), cin * 9 * cout * sizeof(float),
                        (hipStream_t)stream, x, w, bias, reinterpret_cast<half_t*>(out), batch, cin, h, wd, cout);
     return PV_CHECK_LAUNCH();
 }

@@ -106,7 +106,7 @@ class Recorder:
     # ------------------------------------------------------------------ ops
     def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
              rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
-             out_f32=False, geglu=False, conv: Optional[dict] = None) -> torch.Tensor:
+             out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None) -> torch.Tensor:
         """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin]."""
         lda0, c0 = _rows(a)
         lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
@@ -128,11 +128,16 @@ class Recorder:
         if residual is not None:
             ldr, rc = _rows(residual)
             assert rc == n_out and residual.shape[0] == M
+        # split-K for layers whose 128-row tiles cannot fill the 256 CUs (8x8 / 16x16 levels of the UNet)
+        kdim = taps * (c0 + c1)
+        bn = 128 if (geglu or N % 160) else 160
+        tiles = ((M + 127) // 128) * (N // bn)
+        splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(8, 512 // tiles, (kdim // 64) // 8)))
+        ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), _ptr(self.zero_page))
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), None, splitk, _ptr(ws))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
-        kdim = taps * (c0 + c1)
         name = f"gemm_conv_kernel<{nf},{'true' if conv is not None else 'false'},{'true' if geglu else 'false'}>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
