@@ -11,6 +11,7 @@
 // both operands), whose A operand V^T is read straight from the row-major V tile with the gfx950
 // transposing LDS read ds_read_b64_tr_b16.  No P round trip through LDS.
 #include "pv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -40,15 +41,31 @@ __device__ __forceinline__ half8_t vt_frag(const half_t* sV, int VS, int key0, i
     return r;
 }
 
+// waves per SIMD the register allocator is asked to leave room for (occupancy hides the serial QK -> softmax -> PV chain)
 template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
+constexpr int attn_min_waves() { return 1; }
+
+template <int D>
+__global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv_attn_params p) {
     using C = ACfg<D>;
     constexpr int KB = 64;
     constexpr int NCHUNK = KB * C::CH;
     constexpr int KPT = (NCHUNK + 255) / 256;
+    // ONES: the P.V output has a spare padded column (D % 16 != 0).  V's column D is set to 1.0 so that column accumulates
+    // the softmax denominator sum_k P[q][k] inside the MFMA (fp16-rounded P, consistent with the numerator) - no VALU adds.
+#ifdef PV_ATTN_NO_ONES
+    constexpr bool ONES = false;
+#else
+    constexpr bool ONES = (D % 16) != 0;
+#endif
+#ifdef PV_ATTN_DBUF
+    constexpr bool DBUF = D <= 80;                       // two K/V LDS stages -> one barrier per tile (measured slower: off)
+#else
+    constexpr bool DBUF = false;
+#endif
+    constexpr int STAGE = KB * (C::KS + C::VS);          // halfs per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sK = reinterpret_cast<half_t*>(smem);
-    half_t* sV = sK + KB * C::KS;
+    half_t* sbase = reinterpret_cast<half_t*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
@@ -57,12 +74,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
     const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
     const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
 
-    // zero the K pad columns [D, KS) once: the contraction runs over DK >= D
-    {
-        constexpr int NPC = (C::KS - D) / 8;
+    // pad columns, written once (staging only touches columns [0, D)): K pads are zero (the contraction runs over DK >= D);
+    // V pads are zero except column D = 1.0 when ONES
+    for (int st = 0; st < (DBUF ? 2 : 1); ++st) {
+        half_t* sK = sbase + st * STAGE;
+        half_t* sV = sK + KB * C::KS;
+        constexpr int NPC = (C::KS - D) / 8, NPV = (C::VS - D) / 8;
         for (int i = tid; i < KB * NPC; i += 256) {
             const int r = i / NPC, c = i - r * NPC;
             *reinterpret_cast<half8_t*>(sK + r * C::KS + D + c * 8) = zero8();
+        }
+        for (int i = tid; i < KB * NPV; i += 256) {
+            const int r = i / NPV, c = i - r * NPV;
+            half8_t v = zero8();
+            if (ONES && c == 0) v[0] = (half_t)1.0f;
+            *reinterpret_cast<half8_t*>(sV + r * C::VS + D + c * 8) = v;
         }
     }
 
@@ -95,7 +121,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
             }
         }
     };
-    auto swrite = [&]() {
+    auto swrite = [&](int st) {
+        half_t* sK = sbase + st * STAGE;
+        half_t* sV = sK + KB * C::KS;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + i * 256;
@@ -115,15 +143,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     const float sc = rsqrtf((float)D) * 1.4426950408889634f;
 
-    int ntiles = (p.nk + KB - 1) / KB;
-    if (p.causal) ntiles = min(ntiles, (min(qt * 128 + 127, p.nq - 1)) / KB + 1);
-    gload(0);
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();  // previous tile fully consumed
-        swrite();
-        __syncthreads();
-        if (t + 1 < ntiles) gload(t + 1);
-
+    // one 64-key tile: S^T = K.Q^T, online softmax, O^T += V^T.P^T
+    auto tile = [&](int t, int st, const bool MASKED) {
+        const half_t* sK = sbase + st * STAGE;
+        const half_t* sV = sK + KB * C::KS;
         float4_t s[4][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -137,12 +160,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
             }
-
-        const bool need_mask = p.causal || (t + 1) * KB > p.nk;
         half8_t pb[2][2];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            if (need_mask) {
+            if (MASKED) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -159,7 +180,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
             mx = pv_quad_max(mx);
             const float m_new = fmaxf(m_run[qi], mx * sc);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = PV_EXP2(m_run[qi] - m_use);
+            // rescale the running output only when this row's maximum moved (wave-uniform skip: after the first few
+            // tiles most rows keep their maximum)
+#ifdef PV_ATTN_NO_SKIP
+            {
+#else
+            if (__any(m_new > m_run[qi])) {
+#endif
+                const float alpha = PV_EXP2(m_run[qi] - m_use);
+                if (!ONES) l_run[qi] *= alpha;
+#pragma unroll
+                for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
+            }
             m_run[qi] = m_new;
             float rs = 0.f;
 #pragma unroll
@@ -167,12 +199,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = PV_EXP2(fmaf(s[kb][qi][r], sc, -m_use));
-                    rs += e;
+                    if (!ONES) rs += e;
                     s[kb][qi][r] = e;
                 }
-            l_run[qi] = l_run[qi] * alpha + rs;
-#pragma unroll
-            for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
+            if (!ONES) l_run[qi] += rs;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -189,12 +219,42 @@ __global__ __launch_bounds__(256) void attn_kernel(const pv_attn_params p) {
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
             }
+    };
+
+    int ntiles = (p.nk + KB - 1) / KB;
+    if (p.causal) ntiles = min(ntiles, (min(qt * 128 + 127, p.nq - 1)) / KB + 1);
+    gload(0);
+    if (DBUF) {
+        swrite(0);
+        __syncthreads();
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        const int st = DBUF ? (t & 1) : 0;
+        if (!DBUF) {
+            __syncthreads();  // previous tile fully consumed
+            swrite(0);
+            __syncthreads();
+        }
+        if (t + 1 < ntiles) gload(t + 1);
+        const bool need_mask = p.causal || (t + 1) * KB > p.nk;
+        tile(t, st, need_mask);
+        if (DBUF) {
+            if (t + 1 < ntiles) swrite(st ^ 1);   // the other stage was last read in iteration t-1 (barrier below)
+            __syncthreads();
+        }
     }
 
     half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        const float inv = 1.0f / pv_quad_sum(l_run[qi]);
+        float l;
+        if (ONES) {
+            // denominator lives in output column D: fragment D/16, lanes with fq == (D%16)/4, register (D%4)
+            l = __shfl(o[D / 16][qi][D % 4], fr + 16 * ((D % 16) / 4), 64);
+        } else {
+            l = pv_quad_sum(l_run[qi]);
+        }
+        const float inv = 1.0f / l;
         if (qrow[qi] < p.nq) {
 #pragma unroll
             for (int f = 0; f < C::DVF; ++f) {
@@ -375,7 +435,11 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
 template <int D>
 int launch_attn(const pv_attn_params& p, hipStream_t s) {
     using C = ACfg<D>;
+#ifdef PV_ATTN_DBUF
+    constexpr int smem = 64 * (C::KS + C::VS) * 2 * (D <= 80 ? 2 : 1);
+#else
     constexpr int smem = 64 * (C::KS + C::VS) * 2;
+#endif
     hipLaunchKernelGGL(attn_kernel<D>, dim3((p.nq + 127) / 128, p.heads, p.batch), dim3(256), smem, s, p);
     return PV_CHECK_LAUNCH();
 }
