@@ -80,8 +80,9 @@ int pv_gemm_conv(const pv_gemm_params* p, void* stream);
  * GroupNorm(32 groups) over NHWC fp16, optionally over a channel concat of two tensors.
  * Replaces F.group_norm (+ SiLU) dispatches of [EXT] ResnetBlock2D.norm1/norm2,
  * Transformer2DModel.norm, conv_norm_out.
- *   pv_groupnorm_stats : partial (sum, sumsq) per (image, split, group) -> partial[B][S][G][2]
- *   pv_groupnorm_apply : y = act(gamma*(x-mean)*rstd+beta), contiguous fp16 [B*HW][C]
+ *   pv_groupnorm_stats : partial (sum, sumsq) per (image, split, group) -> partial[B][S][G][2], then reduced in a
+ *                        fixed order to (mean, rstd) stored at partial[b][0][g][0..1] (deterministic, no atomics)
+ *   pv_groupnorm_apply : y = act(gamma*(x-mean)*rstd+beta), contiguous fp16 [B*HW][C]; must follow _stats
  */
 typedef struct pv_groupnorm_params {
     const void* x0; const void* x1;  /* fp16 sources; x1 may be NULL */
@@ -179,6 +180,9 @@ int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t group
 /* ------------------------------------------------------------------------------------------
  * Pre-loop conditioning front ends (infer.py:76-96).
  */
+/* im2col of a 3x3 / pad-1 conv over NCHW fp32 with few channels (UNet conv_in): fp16 rows [B*H*W][kpad], column
+ * k = ci*9 + ky*3 + kx, zero padded (kpad % 64 == 0), so conv_in runs on pv_gemm_conv with w.reshape(cout, cin*9). */
+int pv_im2col3x3(const float* x, void* out, int32_t batch, int32_t cin, int32_t h, int32_t wd, int32_t kpad, void* stream);
 /* CLIP ViT patch embedding input: NCHW fp32 pixels -> fp16 rows [B*(img/patch)^2][kpad], one patch per row in
  * (channel, py, px) order = the flattened Conv2d(3,dim,patch,stride=patch) weight order, zero padded to kpad
  * (kpad % 64 == 0) so the patch embedding is a pv_gemm_conv call.  [EXT transformers CLIPVisionEmbeddings] */

@@ -69,6 +69,11 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else static_assert(N < 0, "add the immediate");
 }
 
@@ -200,67 +205,87 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    constexpr int PRE = Cfg::STAGES - 1;  // prefetch distance in K-steps
-#pragma unroll
-    for (int s = 0; s < PRE; ++s)
-        if (s < nk) stage(s, s);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once at most the loads of the (PRE-1) younger stages are still outstanding
-        if (PRE == 1 || kt + 1 >= nk) {
-            wait_vmcnt<0>();
-        } else if (b_full) {
-            wait_vmcnt<(4 + Cfg::B_PER_WAVE) * (PRE - 1)>();
-        } else {
-            wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1) * (PRE - 1)>();
-        }
-        // one barrier per K-step: (a) every wave's pieces of stage kt are visible, (b) every wave has finished reading the
-        // buffer of step kt-1, which the prefetch below overwrites.  Raw s_barrier: __syncthreads() would drain vmcnt.
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* sa = smem + (kt % Cfg::STAGES) * Cfg::STAGE_BYTES;
+    // ---- main loop ----------------------------------------------------------------------------------------------
+    // Each 64-deep K-step is two 32-deep halves (fragment sets F0, F1).  The workgroup barrier sits BETWEEN the halves:
+    //
+    //   iteration kt:   read F1(kt) | MFMA F0(kt)          <- LDS reads of one half overlap the MFMAs of the other
+    //                   wait stage kt+1 landed, lgkmcnt(0), s_barrier
+    //                   issue LDS-DMA of stage kt+S into buffer kt % S     (its reads were retired before the barrier)
+    //                   read F0(kt+1) | MFMA F1(kt)
+    //
+    // S = LDS stages (2 or 3): S-1 stages of global->LDS traffic are always in flight behind a COUNTED vmcnt (raw
+    // s_barrier: __syncthreads() would drain the DMA queue).  hipcc left alone serialises "ds_read, wait, 4 MFMA".
+    constexpr int S = Cfg::STAGES;
+    auto read_half = [&](half8_t (&xa)[4], half8_t (&wb)[NF], int kt, int ks) {
+        const char* sa = smem + (kt % S) * Cfg::STAGE_BYTES;
         const char* sb = sa + Cfg::A_BYTES;
-        // Explicit software pipeline (hipcc otherwise re-uses one fragment register per weight fragment and serialises
-        // "ds_read -> wait -> 4 MFMA"): issue ALL fragment reads of the K-step (2 x (4 + NF) ds_read_b128) up front, put the
-        // next stage's LDS-DMA issue between the two read groups, then run the 8*NF MFMAs back to back.
-        half8_t xa0[4], wb0[NF], xa1[4], wb1[NF];
-#if PV_ABLATE != 3
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) xa0[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, fq);
+        for (int mi = 0; mi < 4; ++mi) xa[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, ks * 4 + fq);
 #pragma unroll
-        for (int ni = 0; ni < NF; ++ni) wb0[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, fq);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if PV_ABLATE == 2   // timing experiment: no global->LDS traffic after the prologue
-        if (kt + PRE < nk && kt < 0) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
-#else
-        if (kt + PRE < nk) stage(kt + PRE, (kt + PRE) % Cfg::STAGES);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if PV_ABLATE == 3   // timing experiment: DMA only
-        if (kt >= 0) continue;
-#endif
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) xa1[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, 4 + fq);
-#pragma unroll
-        for (int ni = 0; ni < NF; ++ni) wb1[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, 4 + fq);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
+    };
+    auto mma_half = [&](const half8_t (&xa)[4], const half8_t (&wb)[NF]) {
 #if PV_ABLATE == 1   // timing experiment: LDS reads without the MFMAs
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa0[mi]), "v"(xa1[mi]));
+        for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa[mi]));
 #pragma unroll
-        for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb0[ni]), "v"(wb1[ni]));
+        for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb[ni]));
 #else
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[ni], xa0[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+#endif
+    };
+
 #pragma unroll
-        for (int ni = 0; ni < NF; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[ni], xa1[mi], acc[ni][mi], 0, 0, 0);
+    for (int s = 0; s < S; ++s)
+        if (s < nk) stage(s, s);
+    // stage 0 landed <=> at most the pieces of the younger issued stages are outstanding; drain fully when short
+    if (nk >= S && S == 3) {
+        if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE) * 2>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1) * 2>();
+    } else if (nk >= S && S == 2) {
+        if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1)>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    half8_t xa0[4], wb0[NF], xa1[4], wb1[NF];
+#if PV_ABLATE != 3
+    if (nk > 0) read_half(xa0, wb0, 0, 0);
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+#if PV_ABLATE != 3
+        read_half(xa1, wb1, kt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(xa0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (kt + 1 < nk) {
+            // stage kt+1 landed: all younger issued stages (kt+2 .. kt+S-1) may stay in flight, if they were all issued
+            if (S == 3 && kt + S - 1 < nk) {
+                if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1)>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer kt % S are retired
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#if PV_ABLATE != 2
+            if (kt + S < nk) stage(kt + S, kt % S);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if PV_ABLATE != 3
+            read_half(xa0, wb0, kt + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#if PV_ABLATE != 3
+        mma_half(xa1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
 #endif
     }
 

@@ -182,6 +182,33 @@ __global__ void rows_mean_kernel(const half_t* x, int ldx, half_t* y, int ldy, i
     *reinterpret_cast<half8_t*>(yo) = o;
 }
 
+// im2col of a 3x3 / pad 1 convolution over an NCHW fp32 tensor with few channels (the UNet's conv_in, cin = 4):
+// rows [B*H*W][kpad] fp16, column k = ci*9 + ky*3 + kx (the flattened Conv2d weight order), zero padded to kpad.
+// The conv itself then runs on the MFMA GEMM.
+__global__ void im2col3x3_kernel(const float* __restrict__ x, half_t* __restrict__ out, int batch, int cin, int h, int wd, int kpad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread = 8 consecutive columns of one row
+    const int nch = kpad >> 3;
+    if (idx >= (long)batch * h * wd * nch) return;
+    const int ch = (int)(idx % nch);
+    const long pix = idx / nch;
+    const int b = (int)(pix / (h * wd));
+    const int rem = (int)(pix - (long)b * h * wd);
+    const int y = rem / wd, xx = rem - y * wd;
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = ch * 8 + j;
+        float v = 0.f;
+        if (k < cin * 9) {
+            const int ci = k / 9, t = k - ci * 9;
+            const int iy = y + t / 3 - 1, ix = xx + t % 3 - 1;
+            if (iy >= 0 && iy < h && ix >= 0 && ix < wd) v = x[(((long)b * cin + ci) * h + iy) * wd + ix];
+        }
+        o[j] = (half_t)v;
+    }
+    *reinterpret_cast<half8_t*>(out + pix * kpad + ch * 8) = o;
+}
+
 // CLIP ViT patchify: NCHW fp32 pixels -> fp16 rows [B*gh*gw][kpad], row = one patch flattened (c, py, px), zero padded
 __global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int batch, int ch, int img, int patch, int kpad) {
     const int g = img / patch;
@@ -235,6 +262,14 @@ __global__ void text_embed_kernel(const int64_t* __restrict__ ids, const float* 
 }
 
 }  // namespace
+
+extern "C" int pv_im2col3x3(const float* x, void* out, int32_t batch, int32_t cin, int32_t h, int32_t wd, int32_t kpad, void* stream) {
+    if (batch <= 0 || cin <= 0 || h <= 0 || wd <= 0 || (kpad % 8) || kpad < cin * 9 || !x || !out) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * h * wd * (kpad / 8);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<half_t*>(out), batch, cin, h, wd, kpad);
+    return PV_CHECK_LAUNCH();
+}
 
 extern "C" int pv_patchify(const float* x, void* out, int32_t batch, int32_t ch, int32_t img, int32_t patch, int32_t kpad, void* stream) {
     if (batch <= 0 || ch <= 0 || img <= 0 || patch <= 0 || (img % patch) || kpad < ch * patch * patch || !x || !out)

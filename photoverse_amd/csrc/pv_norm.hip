@@ -54,23 +54,33 @@ __global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, c
     }
 }
 
+// partial (sum, sumsq) over the S splits -> (mean, rstd) per (image, group), written over partial[b][0][g][*]
+__global__ void gn_finalize_kernel(const pv_groupnorm_params p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.batch * p.groups) return;
+    const int b = idx / p.groups, g = idx - b * p.groups;
+    float* part = p.partial + ((size_t)b * p.splits * p.groups + g) * 2;
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+        a += part[(size_t)s * p.groups * 2];
+        q += part[(size_t)s * p.groups * 2 + 1];
+    }
+    const float n = (float)((p.c0 + p.c1) / p.groups) * (float)p.hw;
+    const float mean = a / n;
+    const float var = fmaxf(q / n - mean * mean, 0.f);
+    part[0] = mean;
+    part[1] = rsqrtf(var + p.eps);
+}
+
 __global__ void gn_apply_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass, const int px_per_block) {
     __shared__ float s_mean[64], s_rstd[64];
     const int C = p.c0 + p.c1;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     if (tid < p.groups) {
-        float a = 0.f, q = 0.f;
-        const float* part = p.partial + ((size_t)b * p.splits * p.groups + tid) * 2;
-        for (int s = 0; s < p.splits; ++s) {
-            a += part[(size_t)s * p.groups * 2];
-            q += part[(size_t)s * p.groups * 2 + 1];
-        }
-        const float n = (float)(C / p.groups) * (float)p.hw;
-        const float mean = a / n;
-        const float var = fmaxf(q / n - mean * mean, 0.f);
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + p.eps);
+        const float* part = p.partial + ((size_t)b * p.splits * p.groups + tid) * 2;   // finalized by gn_finalize_kernel
+        s_mean[tid] = part[0];
+        s_rstd[tid] = part[1];
     }
     __syncthreads();
     const int chunk = tid % nchunk, r = tid / nchunk;
@@ -182,6 +192,8 @@ extern "C" int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream) {
     if (threads < p->groups) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(p->splits, p->batch), dim3(threads), (size_t)rpp * 2 * C * sizeof(float), (hipStream_t)stream, *p,
                        nchunk, rpp);
+    const int ng = p->batch * p->groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }
 
@@ -190,7 +202,7 @@ extern "C" int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream) {
     if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->x0 || !p->y || !p->gamma || !p->beta)
         return (int)hipErrorInvalidValue;
     if (threads < p->groups) return (int)hipErrorInvalidValue;
-    const int px_per_block = 64;
+    const int px_per_block = 128;
     const int gx = (p->hw + px_per_block - 1) / px_per_block;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, p->batch), dim3(threads), 0, (hipStream_t)stream, *p, nchunk, rpp, px_per_block);
     return PV_CHECK_LAUNCH();

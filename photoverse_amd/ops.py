@@ -210,6 +210,12 @@ class Recorder:
         self._add(self.lib.pv_conv_in, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, h, wd, cout)
         return out
 
+    def im2col3x3(self, x, *, batch, cin, h, wd, kpad):
+        out = self.empty((batch * h * wd, kpad), torch.float16)
+        self.keep.append(x)
+        self._add(self.lib.pv_im2col3x3, _ptr(x), _ptr(out), batch, cin, h, wd, kpad)
+        return out
+
     def conv_out(self, x, w, bias, *, batch, cin, h, wd, cout, out=None):
         if out is None:
             out = self.empty((batch, cout, h, wd), torch.float32)

@@ -58,6 +58,9 @@ class DenoiseLoop:
             require_cuda(text, "text embeddings")
             dt.copy_(text.reshape(dt.shape))
             di.copy_(ip.reshape(di.shape))
+        # K/V projections of the conditioning: once per generation, outside the per-step graph
+        self.eng_u.run_conditioning()
+        self.eng_c.run_conditioning()
 
     def reset(self, noise: torch.Tensor):
         """latents = noise * init_noise_sigma (``infer.py:70``); step counter to 0."""
