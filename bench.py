@@ -66,12 +66,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or "RANK" in os.environ            # launched by torch.distributed.run (also with one rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     from photoverse_amd.pipeline import DenoiseLoop, gather_latents, shard_batch
@@ -94,7 +96,7 @@ def main():
     loop.reset(noise[sl])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -108,9 +110,9 @@ def main():
         loop.step()
     barrier()
     dt = time.perf_counter() - t0
-    final = gather_latents(loop.latents, world)      # the single collective of the path
+    final = gather_latents(loop.latents, world, force=use_dist)      # the single collective of the path
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
@@ -165,7 +167,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libphotoverse_hip.so")
 SOURCES = ["pv_gemm.hip", "pv_norm.hip", "pv_attn.hip", "pv_misc.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+#: per-source extra flags.  The attention kernels keep MFMA results in VGPRs (the softmax VALU work reads them directly;
+#: AGPR-form costs ~200 v_accvgpr moves per tile); the 256-row GEMM variant needs the AGPR half for its accumulators.
+EXTRA_FLAGS = {"pv_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -42,7 +45,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=4) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):

@@ -32,14 +32,16 @@ struct pv_gemm_params_dev : pv_gemm_params {
     uint32_t a0_bytes, a1_bytes, w_bytes;
 };
 
-// WM = waves along M (each wave owns 64 rows): WM=2 -> 128-row tile, 4 waves, 2 LDS stages, 2 workgroups / CU
-//                                              WM=4 -> 256-row tile, 8 waves, 3 LDS stages (prefetch distance 2), 1 / CU
+// WM=2 -> 128-row tile, wave tile  64 x BN/2, 2 LDS stages, 2 workgroups / CU (two waves per SIMD)
+// WM=4 -> 256-row tile, wave tile 128 x BN/2, 3 LDS stages, 1 workgroup / CU (ONE wave per SIMD, up to 512 registers)
 template <int NF, int WM>
 struct TileCfg {
-    static constexpr int BM = WM * 64;
+    static constexpr int MI = WM * 2;              // 16-row M fragments per wave: 4 (128-row tile) or 8 (256-row tile)
+    static constexpr int BM = 2 * MI * 16;
     static constexpr int BN = NF * 32;
-    static constexpr int NWAVES = WM * 2;
+    static constexpr int NWAVES = 4;               // 2 x 2 waves; WM=4: one wave per SIMD with a 128 x (BN/2) register tile
     static constexpr int THREADS = NWAVES * 64;
+    static constexpr int A_PER_WAVE = BM / 8 / NWAVES;   // 8-row LDS-DMA pieces of the activation tile per wave
     static constexpr int STAGES = WM == 4 ? 3 : 2;
     static constexpr int A_BYTES = BM * ROW_BYTES;
     static constexpr int B_BYTES = BN * ROW_BYTES;
@@ -63,26 +65,18 @@ __device__ __forceinline__ half8_t lds_frag(const char* base, int row, int chunk
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else static_assert(N < 0, "add the immediate");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int NF, int WM, bool CONV, bool GEGLU>
-__global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
+__global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int m_fast) {
     using Cfg = TileCfg<NF, WM>;
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NWAVES;
+    constexpr int MI = Cfg::MI;
+    constexpr int AP = Cfg::A_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = pv_lane_id();
@@ -117,12 +111,12 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     const bool fast_conv = CONV && p.stride == 1 && !p.upsample;
     const int hl = p.upsample ? p.hin * 2 : p.hin;
     const int wl = p.upsample ? p.win * 2 : p.win;
-    // A: 4 pieces per wave; piece j = wave + i*NW covers tile rows [8j, 8j+8)
-    unsigned a_off0[4], a_off1[4];   // byte offset of the row (centre pixel for convs) in source 0 / 1, + lane chunk
-    unsigned a_mask[4];              // conv: bit t set <=> filter tap t reads inside the image
-    int a_b[4], a_y[4], a_x[4];      // generic (strided / upsampled) conv path only
+    // A: AP pieces per wave; piece j = wave + i*NW covers tile rows [8j, 8j+8)
+    unsigned a_off0[AP], a_off1[AP];   // byte offset of the row (centre pixel for convs) in source 0 / 1, + lane chunk
+    unsigned a_mask[AP];             // conv: bit t set <=> filter tap t reads inside the image
+    int a_b[AP], a_y[AP], a_x[AP];   // generic (strided / upsampled) conv path only
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AP; ++i) {
         const int m = m0 + (wave + i * NW) * 8 + lrow;
         const bool ok = m < p.M;
         if (CONV) {
@@ -173,7 +167,7 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
         const int ky = tap / 3, kx = tap - ky * 3;
         const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;   // fast path: centre pixel -> tap pixel
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AP; ++i) {
             unsigned off;
             if (!CONV) {
                 off = (first ? a_off0[i] : a_off1[i]) + (unsigned)sc2;   // OOB rows stay out of range (sc2 < 2^16)
@@ -196,11 +190,11 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     };
 
     // ---- accumulators: acc[ni][mi], D[i = n][j = m] ----------------------------------------
-    float4_t acc[NF][4];
+    float4_t acc[NF][MI];
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
@@ -216,25 +210,25 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     // S = LDS stages (2 or 3): S-1 stages of global->LDS traffic are always in flight behind a COUNTED vmcnt (raw
     // s_barrier: __syncthreads() would drain the DMA queue).  hipcc left alone serialises "ds_read, wait, 4 MFMA".
     constexpr int S = Cfg::STAGES;
-    auto read_half = [&](half8_t (&xa)[4], half8_t (&wb)[NF], int kt, int ks) {
+    auto read_half = [&](half8_t (&xa)[MI], half8_t (&wb)[NF], int kt, int ks) {
         const char* sa = smem + (kt % S) * Cfg::STAGE_BYTES;
         const char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) xa[mi] = lds_frag(sa, wm * 64 + mi * 16 + fr, ks * 4 + fq);
+        for (int mi = 0; mi < MI; ++mi) xa[mi] = lds_frag(sa, wm * (MI * 16) + mi * 16 + fr, ks * 4 + fq);
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
     };
-    auto mma_half = [&](const half8_t (&xa)[4], const half8_t (&wb)[NF]) {
+    auto mma_half = [&](const half8_t (&xa)[MI], const half8_t (&wb)[NF]) {
 #if PV_ABLATE == 1   // timing experiment: LDS reads without the MFMAs
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(xa[mi]));
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xa[mi]));
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb[ni]));
 #else
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
 #endif
     };
@@ -244,16 +238,16 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
         if (s < nk) stage(s, s);
     // stage 0 landed <=> at most the pieces of the younger issued stages are outstanding; drain fully when short
     if (nk >= S && S == 3) {
-        if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE) * 2>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1) * 2>();
+        if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE) * 2>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1) * 2>();
     } else if (nk >= S && S == 2) {
-        if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1)>();
+        if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1)>();
     } else {
         wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    half8_t xa0[4], wb0[NF], xa1[4], wb1[NF];
+    half8_t xa0[MI], wb0[NF], xa1[MI], wb1[NF];
 #if PV_ABLATE != 3
     if (nk > 0) read_half(xa0, wb0, 0, 0);
 #endif
@@ -267,7 +261,7 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
         if (kt + 1 < nk) {
             // stage kt+1 landed: all younger issued stages (kt+2 .. kt+S-1) may stay in flight, if they were all issued
             if (S == 3 && kt + S - 1 < nk) {
-                if (b_full) wait_vmcnt<(4 + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(4 + Cfg::B_PER_WAVE - 1)>();
+                if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1)>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -293,8 +287,8 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
     if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
         float* slab = p.splitk_ws + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
             if (m >= p.M) continue;
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
@@ -304,45 +298,64 @@ __global__ __launch_bounds__(WM * 128, WM == 4 ? 2 : 2) void gemm_conv_kernel(co
         }
         return;
     }
+    // All epilogue loads (bias, time-embedding row, residual) are issued up front into registers and only then consumed:
+    // interleaving "load, wait, store" per fragment serialises ~20 memory round trips per thread (measured: 35 us of a
+    // 45 us K=320 GEMM).
+    const int nbase = n0 + wn * (NF * 16) + fq * 4;
+    if (GEGLU) {
+        float4_t bv[NF / 2], bg[NF / 2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        if (m >= p.M) continue;
-        const float* radd = nullptr;
-        if (p.rowadd) radd = p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld;
-        if (GEGLU) {
+        for (int q = 0; q < NF / 2; ++q) {
+            bv[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+            bg[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q + 1) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
+            if (m >= p.M) continue;
 #pragma unroll
             for (int q = 0; q < NF / 2; ++q) {
-                const int npk = n0 + wn * (NF * 16) + (2 * q) * 16 + fq * 4;   // packed column of the value fragment
                 const int j = (n0 >> 1) + wn * (NF * 8) + q * 16 + fq * 4;      // logical output column
-                float4_t v = acc[2 * q][mi], g = acc[2 * q + 1][mi];
-                if (p.bias) {
-                    const float4_t bv = *reinterpret_cast<const float4_t*>(p.bias + npk);
-                    const float4_t bg = *reinterpret_cast<const float4_t*>(p.bias + npk + 16);
-                    v += bv;
-                    g += bg;
-                }
+                const float4_t v = acc[2 * q][mi] + bv[q], g = acc[2 * q + 1][mi] + bg[q];
                 half4_t o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * pv_gelu_erf(g[r]));
                 *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + j) = o;
             }
-        } else {
+        }
+    } else {
+        float4_t bias_v[NF];
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+            bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        half4_t res[NF][MI];
+        if (p.residual) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = min(m0 + wm * (MI * 16) + mi * 16 + fr, p.M - 1);
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    res[ni][mi] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + nbase + ni * 16);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
+            if (m >= p.M) continue;
+            const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
-                const int n = n0 + wn * (NF * 16) + ni * 16 + fq * 4;
-                float4_t v = acc[ni][mi];
-                if (p.bias) v += *reinterpret_cast<const float4_t*>(p.bias + n);
-                if (radd) v += *reinterpret_cast<const float4_t*>(radd + n);
+                float4_t v = acc[ni][mi] + bias_v[ni];
+                if (radd) v += *reinterpret_cast<const float4_t*>(radd + ni * 16);
                 if (p.act) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
                 }
                 if (p.residual) {
-                    const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[ni][mi][r];
                 }
+                const int n = nbase + ni * 16;
                 if (p.out_f32) {
                     *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
                 } else {

@@ -113,11 +113,11 @@ def shard_batch(total: int, rank: int, world: int) -> slice:
     return slice(rank * per, (rank + 1) * per)
 
 
-def gather_latents(local: torch.Tensor, world: int) -> torch.Tensor:
+def gather_latents(local: torch.Tensor, world: int, force: bool = False) -> torch.Tensor:
     """The single collective of the multi-GPU path: all_gather of the final latents (RCCL over xGMI on GPUs,
     gloo in the CPU tests).  Rank order == batch order, so the result equals the 1-GPU run sample for sample."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
