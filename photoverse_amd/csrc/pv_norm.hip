@@ -22,7 +22,22 @@ __global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, c
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum[j] = sq[j] = 0.f;
     const size_t row0 = (size_t)b * p.hw + (size_t)s * pps;
-    for (int px = r; px < pps; px += rows_per_pass) {
+    // 4 independent 16-byte loads in flight per thread (the kernel is a pure HBM stream)
+    int px = r;
+    for (; px + 3 * rows_per_pass < pps; px += 4 * rows_per_pass) {
+        half8_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_load(p, row0 + px + u * rows_per_pass, chunk);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[u][j];
+                sum[j] += f;
+                sq[j] += f * f;
+            }
+    }
+    for (; px < pps; px += rows_per_pass) {
         const half8_t v = gn_load(p, row0 + px, chunk);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -54,22 +69,29 @@ __global__ void gn_stats_kernel(const pv_groupnorm_params p, const int nchunk, c
     }
 }
 
-// partial (sum, sumsq) over the S splits -> (mean, rstd) per (image, group), written over partial[b][0][g][*]
+// partial (sum, sumsq) over the S <= 64 splits -> (mean, rstd) per (image, group), written over partial[b][0][g][*].
+// One wave per (image, group): lane s loads split s, fixed shuffle tree (deterministic) - a serial loop of S dependent
+// loads per thread took 17 us here.
 __global__ void gn_finalize_kernel(const pv_groupnorm_params p) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (idx >= p.batch * p.groups) return;
     const int b = idx / p.groups, g = idx - b * p.groups;
     float* part = p.partial + ((size_t)b * p.splits * p.groups + g) * 2;
     float a = 0.f, q = 0.f;
-    for (int s = 0; s < p.splits; ++s) {
-        a += part[(size_t)s * p.groups * 2];
-        q += part[(size_t)s * p.groups * 2 + 1];
+    if (lane < p.splits) {
+        a = part[(size_t)lane * p.groups * 2];
+        q = part[(size_t)lane * p.groups * 2 + 1];
     }
-    const float n = (float)((p.c0 + p.c1) / p.groups) * (float)p.hw;
-    const float mean = a / n;
-    const float var = fmaxf(q / n - mean * mean, 0.f);
-    part[0] = mean;
-    part[1] = rsqrtf(var + p.eps);
+    a = pv_wave_sum(a);
+    q = pv_wave_sum(q);
+    if (lane == 0) {
+        const float n = (float)((p.c0 + p.c1) / p.groups) * (float)p.hw;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        part[0] = mean;
+        part[1] = rsqrtf(var + p.eps);
+    }
 }
 
 __global__ void gn_apply_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass, const int px_per_block) {
@@ -97,18 +119,25 @@ __global__ void gn_apply_kernel(const pv_groupnorm_params p, const int nchunk, c
     const int px0 = blockIdx.x * px_per_block;
     const int px1 = min(px0 + px_per_block, p.hw);
     half_t* y = reinterpret_cast<half_t*>(p.y);
-    for (int px = px0 + r; px < px1; px += rows_per_pass) {
-        const size_t row = (size_t)b * p.hw + px;
-        const half8_t v = gn_load(p, row, chunk);
+    auto norm_store = [&](const half8_t& v, size_t row) {
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = (float)v[j] * sc[j] + sf[j];
-            if (p.act == PV_ACT_SILU) f = pv_silu(f);
+            if (p.act == PV_ACT_SILU) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
             o[j] = (half_t)f;
         }
         *reinterpret_cast<half8_t*>(y + row * C + chunk * 8) = o;
+    };
+    int px = px0 + r;
+    for (; px + 3 * rows_per_pass < px1; px += 4 * rows_per_pass) {   // 4 loads in flight per thread
+        half8_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_load(p, (size_t)b * p.hw + px + u * rows_per_pass, chunk);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) norm_store(v[u], (size_t)b * p.hw + px + u * rows_per_pass);
     }
+    for (; px < px1; px += rows_per_pass) norm_store(gn_load(p, (size_t)b * p.hw + px, chunk), (size_t)b * p.hw + px);
 }
 
 // one wave per row; lane owns chunks lane, lane+64, ...
@@ -173,7 +202,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const pv_layernorm_param
 
 bool gn_geometry(const pv_groupnorm_params& p, int& nchunk, int& threads, int& rpp) {
     const int C = p.c0 + p.c1;
-    if (C <= 0 || (C % 8) || (p.c0 % 8) || p.groups <= 0 || p.groups > 64 || (C % p.groups) || p.splits <= 0 || (p.hw % p.splits))
+    if (C <= 0 || (C % 8) || (p.c0 % 8) || p.groups <= 0 || p.groups > 64 || (C % p.groups) || p.splits <= 0 || p.splits > 64 || (p.hw % p.splits))
         return false;
     nchunk = C / 8;
     if (nchunk > 1024) return false;
@@ -193,7 +222,7 @@ extern "C" int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(p->splits, p->batch), dim3(threads), (size_t)rpp * 2 * C * sizeof(float), (hipStream_t)stream, *p,
                        nchunk, rpp);
     const int ng = p->batch * p->groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }
 
@@ -202,7 +231,9 @@ extern "C" int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream) {
     if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->x0 || !p->y || !p->gamma || !p->beta)
         return (int)hipErrorInvalidValue;
     if (threads < p->groups) return (int)hipErrorInvalidValue;
-    const int px_per_block = 128;
+    // enough workgroups to fill the chip (>= ~4096 when the tensor allows), at least 8 pixel rows each
+    long ppb = ((long)p->batch * p->hw) / 4096;
+    const int px_per_block = (int)(ppb < 8 ? 8 : (ppb > 128 ? 128 : ppb));
     const int gx = (p->hw + px_per_block - 1) / px_per_block;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, p->batch), dim3(threads), 0, (hipStream_t)stream, *p, nchunk, rpp, px_per_block);
     return PV_CHECK_LAUNCH();
