@@ -19,6 +19,11 @@ from ._lib import AttnParams, GemmParams, GroupNormParams, LayerNormParams, XAtt
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
+import os as _os
+#: split-K heuristic: split until about SPLITK_TARGET workgroups exist (2 per CU), at most SPLITK_MAX ways
+SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "8"))
+SPLITK_TARGET = int(_os.environ.get("PV_SPLITK_TARGET", "512"))
+
 
 class HipLaunchError(RuntimeError):
     pass
@@ -132,7 +137,7 @@ class Recorder:
         kdim = taps * (c0 + c1)
         bn = 128 if (geglu or N % 160) else 160
         tiles = ((M + 127) // 128) * (N // bn)
-        splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(8, 512 // tiles, (kdim // 64) // 8)))
+        splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
                        _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), None, splitk, _ptr(ws))
