@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--ip-tokens", type=int, default=1, help="image tokens per sample (reference inference default: 1)")
     ap.add_argument("--guidance", type=float, default=7.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="run the uncond / cond forwards back to back on one stream instead of as two parallel graph branches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -85,7 +87,7 @@ def main():
     unet.to(dev)
 
     B, S, P, T = args.batch, args.latent, args.ip_tokens, max(args.steps, 1)
-    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph)
+    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream)
     g = torch.Generator().manual_seed(1234)    # global batch drawn once on CPU (infer.py:52-59), sliced per rank
     GB = B * world
     noise = torch.randn(GB, 4, S, S, generator=g)
@@ -141,6 +143,9 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         ach = flops / (ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "measured": "HIP events around a back-to-back replay of this kernel's launches of one step on one stream "
+                                "(in the timed loop the uncond/cond forwards are two overlapping graph branches, so rocprof "
+                                "per-dispatch durations of the default run include co-scheduling; `--one-stream` is the matching run)",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": nl,
                     "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
                     "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
@@ -160,7 +165,7 @@ def main():
             "data": "synthetic (random-init SD-v1.5-shaped weights, N(0,1) latents / text / image-token embeddings)",
             "config": {"workload": "configs[1]: SD-v1.5 UNet + PhotoVerse processors, 50-step loop, bs=16/GPU, 512x512 (64x64 latents), fp16",
                        "per_gpu_batch": B, "global_batch": GB, "latent": S, "ip_tokens": P, "guidance_scale": args.guidance,
-                       "parallelism": f"dp{world} (batch-sharded, 1 all_gather)", "hip_graph": not args.no_graph,
+                       "parallelism": f"dp{world} (batch-sharded, 1 all_gather)", "hip_graph": not args.no_graph, "graph_branches": 1 if args.one_stream else 2,
                        "launches_per_step": loop.launches_per_step},
             "finite": finite,
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),

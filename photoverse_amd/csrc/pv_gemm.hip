@@ -18,6 +18,9 @@
 #ifndef PV_ABLATE
 #define PV_ABLATE 0   // 1/2/3: timing-only builds (wrong results), see tools/ablate.sh
 #endif
+#ifndef PV_BIG_TILES
+#define PV_BIG_TILES 1 // 0: never dispatch the 256-row big-tile kernel (A/B experiments)
+#endif
 #ifndef PV_FORCE_WM
 #define PV_FORCE_WM 0 // 2 or 4: force the tile variant (experiments)
 #endif
@@ -369,6 +372,239 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
     }
 }
 
+// =================================================================================================================
+// Big-tile variant for the large-M layers: 256 x BN x 32 tile, 4 waves (2 x 2, wave tile 128 x BN/2: 8 x NF fragments,
+// accumulators in the AGPR half of the register file -> ONE wave per SIMD per workgroup), THREE LDS stages of 32-deep
+// K-steps (26.6 KB each at BN = 160) so that TWO workgroups still fit a CU: two independent workgroups per CU keep the
+// latency hiding of the 128-row kernel, while the tile's arithmetic intensity against the L2->LDS path rises from 71 to
+// 98 flop/B (that path, ~70 GB/s per CU, is what bounds the 128-row kernel: profiles/r01_ablate_gemm.txt).
+// Fragments are double-buffered in registers ACROSS K-steps: the ds_reads of step kt+1 are issued before the MFMAs of kt.
+// LDS rows are 64 B; bank-conflict swizzle: 16-B chunk ^= SWZ[(row >> 2) & 3], SWZ = {0,3,2,1} (conflict-free for the
+// 16-lane groups of ds_read_b128), applied on the per-lane DMA source offset and on the read.
+constexpr int BIG_BM = 256;
+constexpr int BIG_BK = 32;
+constexpr int BIG_ROWB = BIG_BK * 2;   // 64 B per LDS row
+constexpr int BIG_S = 3;
+
+__device__ __forceinline__ int big_swz(int g) { return (4 - g) & 3; }   // {0,3,2,1}
+
+__device__ __forceinline__ half8_t big_frag(const char* base, int row, int q) {
+    return *reinterpret_cast<const half8_t*>(base + row * BIG_ROWB + ((q ^ big_swz((row >> 2) & 3)) << 4));
+}
+
+template <int NF, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
+    constexpr int BN = NF * 32;
+    constexpr int MI = 8;
+    constexpr int STAGE_BYTES = (BIG_BM + BN) * BIG_ROWB;
+    constexpr int A_BYTES = BIG_BM * BIG_ROWB;
+    constexpr int AP = BIG_BM / 16 / 4;                 // 16-row DMA pieces of the activation tile per wave (4)
+    constexpr int B_PIECES = BN / 16;                   // 10 (NF=5) or 8 (NF=4)
+    constexpr int BP = (B_PIECES + 3) / 4;              // max pieces per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = pv_lane_id();
+    const int wave = pv_wave_id();
+    const int bid = pv_xcd_remap((int)blockIdx.x, nblk);
+    const int tiles_m = nblk / tiles_n;
+    const int tile_m = m_fast ? bid % tiles_m : bid / tiles_n;
+    const int tile_n = m_fast ? bid / tiles_m : bid % tiles_n;
+    const int m0 = tile_m * BIG_BM;
+    const int n0 = tile_n * BN;
+    const int cin = p.c0 + p.c1;
+    const int K = p.taps * cin;
+    const int nk = K / BIG_BK;
+
+    const int lrow = lane >> 2;                                  // row inside the 16-row piece
+    const int lane_cc2 = ((lane & 3) ^ big_swz(lane >> 4)) * 16; // swizzled source chunk, bytes inside the 64-B slab
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int hw_out = p.hout * p.wout;
+
+    unsigned a_off0[AP], a_off1[AP], a_mask[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + (wave + i * 4) * 16 + lrow;
+        const bool ok = m < p.M;
+        if (CONV) {   // stride 1, no upsample (the launcher only routes those here)
+            const int b = m / hw_out;
+            const int rem = m - b * hw_out;
+            const int y = rem / p.wout, x = rem - y * p.wout;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                if (ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win) mask |= 1u << t;
+            }
+            a_mask[i] = mask;
+            const unsigned pix = (unsigned)((b * p.hin + y) * p.win + x);
+            a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
+            a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
+        } else {
+            a_mask[i] = 1u;
+            a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
+            a_off1[i] = ok ? (unsigned)m * (unsigned)(p.lda1 * 2) + lane_cc2 : OOB;
+        }
+    }
+    unsigned w_off[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + min(wave + i * 4, B_PIECES - 1) * 16 + lrow;
+        w_off[i] = (unsigned)n * (unsigned)(K * 2) + lane_cc2;
+    }
+    const bool b_full = (B_PIECES % 4 == 0) || (wave + (BP - 1) * 4 < B_PIECES);
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+        // K order: 64-channel slab major, filter tap, then the two 32-channel halves of the slab
+        const int half = kt & 1;
+        const int kt2 = kt >> 1;
+        const int slab = CONV ? kt2 / 9 : kt2;
+        const int tap = CONV ? kt2 - slab * 9 : 0;
+        const int c = slab * 64 + half * 32;
+        const bool first = c < p.c0;
+        const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
+        const int ld2 = (first ? p.lda0 : p.lda1) * 2;
+        const int sc2 = (first ? c : c - p.c0) * 2;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            unsigned off;
+            if (!CONV) off = (first ? a_off0[i] : a_off1[i]) + (unsigned)sc2;
+            else off = ((a_mask[i] >> tap) & 1u) ? (first ? a_off0[i] : a_off1[i]) + (unsigned)tap_delta : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * 4) * 16 * BIG_ROWB), 16, (int)off, 0, 0, 0);
+        }
+        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            if (i < BP - 1 || b_full)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + i * 4) * 16 * BIG_ROWB), 16, (int)(w_off[i] + wk2), 0, 0, 0);
+        }
+    };
+
+    float4_t acc[NF][MI];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // One K-step (32 deep) with ONE fragment register set (two workgroups per CU need <= 256 registers per lane):
+    //   wait stage kt landed, barrier, refill the buffer of step kt-1 with stage kt+S-1,
+    //   read W[NF] + A[0..3], issue the reads of A[4..7], MFMA W x A[0..3]  (covers those reads), MFMA W x A[4..7]
+    half8_t xa[MI], wb[NF];
+#pragma unroll
+    for (int s = 0; s < BIG_S - 1; ++s)
+        if (s < nk) stage(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + BIG_S - 2 < nk) {   // stage kt+1 (.. kt+S-2) was issued and may stay in flight
+            if (b_full) wait_vmcnt<(AP + BP) * (BIG_S - 2)>(); else wait_vmcnt<(AP + BP - 1) * (BIG_S - 2)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();   // stage kt visible to all; every wave has consumed (lgkmcnt) the fragments of step kt-1
+        asm volatile("" ::: "memory");
+        if (kt + BIG_S - 1 < nk) stage(kt + BIG_S - 1, (kt + BIG_S - 1) % BIG_S);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sa = smem + (kt % BIG_S) * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) wb[ni] = big_frag(sb, wn * (NF * 16) + ni * 16 + fr, fq);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xa[mi] = big_frag(sa, wm * 128 + mi * 16 + fr, fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 4; mi < 8; ++mi) xa[mi] = big_frag(sa, wm * 128 + mi * 16 + fr, fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = 4; mi < 8; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (bias, time-embedding row, activation, residual; loads batched ahead of the stores) ----
+    const int nbase = n0 + wn * (NF * 16) + fq * 4;
+    float4_t bias_v[NF];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+        bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {            // two halves of the 8 M-fragments: bounds the registers of the batched residual
+        half4_t res[NF][4];
+        if (p.residual) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = min(m0 + wm * 128 + (mh * 4 + mi) * 16 + fr, p.M - 1);
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    res[ni][mi] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + nbase + ni * 16);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 128 + (mh * 4 + mi) * 16 + fr;
+            if (m >= p.M) continue;
+            const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) {
+                float4_t v = acc[ni][mh * 4 + mi] + bias_v[ni];
+                if (radd) v += *reinterpret_cast<const float4_t*>(radd + ni * 16);
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[ni][mi][r];
+                }
+                const int n = nbase + ni * 16;
+                if (p.out_f32) {
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                    *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NF, bool CONV>
+int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
+    constexpr int BN = NF * 32;
+    constexpr int SMEM = BIG_S * (BIG_BM + BN) * BIG_ROWB;
+    static bool attr_set = false;
+    auto kern = gemm_big_kernel<NF, CONV>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    const size_t wbytes = (size_t)p.N * p.taps * (p.c0 + p.c1) * 2;
+    const int m_fast = (wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), SMEM, stream, p, tiles_n, nblk, m_fast);
+    return PV_CHECK_LAUNCH();
+}
+
 // sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue
 __global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int splits) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +666,15 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
     if (PV_FORCE_WM == 4) return launch<NF, 4, CONV, GEGLU>(p, stream);
+#if PV_FORCE_WM != 2
+    if constexpr (!GEGLU) {
+        // big tile when it still gives every CU two workgroups; convs: stride 1 / no upsample only
+        const long tiles256 = (long)((p.M + BIG_BM - 1) / BIG_BM) * (p.N / (NF * 32));
+        const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);
+        // measured (profiles/r01_kbench_c.txt): ~3 % faster on the 64x64-level 3x3 convs, not on the short-K Linear layers
+        if (PV_BIG_TILES && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, CONV>(p, stream);
+    }
+#endif
     return launch<NF, 2, CONV, GEGLU>(p, stream);
 }
 

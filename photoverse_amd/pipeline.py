@@ -20,7 +20,8 @@ from .scheduler import DPMSolverMultistepScheduler
 
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
-                 scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True):
+                 scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
+                 two_streams: bool = True):
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
@@ -49,6 +50,8 @@ class DenoiseLoop:
         self.tail.step_advance(self.state)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
+        self.two_streams = two_streams
+        self._side = torch.cuda.Stream(device=dev) if two_streams else None
         self.launches_per_step = len(self.eng_u.rec) + len(self.eng_c.rec) + len(self.tail)
 
     # ------------------------------------------------------------------
@@ -69,8 +72,19 @@ class DenoiseLoop:
         self.state.zero_()
 
     def _step_eager(self):
-        self.eng_u.rec.run()
-        self.eng_c.rec.run()
+        if self.two_streams:
+            # the unconditional and conditional forwards are independent until the CFG combine: fork them onto two HIP
+            # streams (two parallel branches of the captured graph) so the small low-resolution launches of one overlap
+            # the other's; joined before the combine
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.eng_c.rec.run()
+            self.eng_u.rec.run()
+            main.wait_stream(self._side)
+        else:
+            self.eng_u.rec.run()
+            self.eng_c.rec.run()
         self.tail.run()
 
     def capture(self):

@@ -30,7 +30,8 @@ def h16(*shape, scale=1.0, seed=0):
 
 # the last three shapes give >= 256 tiles of 256 rows and take the 8-wave / 3-stage instantiation (incl. an M tail)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 640, 768), (16, 1280, 1280), (130, 128, 64), (128, 1024, 4096),
-                                   (16384, 640, 640), (32700, 320, 64), (8192, 1024, 128)])
+                                   (16384, 640, 640), (32700, 320, 64), (8192, 1024, 128),
+                                   (65536, 320, 128), (33000, 640, 192), (32768, 512, 64)])   # >= 512 tiles of 256 rows: big-tile kernel
 def test_gemm_bias_residual_act(rec_cls, M, N, K):
     from photoverse_amd import ops
     a, w, res = h16(M, K, seed=1), h16(N, K, scale=K ** -0.5, seed=2), h16(M, N, seed=3)
@@ -104,7 +105,8 @@ def test_gemm_geglu_fused_matches_unfused(rec_cls):
 @pytest.mark.parametrize("cin,cout,h,stride,ups,B", [(320, 320, 16, 1, 0, 2), (640, 320, 8, 1, 0, 2), (320, 320, 16, 2, 0, 2),
                                                      (320, 640, 8, 1, 1, 2), (64, 128, 5, 1, 0, 2),
                                                      (64, 320, 64, 1, 0, 8), (128, 128, 32, 1, 1, 4),
-                                                     (1280, 1280, 8, 1, 0, 4), (640, 1280, 8, 2, 0, 2)])   # last two: split-K heuristic
+                                                     (1280, 1280, 8, 1, 0, 4), (640, 1280, 8, 2, 0, 2),   # split-K heuristic
+                                                     (64, 320, 64, 1, 0, 16), (128, 256, 64, 1, 0, 8)])   # big-tile kernel
 def test_conv3x3(rec_cls, cin, cout, h, stride, ups, B):
     x = h16(B, cin, h, h, seed=11)
     w = h16(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=12)
@@ -129,6 +131,20 @@ def test_conv3x3_dual_source(rec_cls):
     B, c0, c1, cout, h = 2, 320, 640, 320, 8
     x0, x1 = h16(B, c0, h, h, seed=16), h16(B, c1, h, h, seed=17)
     w = h16(cout, c0 + c1, 3, 3, scale=0.01, seed=18)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * h * h, -1).contiguous().cuda()
+    rec = rec_cls("cuda")
+    out = rec.gemm(rows(x0), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), a1=rows(x1),
+                   conv=dict(batch=B, hin=h, win=h, hout=h, wout=h))
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(torch.cat([x0, x1], 1).float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(B * h * h, cout)
+    assert rel_l2(out, ref) < 1e-3
+
+
+def test_conv3x3_dual_source_big_tile(rec_cls):
+    B, c0, c1, cout, h = 16, 64, 128, 320, 64
+    x0, x1 = h16(B, c0, h, h, seed=51), h16(B, c1, h, h, seed=52)
+    w = h16(cout, c0 + c1, 3, 3, scale=0.02, seed=53)
     rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * h * h, -1).contiguous().cuda()
     rec = rec_cls("cuda")
     out = rec.gemm(rows(x0), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), a1=rows(x1),

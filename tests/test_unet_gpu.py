@@ -112,17 +112,18 @@ def test_denoise_loop_matches_oracle_and_graph_equals_eager(tiny_pair, steps, P)
     noise = draw_noise_ref(B, 4, 16, seed=5)
     exp = denoise_ref(ref, noise, cond, uncond, guidance_scale=7.5, timesteps=steps)
     outs = []
-    for use_graph in (False, True):
-        loop = DenoiseLoop(hip, B, 16, P, steps, 7.5, use_graph=use_graph)
+    for use_graph, two in ((False, False), (True, False), (True, True)):
+        loop = DenoiseLoop(hip, B, 16, P, steps, 7.5, use_graph=use_graph, two_streams=two)
         loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
         loop.reset(noise)
         outs.append(loop.run().clone().cpu())
         assert loop.state[0].item() == steps
     assert torch.equal(outs[0], outs[1])                       # graph replay == eager launches, bit for bit
-    assert rel_l2(outs[1], exp) < TOL_LOOP
+    assert torch.equal(outs[0], outs[2])                       # two overlapping graph branches (uncond || cond) change nothing
+    assert rel_l2(outs[2], exp) < TOL_LOOP
     # replay again from the same noise: deterministic
     loop.reset(noise)
-    assert torch.equal(loop.run().cpu(), outs[1])
+    assert torch.equal(loop.run().cpu(), outs[2])
 
 
 def test_full_sd15_unet_forward_matches_oracle():
