@@ -13,6 +13,10 @@
 #include "pv_common.h"
 #include <type_traits>
 
+#ifndef PV_ATTN_ABLATE
+#define PV_ATTN_ABLATE 0   // 1 no exp, 2 no QK MFMA, 3 no PV MFMA: timing-only builds (wrong results)
+#endif
+
 namespace {
 
 template <int D>
@@ -20,7 +24,14 @@ struct ACfg {
     static constexpr int DK = (D + 31) / 32 * 32;  // contraction length of Q.K^T padded to the MFMA K
     static constexpr int KSTEPS = DK / 32;
     static constexpr int DVF = (D + 15) / 16;      // 16-wide output fragments of P.V
-    static constexpr int KS = DK + 8;              // LDS row strides in halfs (+16 B pad)
+    // K rows in LDS: DK == 64 -> 128-B rows with the 16-B chunk XOR-swizzled by (row & 7) (conflict-free ds_read_b128, as
+    // in the GEMM); otherwise rows padded by 16 B (2-way conflicts, only the small d = 80 / 160 levels)
+    static constexpr bool KSWZ = DK == 64;
+    static constexpr int KS = KSWZ ? DK : DK + 8;  // LDS row stride in halfs
+    static constexpr int KCH = KS / 8;             // 16-B chunks per K row (incl. zero padding)
+    __device__ static __forceinline__ int koff(int row, int chunk) {
+        return KSWZ ? row * KS + ((chunk ^ (row & 7)) << 3) : row * KS + (chunk << 3);
+    }
     static constexpr int VS = DVF * 16 + 8;
     static constexpr int CH = D / 8;               // 16-byte chunks per row
 };
@@ -79,10 +90,10 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
     for (int st = 0; st < (DBUF ? 2 : 1); ++st) {
         half_t* sK = sbase + st * STAGE;
         half_t* sV = sK + KB * C::KS;
-        constexpr int NPC = (C::KS - D) / 8, NPV = (C::VS - D) / 8;
+        constexpr int NPC = C::KCH - C::CH, NPV = (C::VS - D) / 8;
         for (int i = tid; i < KB * NPC; i += 256) {
             const int r = i / NPC, c = i - r * NPC;
-            *reinterpret_cast<half8_t*>(sK + r * C::KS + D + c * 8) = zero8();
+            *reinterpret_cast<half8_t*>(sK + C::koff(r, C::CH + c)) = zero8();
         }
         for (int i = tid; i < KB * NPV; i += 256) {
             const int r = i / NPV, c = i - r * NPV;
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
             const int idx = tid + i * 256;
             const int key = idx / C::CH, c = idx - key * C::CH;
             if (idx < NCHUNK) {
-                *reinterpret_cast<half8_t*>(sK + key * C::KS + c * 8) = kreg[i];
+                *reinterpret_cast<half8_t*>(sK + C::koff(key, c)) = kreg[i];
                 *reinterpret_cast<half8_t*>(sV + key * C::VS + c * 8) = vreg[i];
             }
         }
@@ -156,9 +167,13 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
         for (int ks = 0; ks < C::KSTEPS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::KS + (ks * 4 + fq) * 8);
+                const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, ks * 4 + fq));
 #pragma unroll
+#if PV_ATTN_ABLATE == 2
+                asm volatile("" ::"v"(a));
+#else
                 for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+#endif
             }
         half8_t pb[2][2];
 #pragma unroll
@@ -198,7 +213,11 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#if PV_ATTN_ABLATE == 1
+                    const float e = fmaf(s[kb][qi][r], sc, -m_use);
+#else
                     const float e = PV_EXP2(fmaf(s[kb][qi][r], sc, -m_use));
+#endif
                     if (!ONES) rs += e;
                     s[kb][qi][r] = e;
                 }
@@ -216,8 +235,12 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 #pragma unroll
             for (int f = 0; f < C::DVF; ++f) {
                 const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
+#if PV_ATTN_ABLATE == 3
+                asm volatile("" ::"v"(a), "v"(pb[s2][0]), "v"(pb[s2][1]));
+#else
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
+#endif
             }
     };
 
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
 
     // stage K and V (zero-filled pads)
     {
-        constexpr int KC = C::KS / 8, VC = C::VS / 8;
+        constexpr int KC = C::KCH, VC = C::VS / 8;
         for (int i = tid; i < XKEYS * KC; i += 256) {
             const int r = i / KC, c = i - r * KC;
             half8_t v = zero8();
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
                 else if (r >= IP0 && r < IP0 + p.nip)
                     v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.kip) + ((size_t)b * p.nip + (r - IP0)) * p.ldkip + h * D + c * 8);
             }
-            *reinterpret_cast<half8_t*>(sK + r * C::KS + c * 8) = v;
+            *reinterpret_cast<half8_t*>(sK + C::koff(r, c)) = v;
         }
         for (int i = tid; i < XKEYS * VC; i += 256) {
             const int r = i / VC, c = i - r * VC;
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
     for (int ks = 0; ks < C::KSTEPS; ++ks)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::KS + (ks * 4 + fq) * 8);
+            const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
         }

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-for fl in "" "-DPV_ATTN_NO_SKIP" "-DPV_ATTN_NO_ONES" "-DPV_ATTN_DBUF"; do
+for fl in "" "-DPV_ATTN_ABLATE=1" "-DPV_ATTN_ABLATE=2" "-DPV_ATTN_ABLATE=3"; do
 python - "$fl" <<'PY' > /dev/null
 import sys, photoverse_amd.build as b
 b.FLAGS = b.FLAGS + sys.argv[1].split()
