@@ -142,11 +142,22 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         ach = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        # HBM traffic of this kernel from the rocprofv3 PMC passes of the same command (tools/profile_bench.py; counters are
+        # collected in their own runs, so the number is read from the committed summary, not measured in this process)
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r01_pmc_traffic.json: " + pmc.get("note", "")
+        except (OSError, ValueError):
+            pass
+        algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl
+        roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel<5, 2, true, false>", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "measured": "HIP events around a back-to-back replay of this kernel's launches of one step on one stream "
                                 "(in the timed loop the uncond/cond forwards are two overlapping graph branches, so rocprof "
                                 "per-dispatch durations of the default run include co-scheduling; `--one-stream` is the matching run)",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": nl,
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": algo_bytes, "launches_per_step": nl,
                     "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
                     "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
 

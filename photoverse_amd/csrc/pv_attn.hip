@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: the q-tiles of one (batch, head) get consecutive remapped ids, i.e. run on ONE XCD, so its K/V
+    // (655 KB at N = 4096) are fetched into one L2 instead of all eight (FETCH_SIZE was 8x the K/V bytes)
+    const int nqt = (p.nq + 127) / 128;
+    const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
     const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
     const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
     const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
@@ -307,7 +311,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int nqt = (p.nq + 127) / 128;
+    const int rid = (int)blockIdx.x;     // K/V are 96 rows: no L2 affinity to gain from an XCD remap (measured slower)
+    const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
     const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
 
     // stage K and V (zero-filled pads)
@@ -463,7 +469,7 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
 #else
     constexpr int smem = 64 * (C::KS + C::VS) * 2;
 #endif
-    hipLaunchKernelGGL(attn_kernel<D>, dim3((p.nq + 127) / 128, p.heads, p.batch), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(attn_kernel<D>, dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem, s, p);
     return PV_CHECK_LAUNCH();
 }
 
@@ -477,7 +483,7 @@ int launch_xattn(const pv_xattn_params& p, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(xattn_kernel<D>, dim3((p.nq + 127) / 128, p.heads, p.batch), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(xattn_kernel<D>, dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem, s, p);
     return PV_CHECK_LAUNCH();
 }
 

@@ -19,7 +19,8 @@
 #define PV_ABLATE 0   // 1/2/3: timing-only builds (wrong results), see tools/ablate.sh
 #endif
 #ifndef PV_BIG_TILES
-#define PV_BIG_TILES 1 // 0: never dispatch the 256-row big-tile kernel (A/B experiments)
+#define PV_BIG_TILES 0 // 1: dispatch the 256-row big-tile kernel for the 64x64-level 3x3 convs (measured +3 % there; off so that
+                       //    every 3x3 conv is ONE kernel in the profiles and the roofline accounting)
 #endif
 #ifndef PV_FORCE_WM
 #define PV_FORCE_WM 0 // 2 or 4: force the tile variant (experiments)
