@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--ip-tokens", type=int, default=1, help="image tokens per sample (reference inference default: 1)")
     ap.add_argument("--guidance", type=float, default=7.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch-splits", type=int, default=1, help="independent sub-batches per forward (extra parallel graph branches)")
     ap.add_argument("--one-stream", action="store_true",
                     help="run the uncond / cond forwards back to back on one stream instead of as two parallel graph branches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,7 +88,7 @@ def main():
     unet.to(dev)
 
     B, S, P, T = args.batch, args.latent, args.ip_tokens, max(args.steps, 1)
-    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream)
+    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream, batch_splits=args.batch_splits)
     g = torch.Generator().manual_seed(1234)    # global batch drawn once on CPU (infer.py:52-59), sliced per rank
     GB = B * world
     noise = torch.randn(GB, 4, S, S, generator=g)
@@ -125,7 +126,7 @@ def main():
         # dominant kernel = the implicit-GEMM 3x3 conv instantiation; replay exactly its launches of one step and
         # time them with HIP events on the launch stream
         dom = "gemm_conv_kernel<5,true,false>"
-        subs = [e.rec.subset(lambda t: t[0] == dom) for e in (loop.eng_u, loop.eng_c)]
+        subs = [e.rec.subset(lambda t: t[0] == dom) for e in loop.engines_u + loop.engines_c]
         nl = sum(len(s) for s in subs)
         flops = sum(t[1] for s in subs for t in s.tags)
         stream = torch.cuda.current_stream()
@@ -176,7 +177,7 @@ def main():
             "data": "synthetic (random-init SD-v1.5-shaped weights, N(0,1) latents / text / image-token embeddings)",
             "config": {"workload": "configs[1]: SD-v1.5 UNet + PhotoVerse processors, 50-step loop, bs=16/GPU, 512x512 (64x64 latents), fp16",
                        "per_gpu_batch": B, "global_batch": GB, "latent": S, "ip_tokens": P, "guidance_scale": args.guidance,
-                       "parallelism": f"dp{world} (batch-sharded, 1 all_gather)", "hip_graph": not args.no_graph, "graph_branches": 1 if args.one_stream else 2,
+                       "parallelism": f"dp{world} (batch-sharded, 1 all_gather)", "hip_graph": not args.no_graph, "graph_branches": 1 if args.one_stream else 2 * args.batch_splits,
                        "launches_per_step": loop.launches_per_step},
             "finite": finite,
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),

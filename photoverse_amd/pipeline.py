@@ -21,7 +21,7 @@ from .scheduler import DPMSolverMultistepScheduler
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
-                 two_streams: bool = True):
+                 two_streams: bool = True, batch_splits: int = 1):
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
@@ -42,17 +42,31 @@ class DenoiseLoop:
         self.text_u = torch.zeros_like(self.text_c)
         self.ip_c = torch.zeros((batch * n_ip, xdim), dtype=f16, device=dev)
         self.ip_u = torch.zeros_like(self.ip_c)
-        kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents, n_text=n_text)
-        self.eng_u = unet.engine(batch, latent_size, latent_size, n_ip, 1, text=self.text_u, ip=self.ip_u, **kw)
-        self.eng_c = unet.engine(batch, latent_size, latent_size, n_ip, 1, text=self.text_c, ip=self.ip_c, **kw)
+        # Engines: one per (CFG branch, sub-batch).  batch_splits > 1 cuts each forward into independent sub-batches (samples
+        # never interact inside the UNet) that run as additional parallel graph branches.
+        if batch % batch_splits:
+            raise ValueError("batch_splits must divide the batch")
+        sb = batch // batch_splits
+        self.eps_u = torch.empty_like(self.latents)
+        self.eps_c = torch.empty_like(self.latents)
+        self.engines_u, self.engines_c = [], []
+        for i in range(batch_splits):
+            sl = slice(i * sb, (i + 1) * sb)
+            kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text)
+            self.engines_u.append(unet.engine(sb, latent_size, latent_size, n_ip, 1, text=self.text_u[i * sb * n_text:(i + 1) * sb * n_text],
+                                              ip=self.ip_u[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_u[sl], **kw))
+            self.engines_c.append(unet.engine(sb, latent_size, latent_size, n_ip, 1, text=self.text_c[i * sb * n_text:(i + 1) * sb * n_text],
+                                              ip=self.ip_c[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_c[sl], **kw))
+        self.eng_u, self.eng_c = self.engines_u[0], self.engines_c[0]
         self.tail = Recorder(dev)
-        self.tail.cfg_dpm_step(self.eng_u.out, self.eng_c.out, self.latents, self.x0_prev, self.coef, self.state, self.guidance)
+        self.tail.cfg_dpm_step(self.eps_u, self.eps_c, self.latents, self.x0_prev, self.coef, self.state, self.guidance)
         self.tail.step_advance(self.state)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
         self.two_streams = two_streams
-        self._side = torch.cuda.Stream(device=dev) if two_streams else None
-        self.launches_per_step = len(self.eng_u.rec) + len(self.eng_c.rec) + len(self.tail)
+        n_side = (2 * batch_splits - 1) if two_streams else 0
+        self._sides = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
+        self.launches_per_step = sum(len(e.rec) for e in self.engines_u + self.engines_c) + len(self.tail)
 
     # ------------------------------------------------------------------
     def set_conditioning(self, cond: Tuple[torch.Tensor, torch.Tensor], uncond: Tuple[torch.Tensor, torch.Tensor]):
@@ -62,8 +76,8 @@ class DenoiseLoop:
             dt.copy_(text.reshape(dt.shape))
             di.copy_(ip.reshape(di.shape))
         # K/V projections of the conditioning: once per generation, outside the per-step graph
-        self.eng_u.run_conditioning()
-        self.eng_c.run_conditioning()
+        for e in self.engines_u + self.engines_c:
+            e.run_conditioning()
 
     def reset(self, noise: torch.Tensor):
         """latents = noise * init_noise_sigma (``infer.py:70``); step counter to 0."""
@@ -77,14 +91,17 @@ class DenoiseLoop:
             # streams (two parallel branches of the captured graph) so the small low-resolution launches of one overlap
             # the other's; joined before the combine
             main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self.eng_c.rec.run()
-            self.eng_u.rec.run()
-            main.wait_stream(self._side)
+            engines = self.engines_u + self.engines_c
+            for side, eng in zip(self._sides, engines[1:]):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    eng.rec.run()
+            engines[0].rec.run()
+            for side in self._sides:
+                main.wait_stream(side)
         else:
-            self.eng_u.rec.run()
-            self.eng_c.rec.run()
+            for e in self.engines_u + self.engines_c:
+                e.rec.run()
         self.tail.run()
 
     def capture(self):

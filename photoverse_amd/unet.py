@@ -187,7 +187,7 @@ class UNetEngine:
     def __init__(self, unet: "UNet2DConditionModel", batch: int, h: int, w: int, n_ip: int, t_rows: int, device,
                  timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
                  latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
-                 ip: Optional[torch.Tensor] = None):
+                 ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         self.unet, self.B, self.H, self.W, self.P, self.NT = unet, batch, h, w, n_ip, n_text
         cfg = unet.config
         rec = self.rec = Recorder(device)
@@ -202,6 +202,7 @@ class UNetEngine:
         self.timesteps = timesteps if timesteps is not None else rec.empty((t_rows,), torch.float32)
         self.state = state
         self.t_rows = t_rows
+        self.out_buf = out
         self.vnorms: Dict[str, torch.Tensor] = {}
         self.xattn_params: Dict[str, object] = {}   # per-layer launch records: (w_text, w_ip) are patched per call in grad mode
         self._build()
@@ -320,7 +321,7 @@ class UNetEngine:
         xn = rec.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w,
                            eps=u.conv_norm_out.eps, act=ACT_SILU)
         wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
-        self.out = rec.conv_out(xn, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels)
+        self.out = rec.conv_out(xn, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels, out=self.out_buf)
 
     def run_conditioning(self):
         self.rec_cond.run()
