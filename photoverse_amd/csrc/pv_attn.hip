@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
         }
     }
 
+    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
     half8_t qf[2][C::KSTEPS];
     int qrow[2];
 #pragma unroll
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
             const int c = ks * 4 + fq;
             qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+            // fold softmax_scale * log2(e) into Q once (one extra fp16 rounding of q): the scores leave the MFMA in log2
+            // units and, with the accumulators initialised to -m_run, already relative to the running row maximum
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qi][ks][j] = (half_t)((float)qf[qi][ks][j] * qscale);
         }
     }
 
@@ -155,18 +160,19 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
     for (int f = 0; f < C::DVF; ++f)
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};     // m_run is meaningful from the first tile on (FIRST path)
 
-    // one 64-key tile: S^T = K.Q^T, online softmax, O^T += V^T.P^T
-    auto tile = [&](int t, int st, const bool MASKED) {
+    // one 64-key tile: S'^T = K.Q'^T - m_run (log2 units, relative to the running maximum), online softmax, O^T += V^T.P^T
+    auto tile = [&](int t, int st, const bool MASKED, const bool FIRST) {
         const half_t* sK = sbase + st * STAGE;
         const half_t* sV = sK + KB * C::KS;
         float4_t s[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int qi = 0; qi < 2; ++qi) {
+            const float init = FIRST ? 0.f : -m_run[qi];      // the row constant rides in the MFMA accumulator
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) s[kb][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < 4; ++kb) s[kb][qi] = float4_t{init, init, init, init};
+        }
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks)
 #pragma unroll
@@ -197,30 +203,31 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qi][r]);
             mx = pv_quad_max(mx);
-            const float m_new = fmaxf(m_run[qi], mx * sc);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            // rescale the running output only when this row's maximum moved (wave-uniform skip: after the first few
-            // tiles most rows keep their maximum)
-#ifdef PV_ATTN_NO_SKIP
-            {
-#else
-            if (__any(m_new > m_run[qi])) {
-#endif
-                const float alpha = PV_EXP2(m_run[qi] - m_use);
+            // mx = (tile row max) - m_run.  Fast path (wave-uniform, the common case after the first tiles): no row of the
+            // wave exceeded its running maximum -> P = exp2(S') with no per-score subtraction at all.
+            // Slow path: shift the reference by d = max(mx, 0), rescale the running output by exp2(-d).
+            float d = 0.f;
+            if (FIRST || __any(mx > 0.f)) {
+                d = FIRST ? (mx == -INFINITY ? 0.f : mx) : fmaxf(mx, 0.f);
+                const float alpha = FIRST ? 0.f : PV_EXP2(-d);
+                m_run[qi] += d;
                 if (!ONES) l_run[qi] *= alpha;
 #pragma unroll
                 for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kb][qi][r] -= d;
             }
-            m_run[qi] = m_new;
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #if PV_ATTN_ABLATE == 1
-                    const float e = fmaf(s[kb][qi][r], sc, -m_use);
+                    const float e = s[kb][qi][r];
 #else
-                    const float e = PV_EXP2(fmaf(s[kb][qi][r], sc, -m_use));
+                    const float e = PV_EXP2(s[kb][qi][r]);
 #endif
                     if (!ONES) rs += e;
                     s[kb][qi][r] = e;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
         }
         if (t + 1 < ntiles) gload(t + 1);
         const bool need_mask = p.causal || (t + 1) * KB > p.nk;
-        tile(t, st, need_mask);
+        tile(t, st, need_mask, t == 0);
         if (DBUF) {
             if (t + 1 < ntiles) swrite(st ^ 1);   // the other stage was last read in iteration t-1 (barrier below)
             __syncthreads();
