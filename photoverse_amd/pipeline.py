@@ -153,3 +153,43 @@ def gather_latents(local: torch.Tensor, world: int, force: bool = False) -> torc
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out
+
+
+class PhotoVersePipeline:
+    """Convenience bundle named in the task text (the reference itself has no such class): holds what
+    ``load_models`` returns and calls ``run_inference`` - optionally sharding the batch over the ranks of an initialised
+    ``torch.distributed`` process group and gathering the final latents with one collective."""
+
+    def __init__(self, tokenizer, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, lora_config=None):
+        self.tokenizer, self.text_encoder, self.vae, self.unet = tokenizer, text_encoder, vae, unet
+        self.image_encoder, self.image_adapter, self.text_adapter = image_encoder, image_adapter, text_adapter
+        self.scheduler, self.lora_config = scheduler, lora_config
+        self.device = torch.device("cpu")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, extra_num_tokens=4, photoverse_path=None, **kw):
+        from .modeling_utils import load_models
+        return cls(*load_models(pretrained_model_name_or_path, extra_num_tokens, photoverse_path, **kw))
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for m in (self.unet, self.text_encoder, self.image_encoder, self.image_adapter, self.text_adapter):
+            m.to(self.device)
+        return self
+
+    @torch.no_grad()
+    def __call__(self, example, image_encoder_layers_idx=(4, 8, 12, 16), shard: bool = False, **kw):
+        from .infer import run_inference
+        if shard:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            n = example["pixel_values_clip"].shape[0]
+            sl = shard_batch(n, rank, world)
+            local = {k: (v[sl] if torch.is_tensor(v) and v.shape[:1] == (n,) else v) for k, v in example.items()}
+            if kw.get("seed") is not None:      # the global noise is drawn once with the reference's generator semantics and sliced
+                raise NotImplementedError("sharded calls take per-rank noise; draw the global noise with DenoiseLoop for exact 1-GPU parity")
+            out = run_inference(local, self.tokenizer, self.image_encoder, self.text_encoder, self.unet, self.text_adapter,
+                                self.image_adapter, self.vae, self.scheduler, self.device, list(image_encoder_layers_idx), **kw)
+            return gather_latents(out, world, force=True)
+        return run_inference(example, self.tokenizer, self.image_encoder, self.text_encoder, self.unet, self.text_adapter,
+                             self.image_adapter, self.vae, self.scheduler, self.device, list(image_encoder_layers_idx), **kw)
