@@ -317,14 +317,23 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
             if (m >= p.M) continue;
+            unsigned pk[NF / 2][2];
 #pragma unroll
             for (int q = 0; q < NF / 2; ++q) {
-                const int j = (n0 >> 1) + wn * (NF * 8) + q * 16 + fq * 4;      // logical output column
                 const float4_t v = acc[2 * q][mi] + bv[q], g = acc[2 * q + 1][mi] + bg[q];
-                half4_t o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * pv_gelu_erf(g[r]));
-                *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + j) = o;
+                pk[q][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[0] * pv_gelu_erf(g[0])), (half_t)(v[1] * pv_gelu_erf(g[1]))});
+                pk[q][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[2] * pv_gelu_erf(g[2])), (half_t)(v[3] * pv_gelu_erf(g[3]))});
+            }
+            // logical output column of pair q: (n0 >> 1) + wn*(NF*8) + q*16 + fq*4; 16-byte stores via the lane swap (see below)
+            half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + (n0 >> 1) + wn * (NF * 8);
+            static_assert(!GEGLU || NF == 4, "GEGLU epilogue pairs the two value|gate fragment pairs of a wave");
+            {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                const unsigned a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+                const int col = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+                typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<uint4_t*>(orow + col) = uint4_t{a0, a1, b0, b1};
             }
         }
     } else {
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
             const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
             if (m >= p.M) continue;
             const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
+            unsigned pk[NF][2];   // fp16-packed results of this row's NF fragments
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
                 float4_t v = acc[ni][mi] + bias_v[ni];
@@ -359,14 +369,31 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)res[ni][mi][r];
                 }
-                const int n = nbase + ni * 16;
                 if (p.out_f32) {
-                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + nbase + ni * 16) = v;
                 } else {
-                    half4_t o;
+                    pk[ni][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[0], (half_t)v[1]});
+                    pk[ni][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[2], (half_t)v[3]});
+                }
+            }
+            if (!p.out_f32) {
+                // Widen the stores to 16 B: a lane holds 4 columns (8 B) of fragment ni; v_permlane16_swap trades the even
+                // lane-rows' fragment ni+1 against the odd lane-rows' fragment ni, after which every lane owns 8 CONSECUTIVE
+                // columns -> half the store instructions at the same bytes (the m >= M rows skip as whole swap pairs: the
+                // partner lane l^16 has the same row).
+                half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n0 + wn * (NF * 16);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                    *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+                for (int q = 0; q < NF / 2; ++q) {
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * q][0], pk[2 * q + 1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * q][1], pk[2 * q + 1][1], false, false);
+                    const unsigned a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+                    const int col = (fq & 1) ? (2 * q + 1) * 16 + (fq - 1) * 4 : (2 * q) * 16 + fq * 4;
+                    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<uint4_t*>(orow + col) = uint4_t{a0, a1, b0, b1};
+                }
+                if (NF & 1) {
+                    typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<uint2_t*>(orow + (NF - 1) * 16 + fq * 4) = uint2_t{pk[NF - 1][0], pk[NF - 1][1]};
                 }
             }
         }
@@ -382,10 +409,8 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
 // Fragments are double-buffered in registers ACROSS K-steps: the ds_reads of step kt+1 are issued before the MFMAs of kt.
 // LDS rows are 64 B; bank-conflict swizzle: 16-B chunk ^= SWZ[(row >> 2) & 3], SWZ = {0,3,2,1} (conflict-free for the
 // 16-lane groups of ds_read_b128), applied on the per-lane DMA source offset and on the read.
-constexpr int BIG_BM = 256;
 constexpr int BIG_BK = 32;
 constexpr int BIG_ROWB = BIG_BK * 2;   // 64 B per LDS row
-constexpr int BIG_S = 3;
 
 __device__ __forceinline__ int big_swz(int g) { return (4 - g) & 3; }   // {0,3,2,1}
 
@@ -393,10 +418,11 @@ __device__ __forceinline__ half8_t big_frag(const char* base, int row, int q) {
     return *reinterpret_cast<const half8_t*>(base + row * BIG_ROWB + ((q ^ big_swz((row >> 2) & 3)) << 4));
 }
 
-template <int NF, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
+// MI = M fragments per wave (8: 256-row tile, 2 workgroups / CU;  4: 128-row tile, 3 workgroups / CU), BIG_S = LDS stages
+template <int NF, int MI, int BIG_S, bool CONV>
+__global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
     constexpr int BN = NF * 32;
-    constexpr int MI = 8;
+    constexpr int BIG_BM = 2 * MI * 16;
     constexpr int STAGE_BYTES = (BIG_BM + BN) * BIG_ROWB;
     constexpr int A_BYTES = BIG_BM * BIG_ROWB;
     constexpr int AP = BIG_BM / 16 / 4;                 // 16-row DMA pieces of the activation tile per wave (4)
@@ -518,21 +544,21 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_d
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) wb[ni] = big_frag(sb, wn * (NF * 16) + ni * 16 + fr, fq);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) xa[mi] = big_frag(sa, wm * 128 + mi * 16 + fr, fq);
+        for (int mi = 0; mi < MI / 2; ++mi) xa[mi] = big_frag(sa, wm * (MI * 16) + mi * 16 + fr, fq);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 4; mi < 8; ++mi) xa[mi] = big_frag(sa, wm * 128 + mi * 16 + fr, fq);
+        for (int mi = MI / 2; mi < MI; ++mi) xa[mi] = big_frag(sa, wm * (MI * 16) + mi * 16 + fr, fq);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI / 2; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-            for (int mi = 4; mi < 8; ++mi)
+            for (int mi = MI / 2; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -544,12 +570,12 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_d
     for (int ni = 0; ni < NF; ++ni)
         bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {            // two halves of the 8 M-fragments: bounds the registers of the batched residual
+    for (int mh = 0; mh < MI / 4; ++mh) {       // groups of 4 M-fragments: bounds the registers of the batched residual
         half4_t res[NF][4];
         if (p.residual) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m = min(m0 + wm * 128 + (mh * 4 + mi) * 16 + fr, p.M - 1);
+                const int m = min(m0 + wm * (MI * 16) + (mh * 4 + mi) * 16 + fr, p.M - 1);
 #pragma unroll
                 for (int ni = 0; ni < NF; ++ni)
                     res[ni][mi] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + nbase + ni * 16);
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_d
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 128 + (mh * 4 + mi) * 16 + fr;
+            const int m = m0 + wm * (MI * 16) + (mh * 4 + mi) * 16 + fr;
             if (m >= p.M) continue;
             const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
 #pragma unroll
@@ -586,12 +612,13 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const pv_gemm_params_d
     }
 }
 
-template <int NF, bool CONV>
+template <int NF, int MI, int BIG_S, bool CONV>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     constexpr int BN = NF * 32;
+    constexpr int BIG_BM = 2 * MI * 16;
     constexpr int SMEM = BIG_S * (BIG_BM + BN) * BIG_ROWB;
     static bool attr_set = false;
-    auto kern = gemm_big_kernel<NF, CONV>;
+    auto kern = gemm_big_kernel<NF, MI, BIG_S, CONV>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
@@ -670,10 +697,13 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
 #if PV_FORCE_WM != 2
     if constexpr (!GEGLU) {
         // big tile when it still gives every CU two workgroups; convs: stride 1 / no upsample only
-        const long tiles256 = (long)((p.M + BIG_BM - 1) / BIG_BM) * (p.N / (NF * 32));
+        const long tiles256 = (long)((p.M + 255) / 256) * (p.N / (NF * 32));
         const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);
         // measured (profiles/r01_kbench_c.txt): ~3 % faster on the 64x64-level 3x3 convs, not on the short-K Linear layers
-        if (PV_BIG_TILES && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, CONV>(p, stream);
+        if (PV_BIG_TILES == 1 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 3, CONV>(p, stream);
+        // experiment: 128-row tile with 32-deep stages -> three workgroups per CU
+        if (PV_BIG_TILES == 2 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 2, CONV>(p, stream);
+        if (PV_BIG_TILES == 3 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 3, CONV>(p, stream);
     }
 #endif
     return launch<NF, 2, CONV, GEGLU>(p, stream);
