@@ -74,3 +74,26 @@ class DPMSolverMultistepRef:
             self.lower_order_nums += 1
         self.step_index += 1
         return prev
+
+
+class DDIMRef:
+    """Stepwise DDIM (eta = 0, epsilon prediction, "leading" spacing, steps_offset 1, set_alpha_to_one False) - the sampler
+    BASELINE.json's metric text names; [EXT diffusers DDIMScheduler], PARITY UNPINNED."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double()
+        self.T, self.steps_offset = num_train_timesteps, steps_offset
+
+    def set_timesteps(self, n):
+        self.ratio = self.T // n
+        self.timesteps = torch.from_numpy((np.arange(0, n) * self.ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset)
+
+    def step(self, eps, t, x):
+        t = int(t)
+        a_t = self.alphas_cumprod[t]
+        prev = t - self.ratio
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.alphas_cumprod[0]
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        return a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps

@@ -75,3 +75,40 @@ class DPMSolverMultistepScheduler:
                 r0 = (lam[i] - lam[i - 1]) / h
                 tab[i, 3], tab[i, 4] = -c * (1.0 + 0.5 / r0), 0.5 * c / r0
         return torch.from_numpy(tab.astype(np.float32))
+
+
+class DDIMScheduler(DPMSolverMultistepScheduler):
+    """Deterministic DDIM (eta = 0) on the same beta schedule / timestep grid, expressed in the SAME coefficient-table form
+    (``c1 = 0``), so the loop kernel and the captured graph are unchanged.  The reference's sampler is DPM-Solver++
+    (``infer.py:39-40``); BASELINE.json's metric text says "DDIM", so both are selectable (``DenoiseLoop(scheduler=...)``).
+
+        x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t)
+        x' = sqrt(a_p) x0 + sqrt(1-a_p) eps,   eps = (x - sqrt(a_t) x0) / sqrt(1-a_t)
+           = [sqrt(1-a_p)/sqrt(1-a_t)] x + [sqrt(a_p) - sqrt(a_t) sqrt(1-a_p)/sqrt(1-a_t)] x0
+    with a_t = alphas_cumprod[t], a_p = alphas_cumprod[t - T/n] (1.0 past the last step, diffusers ``set_alpha_to_one``
+    is False for SD-v1.5 -> alphas_cumprod[0]).
+    """
+
+    def coefficient_table(self) -> torch.Tensor:
+        n = self.num_inference_steps
+        T = self.config["num_train_timesteps"]
+        ratio = T // n
+        ts = self.timesteps.numpy()
+        acp = self.alphas_cumprod.astype(np.float64)
+        tab = np.zeros((n, 8), dtype=np.float64)
+        for i, t in enumerate(ts):
+            a_t = acp[t]
+            prev = t - ratio
+            a_p = acp[prev] if prev >= 0 else acp[0]
+            r = np.sqrt(1 - a_p) / np.sqrt(1 - a_t)
+            tab[i, 0], tab[i, 1] = 1.0 / np.sqrt(a_t), -np.sqrt(1 - a_t) / np.sqrt(a_t)
+            tab[i, 2], tab[i, 3], tab[i, 4] = r, np.sqrt(a_p) - np.sqrt(a_t) * r, 0.0
+        return torch.from_numpy(tab.astype(np.float32))
+
+    def set_timesteps(self, n: int):
+        # diffusers DDIMScheduler "leading" spacing: arange(n) * (T // n) reversed, + steps_offset
+        T = self.config["num_train_timesteps"]
+        ts = (np.arange(0, n) * (T // n)).round()[::-1].copy().astype(np.int64) + self.config["steps_offset"]
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = n
+        self.sigmas = None

@@ -267,3 +267,24 @@ def test_batch_shard_and_single_gather_gloo_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True, (8, 4, 16, 16)), (1, True, (8, 4, 16, 16))]
+
+
+def test_ddim_table_reproduces_stepwise_ddim():
+    from oracle.scheduler_ref import DDIMRef
+    from photoverse_amd.scheduler import DDIMScheduler
+    for n in (10, 50):
+        s = DDIMScheduler()
+        s.set_timesteps(n)
+        tab = s.coefficient_table().double()
+        r = DDIMRef()
+        r.set_timesteps(n)
+        assert torch.equal(s.timesteps, r.timesteps) and tab[:, 4].abs().max() == 0
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(64, generator=g, dtype=torch.float64)
+        xr = x.clone()
+        for i, t in enumerate(r.timesteps):
+            eps = torch.randn(64, generator=g, dtype=torch.float64)
+            xr = r.step(eps, t, xr)
+            ca, cb, cx, c0, _ = tab[i, :5]
+            x = cx * x + c0 * (ca * x + cb * eps)
+            assert ((x - xr).norm() / xr.norm()).item() < 1e-6
