@@ -3,8 +3,7 @@
 
 Same flags and the same call into ``run_inference`` as the reference (``generate.py:21-34,82-85``); additions forced by
 the offline environment: ``--model_path random`` (seeded random-init weights), ``--synthetic_input`` (no image / tokenizer
-files needed), ``--seed``, ``--latent_size`` and ``--output_latents`` (the VAE is outside this build's scope, so the result is
-the final latents tensor saved as ``.pt``; pass your own VAE through the Python API to get images).
+files needed), ``--seed``, ``--latent_size``.  Images are written as PNG like the reference (``generate.py:86-90``).
 """
 import argparse
 import os
@@ -69,7 +68,7 @@ if __name__ == "__main__":
     device = torch.device("cuda")
     tokenizer, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
         None if args.model_path == "random" else args.model_path, args.extra_num_tokens, args.checkpoint_path)
-    for m in (unet, text_encoder, image_encoder, image_adapter, text_adapter):
+    for m in (vae, unet, text_encoder, image_encoder, image_adapter, text_adapter):
         m.to(device)
     example = prepare_example(args, tokenizer)
     with torch.no_grad():
@@ -77,6 +76,8 @@ if __name__ == "__main__":
                             args.encoder_layers_idx, latent_size=args.latent_size, guidance_scale=args.guidance_scale,
                             timesteps=args.num_timesteps, from_noised_image=args.from_noised_image, seed=args.seed)
     os.makedirs(args.results_dir, exist_ok=True)
-    path = os.path.join(args.results_dir, f"{args.output_image_path}_latents.pt")
-    torch.save(out.cpu(), path)
-    print(f"saved final latents {tuple(out.shape)} to {path} (VAE decode is outside this build's scope)")
+    from PIL import Image
+    imgs = ((out.float().cpu() + 1.0) / 2.0).clamp(0, 1).mul(255).round().to(torch.uint8)     # utils/image_utils.py:6-29 denormalize + to_pil
+    for idx, img in enumerate(imgs):
+        Image.fromarray(img.permute(1, 2, 0).numpy()).save(os.path.join(args.results_dir, f"{args.output_image_path}{idx}.png"))
+    print(f"saved {len(imgs)} image(s) {tuple(out.shape[1:])} to {args.results_dir}/")

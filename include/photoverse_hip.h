@@ -158,7 +158,7 @@ int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t 
 /* conv_in: NCHW fp32 latents (B,cin,H,W) -> NHWC fp16 (B,H,W,cout), 3x3 pad 1; w fp32 [cout][cin][3][3] */
 int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin,
                int32_t h, int32_t wd, int32_t cout, void* stream);
-/* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin] */
+/* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin]; cout 4 (UNet) or 3 (VAE) */
 int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin,
                 int32_t h, int32_t wd, int32_t cout, void* stream);
 /* CFG combine (infer.py:116) + DPM-Solver++(2M) update (infer.py:119) on fp32 NCHW latents.
@@ -180,6 +180,19 @@ int pv_rows_mean(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t group
 /* ------------------------------------------------------------------------------------------
  * Pre-loop conditioning front ends (infer.py:76-96).
  */
+/* ------------------------------------------------------------------------------------------
+ * VAE decode helpers (infer.py:121-123; [EXT] diffusers AutoencoderKL.decode).  The decoder's convolutions, GroupNorms
+ * and Linear layers run on pv_gemm_conv / pv_groupnorm_*; its single-head attention over H*W tokens (head dim 512) is
+ * GEMM -> pv_softmax_rows -> GEMM.
+ */
+/* in place: x[r][c] = softmax_c(scale * x[r][c]) over fp16 rows (fp32 math), cols % 8 == 0 */
+int pv_softmax_rows(void* x, int32_t ld, int32_t rows, int32_t cols, float scale, void* stream);
+/* 1x1 conv over NCHW fp32 with few channels (post_quant_conv 4->4): w [cout][cin], bias [cout] or NULL */
+int pv_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t cout,
+                      int32_t hw, void* stream);
+/* in place clamp of fp32 values (images.clamp(-1, 1), infer.py:122) */
+int pv_clamp_f32(float* x, float lo, float hi, int64_t n, void* stream);
+
 /* im2col of a 3x3 / pad-1 conv over NCHW fp32 with few channels (UNet conv_in): fp16 rows [B*H*W][kpad], column
  * k = ci*9 + ky*3 + kx, zero padded (kpad % 64 == 0), so conv_in runs on pv_gemm_conv with w.reshape(cout, cin*9). */
 int pv_im2col3x3(const float* x, void* out, int32_t batch, int32_t cin, int32_t h, int32_t wd, int32_t kpad, void* stream);

@@ -65,6 +65,9 @@ SIGNATURES = {
     "pv_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pv_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pv_rows_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pv_pointwise_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_clamp_f32": (c_int, [c_void_p, c_float, c_float, c_int64, c_void_p]),
     "pv_im2col3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_clip_vision_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

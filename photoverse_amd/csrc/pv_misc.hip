@@ -209,6 +209,60 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, half_t* __restrict
     *reinterpret_cast<half8_t*>(out + pix * kpad + ch * 8) = o;
 }
 
+// in-place row softmax of fp16 scores: x[r][c] = softmax_c(scale * x[r][c]); one 256-thread workgroup per row, fp32 math
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, int ld, int cols, float scale) {
+    __shared__ float red[4];
+    half_t* row = x + (size_t)blockIdx.x * ld;
+    const int nch = cols >> 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float sl2 = scale * 1.4426950408889634f;
+    float mx = -INFINITY;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(row + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j]);
+    }
+    mx = pv_wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * sl2;
+    __syncthreads();
+    float sum = 0.f;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(row + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __builtin_amdgcn_exp2f(fmaf((float)v[j], sl2, -mx));
+    }
+    sum = pv_wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(row + ch * 8);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__builtin_amdgcn_exp2f(fmaf((float)v[j], sl2, -mx)) * inv);
+        *reinterpret_cast<half8_t*>(row + ch * 8) = o;
+    }
+}
+
+// 1x1 convolution over an NCHW fp32 tensor with few channels (VAE post_quant_conv, 4 -> 4)
+__global__ void pointwise_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                      float* __restrict__ out, int batch, int cin, int cout, int hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * hw) return;
+    const int b = (int)(idx / hw), px = (int)(idx - (long)b * hw);
+    for (int co = 0; co < cout; ++co) {
+        float acc = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < cin; ++ci) acc += w[co * cin + ci] * x[((long)b * cin + ci) * hw + px];
+        out[((long)b * cout + co) * hw + px] = acc;
+    }
+}
+
+__global__ void clamp_f32_kernel(float* x, float lo, float hi, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
 // CLIP ViT patchify: NCHW fp32 pixels -> fp16 rows [B*gh*gw][kpad], row = one patch flattened (c, py, px), zero padded
 __global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int batch, int ch, int img, int patch, int kpad) {
     const int g = img / patch;
@@ -271,6 +325,27 @@ extern "C" int pv_im2col3x3(const float* x, void* out, int32_t batch, int32_t ci
     return PV_CHECK_LAUNCH();
 }
 
+extern "C" int pv_softmax_rows(void* x, int32_t ld, int32_t rows, int32_t cols, float scale, void* stream) {
+    if (rows <= 0 || cols <= 0 || (cols % 8) || (ld % 8) || !x) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<half_t*>(x), ld, cols, scale);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t cout,
+                                 int32_t hw, void* stream) {
+    if (batch <= 0 || cin <= 0 || cout <= 0 || hw <= 0 || !x || !w || !out) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * hw;
+    hipLaunchKernelGGL(pointwise_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out,
+                       batch, cin, cout, hw);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_clamp_f32(float* x, float lo, float hi, int64_t n, void* stream) {
+    if (n <= 0 || !x) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(clamp_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, lo, hi, (long)n);
+    return PV_CHECK_LAUNCH();
+}
+
 extern "C" int pv_patchify(const float* x, void* out, int32_t batch, int32_t ch, int32_t img, int32_t patch, int32_t kpad, void* stream) {
     if (batch <= 0 || ch <= 0 || img <= 0 || patch <= 0 || (img % patch) || kpad < ch * patch * patch || !x || !out)
         return (int)hipErrorInvalidValue;
@@ -321,10 +396,14 @@ extern "C" int pv_conv_in(const float* x, const float* w, const float* bias, voi
 
 extern "C" int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t h,
                            int32_t wd, int32_t cout, void* stream) {
-    if (batch <= 0 || (cin % 8) || cout != 4 || !x || !w || !out) return (int)hipErrorInvalidValue;
+    if (batch <= 0 || (cin % 8) || (cout != 4 && cout != 3) || !x || !w || !out) return (int)hipErrorInvalidValue;
     const long pix = (long)batch * h * wd;
-    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
+    if (cout == 4)
+        hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
     return PV_CHECK_LAUNCH();
 }
 

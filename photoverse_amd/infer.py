@@ -1,9 +1,10 @@
 """``run_inference`` with the reference's signature (``/root/reference/models/infer.py:7-123``).
 
 Conditioning runs once per call on HIP kernels (CLIP ViT x2, adapters x3, text encoder x2, ``infer.py:76-96``); the
-denoising loop (``:98-119``) is the graph-captured ``DenoiseLoop``.  VAE encode / decode (``:62-68,121-123``) is outside
-this build's scope: with ``vae=None`` the function returns the final LATENTS (the value of ``latents`` after
-``:119``); a caller-supplied ``vae`` object with ``.decode`` / ``.config.scaling_factor`` is used as in ``:121-123``.
+denoising loop (``:98-119``) is the graph-captured ``DenoiseLoop``; the VAE decode + clamp of ``:121-123`` runs on
+``photoverse_amd.vae.AutoencoderKL`` (or any object with ``.decode`` / ``.config.scaling_factor``).  With ``vae=None`` the
+function returns the final LATENTS (the value of ``latents`` after ``:119``).  VAE *encode* (``:62-68``, img2img start) is not
+built: ``from_noised_image`` needs a VAE that has ``encode``.
 """
 from __future__ import annotations
 
@@ -47,8 +48,8 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
         noise = torch.randn(shape, generator=generator).to(device)
 
     if from_noised_image:                                                                 # :62-65
-        if vae is None:
-            raise NotImplementedError("from_noised_image needs vae.encode; the VAE is outside this build's scope (SURVEY 8f-1)")
+        if vae is None or not hasattr(vae, "encode"):
+            raise NotImplementedError("from_noised_image needs vae.encode; only the VAE decoder is built (SURVEY 8f-1)")
         latents0 = vae.encode(example["pixel_values"].to(device)).latent_dist.sample().detach() * vae.config.scaling_factor
         sch.set_timesteps(timesteps)
         acp = torch.from_numpy(sch.alphas_cumprod).to(device)[sch.timesteps[:1].to(device)]
@@ -80,4 +81,11 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
     if vae is None:
         return latents
     _latents = 1 / vae.config.scaling_factor * latents.clone()                            # :121-123
-    return vae.decode(_latents).sample.clamp(-1, 1)
+    images = vae.decode(_latents).sample
+    if images.is_cuda and images.dtype == torch.float32 and images.is_contiguous():
+        from .ops import Recorder
+        rec = Recorder(images.device)
+        rec.clamp_(images, -1.0, 1.0)
+        rec.run()
+        return images
+    return images.clamp(-1, 1)

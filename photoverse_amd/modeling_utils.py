@@ -5,9 +5,10 @@
 
 Differences forced by the environment (no network, no diffusers / peft): weights come either from a LOCAL directory in
 the HF layout (``unet/diffusion_pytorch_model.safetensors``, ``text_encoder/model.safetensors``,
-``image_encoder/model.safetensors`` - names are diffusers/transformers-compatible) or from seeded random init
-(``pretrained_model_name_or_path=None`` or ``"random"``); the VAE is out of scope for this build so the
-``vae`` slot is ``None`` and ``run_inference`` returns latents.
+``image_encoder/model.safetensors``, ``vae/diffusion_pytorch_model.safetensors`` - names are diffusers/transformers-compatible)
+or from seeded random init (``pretrained_model_name_or_path=None`` or ``"random"``); the ``vae`` slot holds the DECODER half
+only (``photoverse_amd.vae.AutoencoderKL``: ``decode`` exists, ``encode`` does not, so ``from_noised_image`` needs a
+caller-supplied VAE).
 """
 from __future__ import annotations
 
@@ -22,6 +23,7 @@ from .lora import LoraConfig, inject_adapter_in_model
 from .scheduler import DPMSolverMultistepScheduler
 from .tokenizer import SyntheticCLIPTokenizer
 from .unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+from .vae import AutoencoderKL
 
 
 def load_photoverse_model(path, image_adapter, text_adapter, unet):
@@ -75,7 +77,7 @@ def _load_safetensors_into(module, path, prefix_fix=None):
 
 
 def load_models(pretrained_model_name_or_path, extra_num_tokens, photoverse_path=None, use_lora=False, lora_config=None, *,
-                seed=0, unet_config=None, vision_config=None, text_config=None):
+                seed=0, unet_config=None, vision_config=None, text_config=None, vae_config=None):
     local = pretrained_model_name_or_path not in (None, "random") and os.path.isdir(str(pretrained_model_name_or_path))
     if pretrained_model_name_or_path not in (None, "random") and not local:
         raise FileNotFoundError(
@@ -84,18 +86,18 @@ def load_models(pretrained_model_name_or_path, extra_num_tokens, photoverse_path
     torch.manual_seed(seed)
     tokenizer = SyntheticCLIPTokenizer()
     text_encoder = CLIPTextModel(**(text_config or {}))
-    vae = None
+    vae = AutoencoderKL(**(vae_config or {}))
     unet = UNet2DConditionModel(**(unet_config or {}))
     image_encoder = CLIPVisionModel(**(vision_config or {}))
     scheduler = SimpleNamespace(config=DPMSolverMultistepScheduler().config)     # plays the DDPMScheduler of :60 (only .config is read)
     if local:
         root = str(pretrained_model_name_or_path)
         for mod, rel in ((unet, "unet/diffusion_pytorch_model.safetensors"), (text_encoder, "text_encoder/model.safetensors"),
-                         (image_encoder, "image_encoder/model.safetensors")):
+                         (image_encoder, "image_encoder/model.safetensors"), (vae, "vae/diffusion_pytorch_model.safetensors")):
             f = os.path.join(root, rel)
             if os.path.exists(f):
                 _load_safetensors_into(mod, f)
-    for m in (unet, text_encoder, image_encoder):                                # :63-66 (no VAE here)
+    for m in (unet, vae, text_encoder, image_encoder):                           # :63-66
         m.requires_grad_(False)
     image_adapter = PhotoVerseAdapter(cross_attention_dim=unet.config.cross_attention_dim,
                                       clip_embedding_dim=image_encoder.config.hidden_size, num_tokens=extra_num_tokens + 1)

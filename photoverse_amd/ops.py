@@ -215,6 +215,23 @@ class Recorder:
         self._add(self.lib.pv_conv_in, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, h, wd, cout)
         return out
 
+    def softmax_rows(self, x, *, scale):
+        ld, cols = _rows(x)
+        self.keep.append(x)
+        self._add(self.lib.pv_softmax_rows, _ptr(x), ld, x.shape[0], cols, float(scale))
+        return x
+
+    def pointwise_nchw(self, x, w, bias, *, batch, cin, cout, hw):
+        out = self.empty((batch, cout, hw), torch.float32)
+        self.keep.extend((x, w, bias))
+        self._add(self.lib.pv_pointwise_nchw, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, cout, hw)
+        return out
+
+    def clamp_(self, x, lo, hi):
+        self.keep.append(x)
+        self._add(self.lib.pv_clamp_f32, _ptr(x), float(lo), float(hi), x.numel())
+        return x
+
     def im2col3x3(self, x, *, batch, cin, h, wd, kpad):
         out = self.empty((batch * h * wd, kpad), torch.float16)
         self.keep.append(x)

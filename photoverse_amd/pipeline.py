@@ -173,8 +173,9 @@ class PhotoVersePipeline:
 
     def to(self, device):
         self.device = torch.device(device)
-        for m in (self.unet, self.text_encoder, self.image_encoder, self.image_adapter, self.text_adapter):
-            m.to(self.device)
+        for m in (self.unet, self.vae, self.text_encoder, self.image_encoder, self.image_adapter, self.text_adapter):
+            if m is not None:
+                m.to(self.device)
         return self
 
     @torch.no_grad()

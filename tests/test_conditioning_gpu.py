@@ -92,7 +92,8 @@ def test_run_inference_end_to_end_matches_oracle(need_gpu):
     from photoverse_amd.modeling_utils import load_models
     tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
         None, 1, unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT, seed=3)
-    assert vae is None
+    from photoverse_amd.vae import AutoencoderKL
+    assert isinstance(vae, AutoencoderKL)
     # oracle twins with identical weights
     r_unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
     set_visual_cross_attention_adapter_ref(r_unet, (2,))

@@ -14,6 +14,7 @@ TINY = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640), layers
             down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
             attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5)
 VIS = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=1, image_size=56, patch_size=14)
+VAE = dict(block_out_channels=(128, 256), layers_per_block=1)
 TXT = dict(vocab_size=1000, hidden_size=768, num_attention_heads=12, intermediate_size=256, num_hidden_layers=1)
 
 
@@ -164,7 +165,7 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
     """save_progress / load_photoverse_model keep the reference layout (modeling_utils.py:13-50)."""
     from photoverse_amd.lora import LoraConfig
     from photoverse_amd.modeling_utils import load_models, load_photoverse_model, save_progress
-    tok, te, vae, unet, ie, ia, ta, sch, _ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=1)
+    tok, te, vae, unet, ie, ia, ta, sch, _ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=1)
     save_progress(ia, ta, unet, None, str(tmp_path), step=42)
     f = tmp_path / "photoverse_000042.pt"
     assert f.exists()
@@ -177,7 +178,7 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
     assert set(ck["image_adapter"]) == {f"mapping{p}_{i}.{j}.{w}" for p in ("", "_patch") for i in range(2) for j, ws in
                                         ((0, "wb"), (1, "wb"), (3, "wb"), (4, "wb"), (6, "wb")) for w in ("weight", "bias")}
     # load into a differently seeded model: adapters + cross-attention subset become equal, the rest stays
-    tok2, te2, vae2, unet2, ie2, ia2, ta2, sch2, lc = load_models(None, 1, str(f), unet_config=TINY, vision_config=VIS, text_config=TXT, seed=2)
+    tok2, te2, vae2, unet2, ie2, ia2, ta2, sch2, lc = load_models(None, 1, str(f), unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=2)
     assert lc is None
     for k in keys:
         assert torch.equal(unet2.state_dict()[k], unet.state_dict()[k])
@@ -185,7 +186,7 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(ia2.state_dict().values(), ia.state_dict().values()))
     # LoRA: peft-style names, config stored, re-injected on load BEFORE the weights
     cfg = LoraConfig(r=4, lora_alpha=8)
-    tok3, te3, vae3, unet3, *_rest = load_models(None, 1, use_lora=True, lora_config=cfg, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=1)
+    tok3, te3, vae3, unet3, *_rest = load_models(None, 1, use_lora=True, lora_config=cfg, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=1)
     k3 = list(unet3.state_dict())
     base = "mid_block.attentions.0.transformer_blocks.0.attn2.to_q."
     assert base + "base_layer.weight" in k3 and base + "lora_A.default.weight" in k3 and base + "lora_B.default.weight" in k3
@@ -198,11 +199,11 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
     ck3 = torch.load(str(tmp_path / "photoverse.pt"))
     assert {"optimizer", "lora_config"} <= set(ck3) and ck3["lora_config"]["r"] == 4
     assert any(k.endswith("to_q.lora_B.default.weight") for k in ck3["cross_attention_adapter"])
-    *_x, unet4, _ie, _ia, _ta, _s, lc4 = load_models(None, 1, str(tmp_path / "photoverse.pt"), unet_config=TINY, vision_config=VIS, text_config=TXT, seed=5)
+    *_x, unet4, _ie, _ia, _ta, _s, lc4 = load_models(None, 1, str(tmp_path / "photoverse.pt"), unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=5)
     assert lc4 is not None and lc4.r == 4
     assert torch.equal(unet4.state_dict()[base + "lora_B.default.weight"], unet3.state_dict()[base + "lora_B.default.weight"])
     with pytest.raises(AssertionError):
-        load_models(None, 1, use_lora=True, unet_config=TINY, vision_config=VIS, text_config=TXT)     # modeling_utils.py:87
+        load_models(None, 1, use_lora=True, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE)     # modeling_utils.py:87
     with pytest.raises(FileNotFoundError):
         load_models("runwayml/stable-diffusion-v1-5", 1)                                              # no network here
 
@@ -210,16 +211,21 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
 def test_load_models_from_local_hf_layout(tmp_path):
     from safetensors.torch import save_file
     from photoverse_amd.modeling_utils import load_models
-    tok, te, vae, unet, ie, *_ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=7)
-    (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "image_encoder").mkdir()
+    tok, te, vae, unet, ie, *_ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=7)
+    (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "image_encoder").mkdir(); (tmp_path / "vae").mkdir()
+    vsd = {k: v.contiguous() for k, v in vae.state_dict().items()}
+    vsd["encoder.conv_in.weight"] = torch.zeros(2)            # HF vae checkpoints also hold the encoder: ignored
+    save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
     plain = {k: v.contiguous() for k, v in unet.state_dict().items() if "processor" not in k}
     save_file(plain, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
     save_file({k: v.contiguous() for k, v in te.state_dict().items()}, str(tmp_path / "text_encoder" / "model.safetensors"))
     save_file({k: v.contiguous() for k, v in ie.state_dict().items()}, str(tmp_path / "image_encoder" / "model.safetensors"))
-    tok2, te2, vae2, unet2, ie2, *_ = load_models(str(tmp_path), 1, unet_config=TINY, vision_config=VIS, text_config=TXT, seed=8)
+    tok2, te2, vae2, unet2, ie2, *_ = load_models(str(tmp_path), 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=8)
     assert all(torch.equal(unet2.state_dict()[k], v) for k, v in plain.items())
     assert all(torch.equal(a, b) for a, b in zip(te2.state_dict().values(), te.state_dict().values()))
     assert all(torch.equal(a, b) for a, b in zip(ie2.state_dict().values(), ie.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(vae2.state_dict().values(), vae.state_dict().values()))
+    assert not any(p.requires_grad for p in vae2.parameters())
     assert not any(p.requires_grad for p in unet2.conv_in.parameters())                # frozen (modeling_utils.py:63-66)
     assert all(p.requires_grad for n, p in unet2.named_parameters() if "processor" in n)   # created after the freeze
 
