@@ -484,7 +484,10 @@ template <int D>
 int launch_xattn(const pv_xattn_params& p, hipStream_t s) {
     using C = ACfg<D>;
     constexpr int smem = XKEYS * (C::KS + C::VS) * 2;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
     if (smem > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;

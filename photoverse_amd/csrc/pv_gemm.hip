@@ -2,17 +2,24 @@
 //
 //   out[M][N] = epilogue( A[M][K] * W[N][K]^T )           fp16 in, fp32 accumulate
 //
-// Tile: 128 (M) x BN (N) x 64 (K), BN = 160 (NF=5) or 128 (NF=4); 256 threads = 4 waves in a 2x2
-// grid, each wave owns 64 x (BN/2) outputs as 4 x NF fragments of v_mfma_f32_16x16x32_f16.
-// Operands are passed swapped (W as MFMA-A, activations as MFMA-B), so a lane's 4 accumulator
-// registers are 4 CONSECUTIVE output columns of one row -> 8-byte fp16 stores, 32-byte runs.
+// Dispatched kernel (gemm_conv_kernel<NF, 2, CONV, GEGLU>): tile 128 (M) x BN (N) x 64 (K), BN = 160 (NF=5) or 128
+// (NF=4); 256 threads = 4 waves in a 2x2 grid, each wave owns 64 x (BN/2) outputs as 4 x NF fragments of
+// v_mfma_f32_16x16x32_f16; two workgroups per CU.  Operands are passed swapped (W as MFMA-A, activations as MFMA-B), so a
+// lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one row; fragment pairs are traded between lane rows
+// (v_permlane16_swap) so the epilogue stores 16 bytes per lane.
 //
-// Both operands reach LDS by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves
-// 8 rows x 128 B.  The LDS image is lane-linear, so the bank-conflict swizzle (16-B chunk ^= row&7)
-// is applied to the per-lane SOURCE address and again on the ds_read_b128 side.  For the 3x3 conv
-// the per-lane source address IS the im2col gather: each 64-channel K-chunk lies inside one filter
-// tap, out-of-image taps (zero padding) and the M tail read a zero page.  Two LDS stages, one
-// barrier per K-step, 2 workgroups per CU.
+// Both operands reach LDS by LDS-DMA through raw buffer descriptors (buffer_load_dwordx4 ... lds): one wave-instruction
+// moves 8 rows x 128 B.  The LDS image is lane-linear, so the bank-conflict swizzle (16-B chunk ^= row&7) is applied to the
+// per-lane SOURCE offset and again on the ds_read_b128 side.  For the 3x3 conv the per-lane source offset IS the im2col
+// gather: each 64-channel K-chunk lies inside one filter tap; out-of-image taps (zero padding) and the M tail use an
+// out-of-range offset that the hardware range check turns into zeros.  K order is channel-chunk major / tap minor (the 9
+// shifted re-reads of a slab hit L1/L2).  Two LDS stages; one raw s_barrier per K-step placed BETWEEN the two 32-deep
+// halves of the step, so the fragment reads of one half overlap the MFMAs of the other and the next stage's DMA is issued
+// behind a counted vmcnt.  Small-M layers split K over several workgroups (fp32 slabs reduced in fixed order).
+//
+// Also in this file, measured and NOT dispatched by default: the 256-row instantiation <NF, 4, ...>
+// (one wave per SIMD, AGPR accumulators, 3 stages) and gemm_big_kernel (32-deep stages; 256-row / 2 workgroups per CU or
+// 128-row / 3 per CU).
 #include "pv_common.h"
 
 #ifndef PV_ABLATE
@@ -617,7 +624,10 @@ int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     constexpr int BN = NF * 32;
     constexpr int BIG_BM = 2 * MI * 16;
     constexpr int SMEM = BIG_S * (BIG_BM + BN) * BIG_ROWB;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
     auto kern = gemm_big_kernel<NF, MI, BIG_S, CONV>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -665,7 +675,10 @@ __global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int split
 template <int NF, int WM, bool CONV, bool GEGLU>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = TileCfg<NF, WM>;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
     auto kern = gemm_conv_kernel<NF, WM, CONV, GEGLU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
