@@ -82,7 +82,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int NF, int WM, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
-                                                                              const int nblk, const int m_fast) {
+                                                                              const int nblk, const int order) {
     using Cfg = TileCfg<NF, WM>;
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NWAVES;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
 
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
-    const int bid = pv_xcd_remap((int)blockIdx.x, nblk);
+    const int bid = (order & 2) ? (int)blockIdx.x : pv_xcd_remap((int)blockIdx.x, nblk);
+    const int m_fast = order & 1;
     const int tiles_m = nblk / tiles_n;
     const int tile_m = m_fast ? bid % tiles_m : bid / tiles_n;
     const int tile_n = m_fast ? bid / tiles_m : bid % tiles_n;
@@ -691,7 +692,8 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     const int nblk = tiles_m * tiles_n;
     // XCD footprint heuristic: walk M fastest when the weight panel is too big to sit in every XCD's L2
     const size_t wbytes = (size_t)p.N * p.taps * (p.c0 + p.c1) * 2;
-    const int m_fast = (wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0;
+    static const int order_env = getenv("PV_TILE_ORDER") ? atoi(getenv("PV_TILE_ORDER")) : -1;   // experiments: bit0 M-fastest, bit1 no XCD remap
+    const int m_fast = order_env >= 0 ? order_env : ((wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0);
     const int splits = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
     if (splits > 1) {

@@ -17,9 +17,13 @@ PASSES = [
     "FETCH_SIZE GRBM_GUI_ACTIVE",
     "WRITE_SIZE TCP_TCC_READ_REQ_sum",
 ]
+if os.environ.get("PMC_PASSES"):   # e.g. PMC_PASSES=3,4,5 for the cache / traffic counters only
+    PASSES = [PASSES[int(i)] for i in os.environ["PMC_PASSES"].split(",")]
 flt = sys.argv[1]
 ksub = sys.argv[2] if len(sys.argv) > 2 else ""
+import shutil
 out = os.path.join(ROOT, "gpurun_out", "pmc")
+shutil.rmtree(out, ignore_errors=True)   # stale passes of an earlier call would be averaged in
 agg = defaultdict(lambda: defaultdict(list))
 for i, cs in enumerate(PASSES):
     d = os.path.join(out, f"p{i}")
