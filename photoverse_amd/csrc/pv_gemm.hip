@@ -23,8 +23,12 @@
 #include "pv_common.h"
 
 #ifndef PV_ABLATE
-#define PV_ABLATE 0   // 1/2/3: timing-only builds (wrong results), see tools/ablate.sh
+#define PV_ABLATE 0   // timing-only builds (wrong results), see tools/ablate.sh / tools/ablate2.sh
 #endif
+// 1 no MFMA | 2 no DMA | 3 DMA only | 4 A staged for 2 of 9 taps | 5 W staged every other step | 6 MFMA only | 7 LDS reads only
+#define PV_AB_NO_MFMA (PV_ABLATE == 1 || PV_ABLATE == 3 || PV_ABLATE == 7)
+#define PV_AB_NO_DMA (PV_ABLATE == 2 || PV_ABLATE == 6 || PV_ABLATE == 7)
+#define PV_AB_NO_READ (PV_ABLATE == 3 || PV_ABLATE == 6)
 #ifndef PV_BIG_TILES
 #define PV_BIG_TILES 0 // 1: dispatch the 256-row big-tile kernel for the 64x64-level 3x3 convs (measured +3 % there; off so that
                        //    every 3x3 conv is ONE kernel in the profiles and the roofline accounting)
@@ -80,6 +84,10 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef PV_CLOCKPROBE   // diagnostic build: shader clock of the main loop = s_memtime ticks / s_memrealtime (100 MHz) ticks
+__device__ unsigned long long pv_clock_probe[4];
+#endif
+
 template <int NF, int WM, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int order) {
@@ -90,6 +98,10 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
     constexpr int AP = Cfg::A_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef PV_CLOCKPROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
     const int bid = (order & 2) ? (int)blockIdx.x : pv_xcd_remap((int)blockIdx.x, nblk);
@@ -178,6 +190,9 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
         const int sc2 = (first ? c : c - p.c0) * 2;   // scalar byte offset of the slab inside the source row
         const int ky = tap / 3, kx = tap - ky * 3;
         const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;   // fast path: centre pixel -> tap pixel
+#if PV_ABLATE == 4   // timing experiment: A staged for 2 of the 9 taps only (what a halo-reuse patch would move)
+        if (!CONV || tap == 0 || tap == 4)
+#endif
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             unsigned off;
@@ -194,6 +209,9 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * NW) * 8 * ROW_BYTES), 16, (int)off, 0, 0, 0);
         }
         const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+#if PV_ABLATE == 5   // timing experiment: W staged for every other K-step only
+        if (kt & 1)
+#endif
 #pragma unroll
         for (int i = 0; i < Cfg::B_PER_WAVE; ++i) {
             if (i < Cfg::B_PER_WAVE - 1 || b_full)
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
         for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
     };
     auto mma_half = [&](const half8_t (&xa)[MI], const half8_t (&wb)[NF]) {
-#if PV_ABLATE == 1   // timing experiment: LDS reads without the MFMAs
+#if PV_AB_NO_MFMA   // timing experiment: LDS reads without the MFMAs
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xa[mi]));
 #pragma unroll
@@ -260,13 +278,20 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
     asm volatile("" ::: "memory");
 
     half8_t xa0[MI], wb0[NF], xa1[MI], wb1[NF];
-#if PV_ABLATE != 3
+#if PV_AB_NO_READ   // timing experiments without LDS reads: opaque, finite register contents
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { xa0[i] = half8_t{(half_t)lane}; xa1[i] = xa0[i]; asm volatile("" : "+v"(xa0[i]), "+v"(xa1[i])); }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { wb0[i] = half8_t{(half_t)wave}; wb1[i] = wb0[i]; asm volatile("" : "+v"(wb0[i]), "+v"(wb1[i])); }
+#else
     if (nk > 0) read_half(xa0, wb0, 0, 0);
 #endif
     for (int kt = 0; kt < nk; ++kt) {
-#if PV_ABLATE != 3
+#if !PV_AB_NO_READ
         read_half(xa1, wb1, kt, 1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
+#if PV_ABLATE != 3
         mma_half(xa0, wb0);
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -278,13 +303,15 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
                 wait_vmcnt<0>();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer kt % S are retired
+#ifndef PV_NOBAR   // timing experiment only
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
-#if PV_ABLATE != 2
+#if !PV_AB_NO_DMA
             if (kt + S < nk) stage(kt + S, kt % S);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-#if PV_ABLATE != 3
+#if !PV_AB_NO_READ
             read_half(xa0, wb0, kt + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -295,6 +322,15 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
 #endif
     }
 
+#ifdef PV_CLOCKPROBE
+    {
+        const unsigned long long probe_t1 = __builtin_amdgcn_s_memtime(), probe_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {   // a workgroup from the middle of the launch
+            pv_clock_probe[0] = probe_t1 - probe_t0; pv_clock_probe[1] = probe_r1 - probe_r0;
+        }
+    }
+#endif
     // ---- epilogue ---------------------------------------------------------------------------
     if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
         float* slab = p.splitk_ws + (size_t)blockIdx.y * p.M * p.N;
@@ -725,6 +761,12 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef PV_CLOCKPROBE
+extern "C" int pv_debug_clock_probe(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pv_clock_probe), 2 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     pv_gemm_params_dev p;

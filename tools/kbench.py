@@ -26,7 +26,15 @@ def timeit(rec, reps=10):
         rec.run()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3  # us
+    us = e0.elapsed_time(e1) / reps * 1e3
+    if os.environ.get("PV_CLOCKPROBE"):   # diagnostic build (-DPV_CLOCKPROBE): shader clock inside the GEMM main loop
+        import ctypes
+        from photoverse_amd import _lib
+        out = (ctypes.c_ulonglong * 2)()
+        fn = getattr(_lib.load(), "pv_debug_clock_probe", None)
+        if fn is not None and fn(out) == 0 and out[1]:
+            print(f"      main loop of a mid-launch workgroup: {out[1] * 10e-3:.1f} us at {out[0] / out[1] * 0.1:.2f} GHz")
+    return us
 
 
 cases = []
