@@ -160,7 +160,10 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": algo_bytes, "launches_per_step": nl,
                     "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
-                    "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
+                    "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3),
+                    "real_data_ceiling": {"value": 1700.0, "unit": "TFLOP/s", "frac": round(ach / 1700.0, 4),
+                                          "source": "profiles/r01_mfma_power_probe.txt: this kernel's MFMA + ds_read mix on random fp16 "
+                                                    "operands, no global traffic, holds 1.70 GHz (2.40 GHz / 2.45 PFLOP/s only with zeros)"}}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
