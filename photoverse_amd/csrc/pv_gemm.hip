@@ -464,7 +464,7 @@ __device__ __forceinline__ half8_t big_frag(const char* base, int row, int q) {
 
 // MI = M fragments per wave (8: 256-row tile, 2 workgroups / CU;  4: 128-row tile, 3 workgroups / CU), BIG_S = LDS stages
 template <int NF, int MI, int BIG_S, bool CONV>
-__global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 8 ? 2 : 3, MI == 8 ? 2 : 3))) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
     constexpr int BN = NF * 32;
     constexpr int BIG_BM = 2 * MI * 16;
     constexpr int STAGE_BYTES = (BIG_BM + BN) * BIG_ROWB;
@@ -752,6 +752,7 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
         const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);
         // measured (profiles/r01_kbench_c.txt): ~3 % faster on the 64x64-level 3x3 convs, not on the short-K Linear layers
         if (PV_BIG_TILES == 1 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 3, CONV>(p, stream);
+        if (PV_BIG_TILES == 4 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);
         // experiment: 128-row tile with 32-deep stages -> three workgroups per CU
         if (PV_BIG_TILES == 2 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 2, CONV>(p, stream);
         if (PV_BIG_TILES == 3 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 3, CONV>(p, stream);
