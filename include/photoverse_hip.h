@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 1
+#define PV_ABI_VERSION 2
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -42,7 +42,7 @@ int pv_device_count(void);
  *               attention_processor.py:297,304-305,392-393,423 (to_q/to_k/to_v/to_k_ip/
  *               to_v_ip/to_out), adapters.py:14-28, and the [EXT] diffusers proj_in/proj_out/
  *               GEGLU/FF/time-embedding/conv_shortcut layers reached from infer.py:103-114.
- *   taps == 9 : implicit-GEMM 3x3 conv, padding 1, stride 1|2, optional nearest x2 upsample
+ *   taps == 9 : implicit-GEMM 3x3 conv, zero padding, stride 1|2, optional nearest x2 upsample
  *               folded into the gather (ResnetBlock2D conv1/conv2, Downsample2D, Upsample2D).
  *   A may come from two tensors concatenated along channels (skip connections): channels
  *   [0,c0) from a0 and [c0,c0+c1) from a1; c0, c1 multiples of 64.
@@ -67,10 +67,12 @@ typedef struct pv_gemm_params {
     int32_t batch, hin, win, hout, wout; /* taps==9 geometry; taps==1: hout*wout = rows per image */
     int32_t stride;        /* 1 or 2 */
     int32_t upsample;      /* 1 => logical input is the x2 nearest upsample of (hin,win) */
+    int32_t pad;           /* taps==9: zero padding in front (top / left): 1 = Conv2d(padding=1) (every UNet / decoder conv);
+                              0 = the VAE encoder's Downsample2D, F.pad(x,(0,1,0,1)) + Conv2d(stride=2,padding=0) (stride 2
+                              only).  Reads past the bottom / right edge are zeros in both cases (hout, wout say how far). */
     int32_t act;           /* enum pv_act */
     int32_t out_f32;
     int32_t geglu;         /* 1 => W rows are tile-interleaved (value|gate); out[M][N/2] = value*gelu(gate) */
-    const void* zero_page; /* unused since ABI 1 (padding is produced by the buffer range check); may be NULL */
     int32_t splitk;        /* > 1: split the K loop over this many workgroups per tile (small-M layers); needs splitk_ws */
     float* splitk_ws;      /* fp32 workspace [splitk][M][N] for the partial slabs, reduced in fixed order */
 } pv_gemm_params;

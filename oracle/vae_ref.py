@@ -1,4 +1,4 @@
-"""Oracle: fp32 eager restatement of the SD-v1.5 ``AutoencoderKL`` DECODE path.  TEST INFRASTRUCTURE, **PARITY UNPINNED**
+"""Oracle: fp32 eager restatement of the SD-v1.5 ``AutoencoderKL`` decode and encode paths.  TEST INFRASTRUCTURE, **PARITY UNPINNED**
 ([EXT] diffusers==0.27.2, not vendored / not installable; the reference loads it with
 ``AutoencoderKL.from_pretrained(..., subfolder="vae")``, ``/root/reference/models/modeling_utils.py:56`` and calls
 ``vae.decode(latents / vae.config.scaling_factor).sample.clamp(-1, 1)`` at ``/root/reference/models/infer.py:121-123``).
@@ -7,7 +7,13 @@ Restated from the public SD-v1.5 VAE definition with diffusers state-dict names:
 decoder ``conv_in`` 4->512; mid block = ResnetBlock, single-head self-attention over the H*W tokens (GroupNorm(32,1e-6),
 to_q/k/v/out with bias, residual), ResnetBlock; four up blocks of 3 ResnetBlocks (512,512,256,128 channels; 1x1
 ``conv_shortcut`` when channels change) with nearest-x2 + 3x3 conv upsamplers on the first three; GroupNorm + SiLU +
-``conv_out`` 128->3.  All GroupNorms: 32 groups, eps 1e-6.  Only ``decode`` is restated.
+``conv_out`` 128->3.  All GroupNorms: 32 groups, eps 1e-6.
+
+``encode`` (``vae.encode(pixel_values).latent_dist.sample()``, ``/root/reference/models/infer.py:63`` for
+``from_noised_image`` and ``/root/reference/train.py:471``): encoder ``conv_in`` 3->128; four down blocks of 2 ResnetBlocks
+(128,256,512,512) with a Downsample2D on the first three = ``F.pad(x,(0,1,0,1))`` + Conv2d(3x3, stride 2, padding 0);
+the same mid block; GroupNorm + SiLU + ``conv_out`` 512->8; ``quant_conv`` 1x1 8->8; the 8 channels are (mean, logvar)
+of a diagonal Gaussian, logvar clamped to [-30, 20], ``sample() = mean + exp(0.5 logvar) * eps``.
 """
 from types import SimpleNamespace
 
@@ -100,6 +106,61 @@ class _Decoder(nn.Module):
         return self.conv_out(F.silu(self.conv_norm_out(x)))
 
 
+class _Downsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, layers, groups, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(cin if i == 0 else cout, cout, groups) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([_Downsample(cout)]) if add_down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.downsamplers is None else self.downsamplers[0](x)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, in_channels, latent_channels, boc, layers_per_block, groups):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out = boc[0]
+        for i in range(len(boc)):
+            prev, out = out, boc[i]
+            self.down_blocks.append(_Down(prev, out, layers_per_block, groups, i != len(boc) - 1))
+        self.mid_block = _Mid(boc[-1], groups)
+        self.conv_norm_out = nn.GroupNorm(groups, boc[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(boc[-1], 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for d in self.down_blocks:
+            x = d(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class DiagonalGaussianRef:
+    def __init__(self, moments):
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, eps=None, generator=None):
+        eps = torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype) if eps is None else eps
+        return self.mean + self.std * eps
+
+    def mode(self):
+        return self.mean
+
+
 SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
                        norm_num_groups=32, scaling_factor=0.18215)
 TINY_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128), layers_per_block=1, norm_num_groups=32,
@@ -115,6 +176,13 @@ class AutoencoderKLDecoderRef(nn.Module):
         self.post_quant_conv = nn.Conv2d(cfg["latent_channels"], cfg["latent_channels"], 1)
         self.decoder = _Decoder(cfg["latent_channels"], cfg["out_channels"], tuple(cfg["block_out_channels"]), cfg["layers_per_block"],
                                 cfg["norm_num_groups"])
+        if cfg.get("with_encoder", False):
+            self.encoder = _Encoder(cfg.get("in_channels", 3), cfg["latent_channels"], tuple(cfg["block_out_channels"]),
+                                    cfg["layers_per_block"], cfg["norm_num_groups"])
+            self.quant_conv = nn.Conv2d(2 * cfg["latent_channels"], 2 * cfg["latent_channels"], 1)
+
+    def encode(self, x):
+        return SimpleNamespace(latent_dist=DiagonalGaussianRef(self.quant_conv(self.encoder(x))))
 
     def decode(self, z):
         return SimpleNamespace(sample=self.decoder(self.post_quant_conv(z)))

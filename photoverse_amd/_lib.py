@@ -18,7 +18,7 @@ class GemmParams(C.Structure):
                 ("w", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p), ("rowadd_ld", c_int), ("residual", c_void_p),
                 ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
                 ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
-                ("upsample", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int), ("zero_page", c_void_p),
+                ("upsample", c_int), ("pad", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int),
                 ("splitk", c_int), ("splitk_ws", c_void_p)]
 
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

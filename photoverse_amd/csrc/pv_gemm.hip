@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
     const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int hw_out = p.hout * p.wout;
-    const bool fast_conv = CONV && p.stride == 1 && !p.upsample;
+    const bool fast_conv = CONV && p.stride == 1 && !p.upsample;   // pad == 1 (checked by the launcher)
     const int hl = p.upsample ? p.hin * 2 : p.hin;
     const int wl = p.upsample ? p.win * 2 : p.win;
     // A: AP pieces per wave; piece j = wave + i*NW covers tile rows [8j, 8j+8)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
             const int b = m / hw_out;
             const int rem = m - b * hw_out;
             const int y = rem / p.wout, x = rem - y * p.wout;
-            a_b[i] = b; a_y[i] = y * p.stride; a_x[i] = x * p.stride;
+            a_b[i] = b; a_y[i] = y * p.stride + 1 - p.pad; a_x[i] = x * p.stride + 1 - p.pad;   // tap (ky,kx) reads (a_y+ky-1, a_x+kx-1)
             unsigned mask = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -777,6 +777,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU || p.splitk < 0 || p.splitk > 16 ||
         !p.a0 || !p.w || !p.out || (p.c1 && !p.a1) || p.hout * p.wout <= 0)
         return (int)hipErrorInvalidValue;
+    if (p.taps == 9 && !(p.pad == 1 || (p.pad == 0 && p.stride == 2 && !p.upsample))) return (int)hipErrorInvalidValue;
     {
         const size_t a_rows = p.taps == 9 ? (size_t)p.batch * p.hin * p.win : (size_t)p.M;
         const size_t b0 = ((a_rows - 1) * p.lda0 + p.c0) * 2, b1 = p.c1 ? ((a_rows - 1) * p.lda1 + p.c1) * 2 : 0;

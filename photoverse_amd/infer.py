@@ -3,8 +3,9 @@
 Conditioning runs once per call on HIP kernels (CLIP ViT x2, adapters x3, text encoder x2, ``infer.py:76-96``); the
 denoising loop (``:98-119``) is the graph-captured ``DenoiseLoop``; the VAE decode + clamp of ``:121-123`` runs on
 ``photoverse_amd.vae.AutoencoderKL`` (or any object with ``.decode`` / ``.config.scaling_factor``).  With ``vae=None`` the
-function returns the final LATENTS (the value of ``latents`` after ``:119``).  VAE *encode* (``:62-68``, img2img start) is not
-built: ``from_noised_image`` needs a VAE that has ``encode``.
+function returns the final LATENTS (the value of ``latents`` after ``:119``).  ``from_noised_image`` (``:62-65``) starts from
+``add_noise(vae.encode(pixel_values).latent_dist.sample() * scaling_factor, noise, t_0)``; the posterior sample is drawn on the
+device generator (``torch.manual_seed(seed)`` seeds it like the reference's, the streams of two platforms never match bit for bit).
 """
 from __future__ import annotations
 
@@ -49,11 +50,10 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
 
     if from_noised_image:                                                                 # :62-65
         if vae is None or not hasattr(vae, "encode"):
-            raise NotImplementedError("from_noised_image needs vae.encode; only the VAE decoder is built (SURVEY 8f-1)")
+            raise NotImplementedError("from_noised_image needs a vae with .encode (photoverse_amd.vae.AutoencoderKL)")
         latents0 = vae.encode(example["pixel_values"].to(device)).latent_dist.sample().detach() * vae.config.scaling_factor
         sch.set_timesteps(timesteps)
-        acp = torch.from_numpy(sch.alphas_cumprod).to(device)[sch.timesteps[:1].to(device)]
-        noise = acp.sqrt() * latents0 + (1 - acp).sqrt() * noise      # scheduler.add_noise at the first timestep
+        noise = sch.add_noise(latents0, noise, sch.timesteps[:1].repeat(latents0.shape[0]))     # :65
 
     placeholder_idx = example["concept_placeholder_idx"].to(device)                       # :72-73
     pixel_values_clip = example["pixel_values_clip"].to(device)

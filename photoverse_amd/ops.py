@@ -69,7 +69,6 @@ class Recorder:
         self.calls: List[tuple] = []
         self.tags: List[tuple] = []        # per call: (kernel name, algorithmic flops, algorithmic bytes)
         self.keep: List[object] = []       # tensors / structs referenced by raw pointer
-        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
         self.bytes_allocated = 0
 
     # ------------------------------------------------------------------ memory
@@ -92,7 +91,7 @@ class Recorder:
     def subset(self, pred) -> "Recorder":
         """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
         r = Recorder.__new__(Recorder)
-        r.lib, r.device, r.zero_page, r.keep, r.bytes_allocated = self.lib, self.device, self.zero_page, self.keep, 0
+        r.lib, r.device, r.keep, r.bytes_allocated = self.lib, self.device, self.keep, 0
         sel = [i for i, t in enumerate(self.tags) if pred(t)]
         r.calls = [self.calls[i] for i in sel]
         r.tags = [self.tags[i] for i in sel]
@@ -120,10 +119,11 @@ class Recorder:
         assert w.shape[1] == taps * (c0 + c1) and w.is_contiguous() and w.dtype == torch.float16, (w.shape, taps, c0, c1)
         if conv is not None:
             M = conv["batch"] * conv["hout"] * conv["wout"]
-            geo = (conv["batch"], conv["hin"], conv["win"], conv["hout"], conv["wout"], conv.get("stride", 1), conv.get("upsample", 0))
+            geo = (conv["batch"], conv["hin"], conv["win"], conv["hout"], conv["wout"], conv.get("stride", 1), conv.get("upsample", 0), conv.get("pad", 1))
+            assert geo[7] == 1 or (geo[7] == 0 and geo[5] == 2 and not geo[6]), "pad=0 is the stride-2 VAE-encoder downsample only"
         else:
             M = a.shape[0]
-            geo = (1, 1, 1, rows_per_image or M, 1, 1, 0)
+            geo = (1, 1, 1, rows_per_image or M, 1, 1, 0, 1)
         n_out = N // 2 if geglu else N
         if out is None:
             out = self.empty((M, n_out), torch.float32 if out_f32 else torch.float16)
@@ -140,7 +140,7 @@ class Recorder:
         splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), None, splitk, _ptr(ws))
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         name = f"gemm_conv_kernel<{nf},{'true' if conv is not None else 'false'},{'true' if geglu else 'false'}>"

@@ -47,6 +47,12 @@ class DPMSolverMultistepScheduler:
     def scale_model_input(self, sample, t):
         return sample
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """sqrt(acp[t]) x0 + sqrt(1 - acp[t]) noise  (infer.py:65, train.py:484); ``timesteps``: int64 [B]."""
+        acp = torch.from_numpy(self.alphas_cumprod).to(original_samples.device)[timesteps.to(original_samples.device).long()]
+        acp = acp.to(original_samples.dtype).view(-1, *([1] * (original_samples.dim() - 1)))
+        return acp.sqrt() * original_samples + (1 - acp).sqrt() * noise
+
     def coefficient_table(self) -> torch.Tensor:
         """float32 [n, 8] rows {ca, cb, cx, c0, c1, 0, 0, 0} with, per step i (s = current, t = next sigma):
             x0     = ca*x + cb*eps            ca = 1/alpha_s, cb = -sigma_s/alpha_s

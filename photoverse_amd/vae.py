@@ -1,16 +1,21 @@
-"""SD-v1.5 ``AutoencoderKL`` DECODE on HIP kernels - the step right after the denoising loop
+"""SD-v1.5 ``AutoencoderKL`` on HIP kernels: DECODE - the step right after the denoising loop
 (``/root/reference/models/infer.py:121-123``: ``vae.decode(latents / vae.config.scaling_factor).sample.clamp(-1, 1)``;
-the model is loaded at ``/root/reference/models/modeling_utils.py:56``).  SURVEY.md section 8f row 1.
+the model is loaded at ``/root/reference/models/modeling_utils.py:56``), SURVEY.md section 8f row 1 - and ENCODE
+(``vae.encode(pixel_values).latent_dist.sample()``, ``infer.py:63`` for ``from_noised_image``, ``train.py:471``).
 
 Parameter names follow diffusers (``post_quant_conv``, ``decoder.conv_in``, ``decoder.mid_block.resnets.{0,1}``,
 ``decoder.mid_block.attentions.0.{group_norm,to_q,to_k,to_v,to_out.0}``, ``decoder.up_blocks.i.resnets.j``,
-``decoder.up_blocks.i.upsamplers.0.conv``, ``decoder.conv_norm_out``, ``decoder.conv_out``) so the HF ``vae`` checkpoint loads.
-Only ``decode`` exists (the encoder is needed for img2img / training: not built).  Everything runs on the UNet's kernels:
+``decoder.up_blocks.i.upsamplers.0.conv``, ``decoder.conv_norm_out``, ``decoder.conv_out``; ``quant_conv``, ``encoder.conv_in``,
+``encoder.down_blocks.i.{resnets.j,downsamplers.0.conv}``, ``encoder.mid_block``, ``encoder.conv_norm_out``, ``encoder.conv_out``)
+so the HF ``vae`` checkpoint loads.  Everything runs on the UNet's kernels:
 3x3 convs = implicit-GEMM ``pv_gemm_conv`` (nearest-x2 upsample folded into the gather), GroupNorm(+SiLU) kernels, and the
 mid block's single-head attention over the H*W tokens (head dim 512, too wide for the flash kernel's register tiles) as
 GEMM (Q.K^T per image) -> ``pv_softmax_rows`` -> GEMM (P.V with V^T produced directly by an operand-swapped GEMM; the V bias
 is added after P.V, exact because softmax rows sum to 1).  Images are decoded in sub-batches so that no operand exceeds the
-2 GiB the buffer descriptors address.
+2 GiB the buffer descriptors address.  Encoder specifics: ``conv_in`` (3 channels) is im2col + GEMM like the decoder's; the
+Downsample2D convs (``F.pad(x,(0,1,0,1))`` + stride 2 / padding 0) are ``pv_gemm_conv`` with ``pad=0``; ``quant_conv`` (1x1, linear)
+is folded into ``conv_out``'s weights in fp32 when the plan is built, and the 8 moment channels come out of one fp32-output GEMM
+whose weight rows are zero-padded to the 128-column tile.
 """
 from __future__ import annotations
 
@@ -70,6 +75,51 @@ class _Up(_Holder):
         self.upsamplers = nn.ModuleList([_Upsample(cout)]) if add_up else None
 
 
+class _Downsample(_Holder):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+
+class _Down(_Holder):
+    def __init__(self, cin, cout, layers, groups, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(cin if i == 0 else cout, cout, groups) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([_Downsample(cout)]) if add_down else None
+
+
+class _Encoder(_Holder):
+    def __init__(self, in_channels, latent_channels, boc, layers_per_block, groups):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out = boc[0]
+        for i in range(len(boc)):
+            prev, out = out, boc[i]
+            self.down_blocks.append(_Down(prev, out, layers_per_block, groups, i != len(boc) - 1))
+        self.mid_block = _Mid(boc[-1], groups)
+        self.conv_norm_out = nn.GroupNorm(groups, boc[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(boc[-1], 2 * latent_channels, 3, padding=1)
+
+
+class DiagonalGaussianDistribution:
+    """Mirror of diffusers' posterior object: ``mean``, ``logvar`` (clamped to [-30, 20]), ``std``, ``sample()``, ``mode()``."""
+
+    def __init__(self, moments: torch.Tensor):
+        self.parameters = moments
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * eps
+
+    def mode(self):
+        return self.mean
+
+
 class _Decoder(_Holder):
     def __init__(self, latent_channels, out_channels, boc, layers_per_block, groups):
         super().__init__()
@@ -98,7 +148,8 @@ def _conv3_w(w):
 
 
 class AutoencoderKL(nn.Module):
-    """Decoder half of the SD VAE.  ``decode(z) -> .sample`` (B,3,8h,8w) fp32, like diffusers' ``DecoderOutput``."""
+    """The SD VAE.  ``decode(z) -> .sample`` (B,3,8h,8w) fp32 like diffusers' ``DecoderOutput``; ``encode(x) -> .latent_dist``
+    (``with_encoder=False`` builds the decoder half only)."""
 
     MAX_OPERAND_BYTES = 1 << 30     # keep every activation operand well under the 2 GiB of a buffer descriptor
 
@@ -106,19 +157,31 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         cfg = dict(SD15_VAE_CONFIG)
         cfg.update(overrides)
+        cfg.setdefault("with_encoder", True)
+        cfg.setdefault("in_channels", 3)
         self.config = SimpleNamespace(**cfg)
         self.post_quant_conv = nn.Conv2d(cfg["latent_channels"], cfg["latent_channels"], 1)
         self.decoder = _Decoder(cfg["latent_channels"], cfg["out_channels"], tuple(cfg["block_out_channels"]), cfg["layers_per_block"],
                                 cfg["norm_num_groups"])
+        if cfg["with_encoder"]:
+            self.quant_conv = nn.Conv2d(2 * cfg["latent_channels"], 2 * cfg["latent_channels"], 1)
+            self.encoder = _Encoder(cfg["in_channels"], cfg["latent_channels"], tuple(cfg["block_out_channels"]),
+                                    cfg["layers_per_block"], cfg["norm_num_groups"])
         self._plans: Dict[tuple, object] = {}
 
     def repack(self):
         self._plans.clear()
 
     def load_state_dict(self, sd, strict=True, **k):
-        # an HF vae checkpoint also holds the encoder / quant_conv: ignore those keys
-        own = {k_: v for k_, v in sd.items() if k_.startswith(("decoder.", "post_quant_conv."))}
-        r = super().load_state_dict(own, strict=strict, **k)
+        # a decoder-only model ignores the encoder / quant_conv keys of an HF vae checkpoint; a full model accepts a
+        # decoder-only state dict (its encoder keeps its current weights) but never a partial encoder
+        enc = ("encoder.", "quant_conv.")
+        if not self.config.with_encoder:
+            sd = {k_: v for k_, v in sd.items() if not k_.startswith(enc)}
+        elif not any(k_.startswith(enc) for k_ in sd):
+            sd = dict(sd)
+            sd.update({k_: v for k_, v in self.state_dict().items() if k_.startswith(enc)})
+        r = super().load_state_dict(sd, strict=strict, **k)
         self.repack()
         return r
 
@@ -194,6 +257,70 @@ class AutoencoderKL(nn.Module):
         wo = d.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(co, -1).to(torch.float16).contiguous()
         img = rec.conv_out(xn, wo, _f32(d.conv_out.bias), batch=sb, cin=d.conv_out.in_channels, h=h, wd=w, cout=co)
         return SimpleNamespace(rec=rec, z=z, img=img)
+
+    def _plan_encode(self, sb, H, W, dev):
+        cfg, e = self.config, self.encoder
+        rec = Recorder(dev)
+        cin = e.conv_in.in_channels
+        x_in = rec.empty((sb, cin, H, W), torch.float32)
+        c0 = e.conv_in.out_channels
+        kin, kpad = cin * 9, (cin * 9 + 63) // 64 * 64
+        cols = rec.im2col3x3(x_in, batch=sb, cin=cin, h=H, wd=W, kpad=kpad)
+        w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=dev)
+        w_in[:, :kin] = e.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
+        x = rec.gemm(cols, w_in, bias=_f32(e.conv_in.bias), rows_per_image=H * W)
+        h, w = H, W
+        for blk in e.down_blocks:
+            for r in blk.resnets:
+                x = self._res(rec, r, x, sb, h, w)
+            if blk.downsamplers is not None:
+                conv = blk.downsamplers[0].conv
+                x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
+                             conv=dict(batch=sb, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2, pad=0))
+                h, w = h // 2, w // 2
+        x = self._res(rec, e.mid_block.resnets[0], x, sb, h, w)
+        x = self._attn(rec, e.mid_block.attentions[0], x, sb, h, w)
+        x = self._res(rec, e.mid_block.resnets[1], x, sb, h, w)
+        xn = rec.groupnorm(x, _f32(e.conv_norm_out.weight), _f32(e.conv_norm_out.bias), batch=sb, hw=h * w, eps=e.conv_norm_out.eps,
+                           act=ACT_SILU, groups=cfg.norm_num_groups)
+        # quant_conv (1x1) o conv_out (3x3) is one linear map: fold it in fp32, pad the 2*latent output rows to one 128-column tile
+        nm = e.conv_out.out_channels
+        wq = self.quant_conv.weight.detach().reshape(nm, nm).to(torch.float32)
+        wc = e.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(nm, -1).to(torch.float32)
+        w_fold = torch.zeros(128, wc.shape[1], dtype=torch.float16, device=dev)
+        w_fold[:nm] = (wq @ wc).to(torch.float16)
+        b_fold = torch.zeros(128, dtype=torch.float32, device=dev)
+        b_fold[:nm] = wq @ e.conv_out.bias.detach().to(torch.float32) + self.quant_conv.bias.detach().to(torch.float32)
+        mom = rec.gemm(xn, w_fold, bias=b_fold, out_f32=True, conv=dict(batch=sb, hin=h, win=w, hout=h, wout=w))   # [sb*h*w][128] fp32
+        return SimpleNamespace(rec=rec, x=x_in, moments=mom, h=h, w=w, nm=nm)
+
+    def _sub_batch_encode(self, batch, H, W):
+        boc = self.config.block_out_channels
+        worst = max(boc[0] * H * W * 2, 64 * H * W * 2)      # first-level activations / the im2col rows of conv_in
+        return max(1, min(batch, self.MAX_OPERAND_BYTES // worst))
+
+    def encode(self, x: torch.Tensor):
+        """``x``: (B,3,H,W) pixels in [-1,1] on the GPU -> ``.latent_dist`` over (B,latent_channels,H/8,W/8), fp32."""
+        if not self.config.with_encoder:
+            raise RuntimeError("this AutoencoderKL was built with with_encoder=False")
+        require_cuda(x, "pixel_values")
+        B, _, H, W = x.shape
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        assert H % down == 0 and W % down == 0, (H, W, down)
+        sb = self._sub_batch_encode(B, H, W)
+        key = ("enc", sb, H, W, x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._plan_encode(sb, H, W, x.device)
+        outs = []
+        for i in range(0, B, sb):
+            chunk = x[i:i + sb].to(torch.float32)
+            n = chunk.shape[0]
+            plan.x[:n].copy_(chunk)
+            plan.rec.run()
+            m = plan.moments.view(sb, plan.h, plan.w, -1)[:n, :, :, :plan.nm]
+            outs.append(m.permute(0, 3, 1, 2).contiguous())
+        return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(torch.cat(outs, 0)))
 
     def decode(self, z: torch.Tensor):
         require_cuda(z, "latents")

@@ -127,6 +127,26 @@ def test_conv3x3(rec_cls, cin, cout, h, stride, ups, B):
     assert rel_l2(out, ref) < 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,h,B", [(128, 128, 16, 2), (256, 256, 10, 3), (64, 320, 32, 2)])
+def test_conv3x3_stride2_asymmetric_pad(rec_cls, cin, cout, h, B):
+    """pad=0: the VAE encoder's Downsample2D = F.pad(x,(0,1,0,1)) + Conv2d(3x3, stride 2, padding 0)."""
+    x = h16(B, cin, h, h, seed=61)
+    w = h16(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=62)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(63))
+    ho = h // 2
+    rec = rec_cls("cuda")
+    out = rec.gemm(x.permute(0, 2, 3, 1).reshape(B * h * h, cin).contiguous().cuda(), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(),
+                   bias=bias.cuda(), conv=dict(batch=B, hin=h, win=h, hout=ho, wout=ho, stride=2, pad=0))
+    rec.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), bias, stride=2, padding=0)
+    assert ref.shape[-1] == ho
+    assert rel_l2(out, ref.permute(0, 2, 3, 1).reshape(B * ho * ho, cout)) < 1e-3
+    with pytest.raises(AssertionError):          # pad=0 exists for that one layer type only
+        rec_cls("cuda").gemm(x.permute(0, 2, 3, 1).reshape(B * h * h, cin).contiguous().cuda(), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(),
+                             conv=dict(batch=B, hin=h, win=h, hout=h, wout=h, stride=1, pad=0))
+
+
 def test_conv3x3_dual_source(rec_cls):
     B, c0, c1, cout, h = 2, 320, 640, 320, 8
     x0, x1 = h16(B, c0, h, h, seed=16), h16(B, c1, h, h, seed=17)

@@ -34,7 +34,7 @@ def test_cabi_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.pv_abi_version() == 1
+    assert lib.pv_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define PV_ABI_VERSION (\d+)", header).group(1))
     assert lib.pv_device_count() in (-1, 0) or torch.cuda.is_available()
 
 

@@ -1,4 +1,4 @@
-"""GPU parity of the HIP VAE decoder (infer.py:121-123) vs the CPU oracle."""
+"""GPU parity of the HIP VAE decoder (infer.py:121-123) and encoder (infer.py:63) vs the CPU oracle."""
 import pytest
 import torch
 
@@ -46,11 +46,97 @@ def test_vae_sub_batching_and_extra_keys(pair):
     assert rel_l2(got, exp) < 5e-3
     type(hip).MAX_OPERAND_BYTES = 1 << 30
     del hip.MAX_OPERAND_BYTES
-    # an HF checkpoint also carries encoder.* / quant_conv.* keys: ignored on load
+    # a decoder-only model ignores the encoder.* / quant_conv.* keys of an HF checkpoint
+    from photoverse_amd.vae import AutoencoderKL
     sd = dict(ref.state_dict())
     sd["encoder.conv_in.weight"] = torch.zeros(1)
     sd["quant_conv.weight"] = torch.zeros(1)
-    hip.load_state_dict(sd)
+    AutoencoderKL(**TINY, with_encoder=False).load_state_dict(sd)
+
+
+@pytest.fixture(scope="module")
+def enc_pair():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.vae_ref import AutoencoderKLDecoderRef
+    from photoverse_amd.vae import AutoencoderKL
+    torch.manual_seed(5)
+    ref = AutoencoderKLDecoderRef(**TINY, with_encoder=True).eval()
+    hip = AutoencoderKL(**TINY)
+    hip.load_state_dict(ref.state_dict())
+    hip.to("cuda")
+    return ref, hip
+
+
+@pytest.mark.parametrize("B,hw", [(1, 32), (3, 32), (2, 64)])
+def test_vae_encode_matches_oracle(enc_pair, B, hw):
+    """vae.encode(x).latent_dist (infer.py:63): mean / clamped logvar / a sample drawn with the same eps."""
+    ref, hip = enc_pair
+    g = torch.Generator().manual_seed(B * 100 + hw)
+    x = torch.rand(B, 3, hw, hw, generator=g) * 2 - 1
+    eps = torch.randn(B, 4, hw // 2, hw // 2, generator=g)
+    with torch.no_grad():
+        exp = ref.encode(x).latent_dist
+        got = hip.encode(x.cuda()).latent_dist
+    assert got.mean.shape == exp.mean.shape == (B, 4, hw // 2, hw // 2)
+    assert rel_l2(got.mean, exp.mean) < 5e-3
+    assert rel_l2(got.logvar, exp.logvar) < 5e-3
+    assert rel_l2(got.mean + got.std * eps.cuda(), exp.sample(eps=eps)) < 5e-3
+    assert torch.equal(got.mode(), got.mean)
+    torch.manual_seed(11)
+    s1 = got.sample()
+    torch.manual_seed(11)
+    assert torch.equal(s1, got.sample()) and s1.shape == got.mean.shape
+    # the stride-2 / pad-(0,1,0,1) downsample reads one zero row / column past the bottom / right edge only
+    x2 = x.clone()
+    x2[:, :, 0, :] = 0.5
+    with torch.no_grad():
+        assert rel_l2(hip.encode(x2.cuda()).latent_dist.mean, ref.encode(x2).latent_dist.mean) < 5e-3
+
+
+def test_run_inference_from_noised_image(enc_pair):
+    """infer.py:62-65: latents = add_noise(vae.encode(pixel_values).latent_dist.sample() * scaling_factor, noise, t_0)."""
+    from photoverse_amd.infer import run_inference
+    from photoverse_amd.modeling_utils import load_models
+    from oracle.unet_ref import TINY_CONFIG
+    _, hip_vae = enc_pair
+    vis = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2, image_size=56, patch_size=14)
+    txt = dict(vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=512, num_hidden_layers=1)
+    tok, te, vae, unet, ie, ia, ta, sch, _ = load_models(None, 1, unet_config=TINY_CONFIG, vision_config=vis, text_config=txt, seed=3)
+    for m in (unet, te, ie, ia, ta):
+        m.to("cuda")
+    g = torch.Generator().manual_seed(4)
+    ex = {"pixel_values": torch.rand(2, 3, 32, 32, generator=g) * 2 - 1, "pixel_values_clip": torch.randn(2, 3, 56, 56, generator=g),
+          "text_input_ids": torch.randint(0, 1000, (2, 77), generator=g), "concept_placeholder_idx": torch.tensor([[5], [3]])}
+    kw = dict(latent_size=16, guidance_scale=3.0, timesteps=2, seed=1)
+    with torch.no_grad():
+        a = run_inference(ex, tok, ie, te, unet, ta, ia, hip_vae, sch, "cuda", [1], from_noised_image=True, **kw)
+        b = run_inference(ex, tok, ie, te, unet, ta, ia, hip_vae, sch, "cuda", [1], from_noised_image=True, **kw)
+        c = run_inference(ex, tok, ie, te, unet, ta, ia, hip_vae, sch, "cuda", [1], from_noised_image=False, **kw)
+    assert a.shape == (2, 3, 32, 32) and torch.isfinite(a).all()
+    assert torch.equal(a, b)                      # same seed -> same posterior sample and noise
+    assert not torch.allclose(a, c)               # the start is the noised image, not pure noise
+
+
+def test_full_size_vae_encode_matches_oracle():
+    """SD-v1.5 VAE at its real size (83.65 M params with the encoder): one 256x256 image -> 32x32 posterior vs the fp32 CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.vae_ref import AutoencoderKLDecoderRef
+    from photoverse_amd.vae import AutoencoderKL
+    torch.manual_seed(6)
+    ref = AutoencoderKLDecoderRef(with_encoder=True).eval()
+    assert sum(p.numel() for p in ref.parameters()) == 83_653_863          # public SD AutoencoderKL size
+    hip = AutoencoderKL()
+    hip.load_state_dict(ref.state_dict())
+    hip.to("cuda")
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    with torch.no_grad():
+        exp = ref.encode(x).latent_dist
+        got = hip.encode(x.cuda()).latent_dist
+    e1, e2 = rel_l2(got.mean, exp.mean), rel_l2(got.logvar, exp.logvar)
+    print(f"full-size VAE encode rel-L2 vs fp32 oracle: mean {e1:.3e} logvar {e2:.3e}")
+    assert got.mean.shape == (1, 4, 32, 32) and e1 < 5e-3 and e2 < 5e-3
 
 
 def test_run_inference_returns_clamped_images_with_vae(pair):
