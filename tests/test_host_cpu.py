@@ -214,7 +214,7 @@ def test_load_models_from_local_hf_layout(tmp_path):
     tok, te, vae, unet, ie, *_ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=7)
     (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "image_encoder").mkdir(); (tmp_path / "vae").mkdir()
     vsd = {k: v.contiguous() for k, v in vae.state_dict().items()}
-    vsd["encoder.conv_in.weight"] = torch.zeros(2)            # HF vae checkpoints also hold the encoder: ignored
+    assert "encoder.conv_in.weight" in vsd and "quant_conv.weight" in vsd     # the HF vae checkpoint layout: encoder included
     save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
     plain = {k: v.contiguous() for k, v in unet.state_dict().items() if "processor" not in k}
     save_file(plain, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
