@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 2
+#define PV_ABI_VERSION 3
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -75,6 +75,9 @@ typedef struct pv_gemm_params {
     int32_t geglu;         /* 1 => W rows are tile-interleaved (value|gate); out[M][N/2] = value*gelu(gate) */
     int32_t splitk;        /* > 1: split the K loop over this many workgroups per tile (small-M layers); needs splitk_ws */
     float* splitk_ws;      /* fp32 workspace [splitk][M][N] for the partial slabs, reduced in fixed order */
+    float* colstats;       /* optional fp32 [ceil(M/64)][2][N]: per 64-row block and output column, the sum and the sum of
+                              squares of the (fp16-rounded) outputs - GroupNorm statistics of the tensor being written,
+                              consumed by pv_groupnorm_stats_from_colstats.  NULL = off.  fp16 output, no geglu, splitk <= 1. */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 
@@ -96,8 +99,13 @@ typedef struct pv_groupnorm_params {
     float eps;
     int32_t act;                     /* PV_ACT_NONE or PV_ACT_SILU */
     void* y;                         /* fp16 [B*HW][c0+c1] */
+    const float* colstats0;          /* pv_gemm_params.colstats of the launches that produced x0 / x1 (ld == c), or NULL */
+    const float* colstats1;
 } pv_groupnorm_params;
 int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream);
+/* same result as pv_groupnorm_stats, from the column statistics the producing GEMM epilogues left behind (no pass over x);
+ * needs hw % 64 == 0, colstats0 (and colstats1 when c1 > 0); fixed reduction order */
+int pv_groupnorm_stats_from_colstats(const pv_groupnorm_params* p, void* stream);
 int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream);
 
 /* LayerNorm over the last dim of fp16 rows (BasicTransformerBlock.norm1-3, CLIP layer norms,

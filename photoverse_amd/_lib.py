@@ -19,13 +19,14 @@ class GemmParams(C.Structure):
                 ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
                 ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
                 ("upsample", c_int), ("pad", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int),
-                ("splitk", c_int), ("splitk_ws", c_void_p)]
+                ("splitk", c_int), ("splitk_ws", c_void_p), ("colstats", c_void_p)]
 
 
 class GroupNormParams(C.Structure):
     _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("c0", c_int), ("c1", c_int), ("ld0", c_int), ("ld1", c_int),
                 ("batch", c_int), ("hw", c_int), ("groups", c_int), ("splits", c_int), ("partial", c_void_p),
-                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("act", c_int), ("y", c_void_p)]
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("act", c_int), ("y", c_void_p),
+                ("colstats0", c_void_p), ("colstats1", c_void_p)]
 
 
 class LayerNormParams(C.Structure):
@@ -52,6 +53,7 @@ SIGNATURES = {
     "pv_device_count": (c_int, []),
     "pv_gemm_conv": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "pv_groupnorm_stats": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
+    "pv_groupnorm_stats_from_colstats": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
     "pv_groupnorm_apply": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
     "pv_layernorm": (c_int, [C.POINTER(LayerNormParams), c_void_p]),
     "pv_attention": (c_int, [C.POINTER(AttnParams), c_void_p]),
@@ -74,7 +76,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

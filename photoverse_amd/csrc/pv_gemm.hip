@@ -88,6 +88,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ unsigned long long pv_clock_probe[4];
 #endif
 
+// all-reduce over the 16 lanes of a DPP row (row_ror:8,4,2,1)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 template <int NF, int WM, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int order) {
@@ -395,6 +404,11 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
                     res[ni][mi] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + nbase + ni * 16);
             }
         }
+        // optional GroupNorm column statistics of the tile being written (pv_gemm_params.colstats)
+        const bool want_cs = (WM == 2) && p.colstats != nullptr && !p.out_f32;
+        float4_t cs[NF], cq[NF];
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) cs[ni] = cq[ni] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
@@ -416,8 +430,17 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
                 if (p.out_f32) {
                     *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + nbase + ni * 16) = v;
                 } else {
-                    pk[ni][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[0], (half_t)v[1]});
-                    pk[ni][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[2], (half_t)v[3]});
+                    const half4_t hv = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    pk[ni][0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
+                    pk[ni][1] = __builtin_bit_cast(unsigned, half2_t{hv[2], hv[3]});
+                    if (want_cs) {   // statistics of what is stored (the rounded values), as a pass over the tensor would see
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float f = (float)hv[r];
+                            cs[ni][r] += f;
+                            cq[ni][r] += f * f;
+                        }
+                    }
                 }
             }
             if (!p.out_f32) {
@@ -438,6 +461,24 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
                 if (NF & 1) {
                     typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
                     *reinterpret_cast<uint2_t*>(orow + (NF - 1) * 16 + fq * 4) = uint2_t{pk[NF - 1][0], pk[NF - 1][1]};
+                }
+            }
+        }
+        if (want_cs && m0 + wm * (MI * 16) < p.M) {
+            // sum over the 16 lanes (rows) that share fq: DPP row rotations inside the 16-lane row, no LDS, fixed order
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[ni][r] = row16_sum(cs[ni][r]);
+                    cq[ni][r] = row16_sum(cq[ni][r]);
+                }
+            if (fr == 0) {
+                float* dst = p.colstats + ((size_t)(m0 / 64 + wm) * 2) * p.N + nbase;
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni) {
+                    *reinterpret_cast<float4_t*>(dst + ni * 16) = cs[ni];
+                    *reinterpret_cast<float4_t*>(dst + p.N + ni * 16) = cq[ni];
                 }
             }
         }
@@ -744,9 +785,9 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
 // each other's DMA waits; eight lock-stepped waves do not), so the 256-row instantiation is kept for experiments only.
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
-    if (PV_FORCE_WM == 4) return launch<NF, 4, CONV, GEGLU>(p, stream);
+    if (PV_FORCE_WM == 4 && !p.colstats) return launch<NF, 4, CONV, GEGLU>(p, stream);
 #if PV_FORCE_WM != 2
-    if constexpr (!GEGLU) {
+    if constexpr (!GEGLU) if (!p.colstats) {
         // big tile when it still gives every CU two workgroups; convs: stride 1 / no upsample only
         const long tiles256 = (long)((p.M + 255) / 256) * (p.N / (NF * 32));
         const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);
@@ -777,6 +818,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU || p.splitk < 0 || p.splitk > 16 ||
         !p.a0 || !p.w || !p.out || (p.c1 && !p.a1) || p.hout * p.wout <= 0)
         return (int)hipErrorInvalidValue;
+    if (p.colstats && (p.geglu || p.out_f32 || (p.splitk > 1 && p.splitk_ws))) return (int)hipErrorInvalidValue;
     if (p.taps == 9 && !(p.pad == 1 || (p.pad == 0 && p.stride == 2 && !p.upsample))) return (int)hipErrorInvalidValue;
     {
         const size_t a_rows = p.taps == 9 ? (size_t)p.batch * p.hin * p.win : (size_t)p.M;

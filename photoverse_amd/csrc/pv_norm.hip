@@ -94,6 +94,43 @@ __global__ void gn_finalize_kernel(const pv_groupnorm_params p) {
     }
 }
 
+// (mean, rstd) per (image, group) from the per-64-row-block column sums the producing GEMM epilogues wrote
+// (pv_gemm_params.colstats: [block][2][c] fp32).  One wave per (image, group); lanes stride over (block, channel) pairs,
+// fixed shuffle tree: deterministic.  Replaces gn_stats_kernel + gn_finalize_kernel: no pass over the activations.
+__global__ void gn_colstats_finalize_kernel(const pv_groupnorm_params p) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= p.batch * p.groups) return;
+    const int b = idx / p.groups, g = idx - b * p.groups;
+    const int C = p.c0 + p.c1;
+    const int cpg = C / p.groups;
+    const int R = p.hw >> 6;                       // 64-row blocks per image
+    float a = 0.f, q = 0.f;
+    for (int i = lane; i < R * cpg; i += 64) {
+        const int r = i / cpg, c = g * cpg + (i - r * cpg);
+        const size_t blk = (size_t)b * R + r;
+        if (c < p.c0) {
+            const float* src = p.colstats0 + blk * 2 * p.c0 + c;
+            a += src[0];
+            q += src[p.c0];
+        } else {
+            const float* src = p.colstats1 + blk * 2 * p.c1 + (c - p.c0);
+            a += src[0];
+            q += src[p.c1];
+        }
+    }
+    a = pv_wave_sum(a);
+    q = pv_wave_sum(q);
+    if (lane == 0) {
+        float* part = p.partial + ((size_t)b * p.splits * p.groups + g) * 2;
+        const float n = (float)cpg * (float)p.hw;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        part[0] = mean;
+        part[1] = rsqrtf(var + p.eps);
+    }
+}
+
 __global__ void gn_apply_kernel(const pv_groupnorm_params p, const int nchunk, const int rows_per_pass, const int px_per_block) {
     __shared__ float s_mean[64], s_rstd[64];
     const int C = p.c0 + p.c1;
@@ -223,6 +260,16 @@ extern "C" int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream) {
                        nchunk, rpp);
     const int ng = p->batch * p->groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_groupnorm_stats_from_colstats(const pv_groupnorm_params* p, void* stream) {
+    int nchunk, threads, rpp;
+    if (!gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->colstats0 || (p->c1 > 0 && !p->colstats1) || (p->hw % 64) ||
+        p->ld0 != p->c0 || (p->c1 > 0 && p->ld1 != p->c1))
+        return (int)hipErrorInvalidValue;
+    const int ng = p->batch * p->groups;
+    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }
 

@@ -69,6 +69,7 @@ class Recorder:
         self.calls: List[tuple] = []
         self.tags: List[tuple] = []        # per call: (kernel name, algorithmic flops, algorithmic bytes)
         self.keep: List[object] = []       # tensors / structs referenced by raw pointer
+        self.colstats: dict = {}           # (data_ptr, rows, cols) of a GEMM output -> its epilogue column statistics
         self.bytes_allocated = 0
 
     # ------------------------------------------------------------------ memory
@@ -91,7 +92,7 @@ class Recorder:
     def subset(self, pred) -> "Recorder":
         """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
         r = Recorder.__new__(Recorder)
-        r.lib, r.device, r.keep, r.bytes_allocated = self.lib, self.device, self.keep, 0
+        r.lib, r.device, r.keep, r.bytes_allocated, r.colstats = self.lib, self.device, self.keep, 0, self.colstats
         sel = [i for i, t in enumerate(self.tags) if pred(t)]
         r.calls = [self.calls[i] for i in sel]
         r.tags = [self.tags[i] for i in sel]
@@ -110,8 +111,11 @@ class Recorder:
     # ------------------------------------------------------------------ ops
     def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
              rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
-             out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None) -> torch.Tensor:
-        """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin]."""
+             out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None,
+             colstats: bool = False) -> torch.Tensor:
+        """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin].
+        ``colstats``: the output feeds a GroupNorm - let the epilogue leave its per-column (sum, sum of squares) behind so that
+        ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: split-K, fp32, GEGLU)."""
         lda0, c0 = _rows(a)
         lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
         taps = 9 if conv is not None else 1
@@ -139,8 +143,14 @@ class Recorder:
         tiles = ((M + 127) // 128) * (N // bn)
         splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
+        cs = None
+        key = (out.data_ptr(), M, n_out)
+        if colstats and splitk == 1 and not geglu and not out_f32 and ldc == n_out:
+            cs = self.colstats[key] = self.empty(((M + 63) // 64, 2, N), torch.float32)
+        else:
+            self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws))
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         name = f"gemm_conv_kernel<{nf},{'true' if conv is not None else 'false'},{'true' if geglu else 'false'}>"
@@ -156,10 +166,13 @@ class Recorder:
             splits //= 2
         partial = self.empty((batch, splits, groups, 2), torch.float32)
         y = self.empty((batch * hw, c0 + c1), torch.float16)
+        cs0 = self.colstats.get((x.data_ptr(), batch * hw, c0)) if ld0 == c0 else None
+        cs1 = self.colstats.get((x1.data_ptr(), batch * hw, c1)) if (x1 is not None and ld1 == c1) else None
+        from_cs = hw % 64 == 0 and cs0 is not None and (x1 is None or cs1 is not None)
         p = GroupNormParams(_ptr(x), _ptr(x1), c0, c1, ld0, ld1, batch, hw, groups, splits, _ptr(partial), _ptr(gamma), _ptr(beta),
-                            float(eps), act, _ptr(y))
+                            float(eps), act, _ptr(y), _ptr(cs0) if from_cs else None, _ptr(cs1) if from_cs else None)
         self.keep.extend(t for t in (x, x1, gamma, beta) if t is not None)
-        self._add(self.lib.pv_groupnorm_stats, p)
+        self._add(self.lib.pv_groupnorm_stats_from_colstats if from_cs else self.lib.pv_groupnorm_stats, p)
         self._add(self.lib.pv_groupnorm_apply, p)
         return y
 

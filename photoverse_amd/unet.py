@@ -214,14 +214,15 @@ class UNetEngine:
         hn = rec.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=b, hw=h * w, x1=x1, eps=m.norm1.eps, act=ACT_SILU)
         geo = dict(batch=b, hin=h, win=w, hout=h, wout=w)
         h1 = rec.gemm(hn, _conv3_w(m.conv1.weight), bias=_f32(m.conv1.bias), rowadd=temb_all[:, toff:toff + cout],
-                      rowadd_ld=(temb_all.stride(0) if self.t_rows > 1 else 0), conv=geo)
+                      rowadd_ld=(temb_all.stride(0) if self.t_rows > 1 else 0), conv=geo, colstats=True)
         h2 = rec.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=b, hw=h * w, eps=m.norm2.eps, act=ACT_SILU)
         if m.conv_shortcut is not None:
             sc = rec.gemm(x, _conv1_w(m.conv_shortcut.weight), a1=x1, bias=_f32(m.conv_shortcut.bias), rows_per_image=h * w)
         else:
             assert x1 is None
             sc = x
-        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo)
+        # every block output feeds a GroupNorm (next norm1 / Transformer2D.norm / conv_norm_out, directly or as a skip)
+        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo, colstats=True)
 
     def _transformer(self, name: str, m: Transformer2DModel, x, b, h, w):
         rec = self.rec
@@ -259,7 +260,7 @@ class UNetEngine:
         wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
         gg = rec.gemm(n3, wg, bias=bg, geglu=True, rows_per_image=n)
         hs = rec.gemm(gg, _f16(blk.ff.net[2].weight), bias=_f32(blk.ff.net[2].bias), residual=hs, rows_per_image=n)
-        return rec.gemm(hs, _conv1_w(m.proj_out.weight), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n)
+        return rec.gemm(hs, _conv1_w(m.proj_out.weight), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n, colstats=True)
 
     # ------------------------------------------------------------------ plan
     def _build(self):
@@ -288,7 +289,7 @@ class UNetEngine:
         cols = rec.im2col3x3(self.x_in, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
         w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=rec.device)
         w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
-        x = rec.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w)
+        x = rec.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True)
         skips = [(x, h, w)]
         for bi, blk in enumerate(u.down_blocks):
             for i, res in enumerate(blk.resnets):
@@ -299,7 +300,7 @@ class UNetEngine:
             if blk.downsamplers is not None:
                 conv = blk.downsamplers[0].conv
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=B, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2))
+                             conv=dict(batch=B, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2), colstats=True)
                 h, w = h // 2, w // 2
                 skips.append((x, h, w))
         mb = u.mid_block
@@ -316,7 +317,7 @@ class UNetEngine:
             if blk.upsamplers is not None:
                 conv = blk.upsamplers[0].conv
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=B, hin=h, win=w, hout=h * 2, wout=w * 2, upsample=1))
+                             conv=dict(batch=B, hin=h, win=w, hout=h * 2, wout=w * 2, upsample=1), colstats=True)
                 h, w = h * 2, w * 2
         xn = rec.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w,
                            eps=u.conv_norm_out.eps, act=ACT_SILU)

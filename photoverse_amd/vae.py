@@ -201,13 +201,13 @@ class AutoencoderKL(nn.Module):
         geo = dict(batch=b, hin=h, win=w, hout=h, wout=w)
         g = self.config.norm_num_groups
         hn = rec.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=b, hw=h * w, eps=m.norm1.eps, act=ACT_SILU, groups=g)
-        h1 = rec.gemm(hn, _conv3_w(m.conv1.weight), bias=_f32(m.conv1.bias), conv=geo)
+        h1 = rec.gemm(hn, _conv3_w(m.conv1.weight), bias=_f32(m.conv1.bias), conv=geo, colstats=True)
         h2 = rec.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=b, hw=h * w, eps=m.norm2.eps, act=ACT_SILU, groups=g)
         sc = x
         if m.conv_shortcut is not None:
             sc = rec.gemm(x, _f16(m.conv_shortcut.weight.reshape(m.conv_shortcut.out_channels, -1)), bias=_f32(m.conv_shortcut.bias),
                           rows_per_image=h * w)
-        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo)
+        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo, colstats=True)
 
     def _attn(self, rec: Recorder, m: _Attn, x, b, h, w):
         n, c = h * w, m.to_q.in_features
@@ -225,7 +225,7 @@ class AutoencoderKL(nn.Module):
             rec.softmax_rows(scores, scale=c ** -0.5)
             rec.gemm(wv, rec.hold(g[rows]), out=vt, splitk=0)                  # V^T = Wv X^T    (no bias: added after P.V)
             rec.gemm(scores, vt, bias=_f32(m.to_v.bias), out=o[rows], splitk=0)   # O = P V + bv
-        return rec.gemm(o, _f16(m.to_out[0].weight), bias=_f32(m.to_out[0].bias), residual=x, rows_per_image=n)
+        return rec.gemm(o, _f16(m.to_out[0].weight), bias=_f32(m.to_out[0].bias), residual=x, rows_per_image=n, colstats=True)
 
     def _plan(self, sb, h, w, dev):
         cfg, d = self.config, self.decoder
@@ -239,7 +239,7 @@ class AutoencoderKL(nn.Module):
         cols = rec.im2col3x3(zq, batch=sb, cin=lc, h=h, wd=w, kpad=kpad)
         w_in = torch.zeros(c_in, kpad, dtype=torch.float16, device=dev)
         w_in[:, :kin] = d.conv_in.weight.detach().reshape(c_in, kin).to(torch.float16)
-        x = rec.gemm(cols, w_in, bias=_f32(d.conv_in.bias), rows_per_image=h * w)
+        x = rec.gemm(cols, w_in, bias=_f32(d.conv_in.bias), rows_per_image=h * w, colstats=True)
         x = self._res(rec, d.mid_block.resnets[0], x, sb, h, w)
         x = self._attn(rec, d.mid_block.attentions[0], x, sb, h, w)
         x = self._res(rec, d.mid_block.resnets[1], x, sb, h, w)
@@ -249,7 +249,7 @@ class AutoencoderKL(nn.Module):
             if blk.upsamplers is not None:
                 conv = blk.upsamplers[0].conv
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=sb, hin=h, win=w, hout=2 * h, wout=2 * w, upsample=1))
+                             conv=dict(batch=sb, hin=h, win=w, hout=2 * h, wout=2 * w, upsample=1), colstats=True)
                 h, w = 2 * h, 2 * w
         xn = rec.groupnorm(x, _f32(d.conv_norm_out.weight), _f32(d.conv_norm_out.bias), batch=sb, hw=h * w, eps=d.conv_norm_out.eps,
                            act=ACT_SILU, groups=cfg.norm_num_groups)
@@ -268,7 +268,7 @@ class AutoencoderKL(nn.Module):
         cols = rec.im2col3x3(x_in, batch=sb, cin=cin, h=H, wd=W, kpad=kpad)
         w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=dev)
         w_in[:, :kin] = e.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
-        x = rec.gemm(cols, w_in, bias=_f32(e.conv_in.bias), rows_per_image=H * W)
+        x = rec.gemm(cols, w_in, bias=_f32(e.conv_in.bias), rows_per_image=H * W, colstats=True)
         h, w = H, W
         for blk in e.down_blocks:
             for r in blk.resnets:
@@ -276,7 +276,7 @@ class AutoencoderKL(nn.Module):
             if blk.downsamplers is not None:
                 conv = blk.downsamplers[0].conv
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=sb, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2, pad=0))
+                             conv=dict(batch=sb, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2, pad=0), colstats=True)
                 h, w = h // 2, w // 2
         x = self._res(rec, e.mid_block.resnets[0], x, sb, h, w)
         x = self._attn(rec, e.mid_block.attentions[0], x, sb, h, w)

@@ -193,6 +193,50 @@ def test_groupnorm(rec_cls, c0, c1, hw, act):
     assert rel_l2(y, ref.reshape(B * hw, C)) < 1e-3
 
 
+@pytest.mark.parametrize("c0,c1,cout,h,B", [(320, 0, 320, 16, 2), (64, 0, 128, 8, 3), (640, 320, 320, 16, 2), (128, 0, 320, 24, 1)])
+def test_groupnorm_from_gemm_column_statistics(rec_cls, c0, c1, cout, h, B):
+    """The GEMM / conv epilogue leaves per-64-row-block column (sum, sumsq) behind (pv_gemm_params.colstats) and GroupNorm takes
+    its statistics from them: same result as the pass over the tensor, on single- and dual-source (skip concat) inputs."""
+    hw = h * h
+    g = torch.Generator().manual_seed(70 + c0 + h)
+    gamma, beta = torch.randn(cout + (cout if c1 else 0), generator=g), torch.randn(cout + (cout if c1 else 0), generator=g)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * hw, -1).contiguous().cuda()
+    xa = h16(B, c0, h, h, seed=71)
+    wa = h16(cout, c0, 3, 3, scale=(9 * c0) ** -0.5 * 3, seed=72)
+    res = h16(B * hw, cout, seed=73)
+    rec = rec_cls("cuda")
+    ya = rec.gemm(rows(xa), wa.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), bias=torch.ones(cout).cuda(), residual=res.cuda(),
+                  conv=dict(batch=B, hin=h, win=h, hout=h, wout=h), colstats=True, splitk=0)   # (split-K launches have no statistics)
+    yb = None
+    if c1:   # second source: a 1x1 GEMM output (like a skip tensor written by proj_out)
+        xb = h16(B * hw, c1, seed=74)
+        yb = rec.gemm(xb.cuda(), h16(cout, c1, scale=c1 ** -0.5, seed=75).cuda(), rows_per_image=hw, colstats=True, splitk=0)
+    out = rec.groupnorm(ya, gamma.cuda(), beta.cuda(), batch=B, hw=hw, x1=yb, eps=1e-5, act=1)
+    names = [fn.__name__ for fn, _ in rec.calls]
+    assert ("pv_groupnorm_stats_from_colstats" in names) == (hw % 64 == 0) and ("pv_groupnorm_stats" in names) == (hw % 64 != 0)
+    rec.run()
+    torch.cuda.synchronize()
+    # the statistics themselves
+    cs = rec.colstats[(ya.data_ptr(), B * hw, cout)].cpu()
+    yf = ya.float().cpu()
+    nblk = (B * hw + 63) // 64
+    pad = torch.zeros(nblk * 64, cout); pad[:B * hw] = yf
+    blocks = pad.view(nblk, 64, cout)
+    assert torch.allclose(cs[:, 0], blocks.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(cs[:, 1], (blocks * blocks).sum(1), rtol=1e-4, atol=1e-3)
+    # GroupNorm of the stored tensors
+    x_all = torch.cat([yf] + ([yb.float().cpu()] if c1 else []), 1).view(B, hw, -1).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(x_all, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(B * hw, -1)
+    assert rel_l2(out, ref) < 1e-3
+    # a buffer rewritten without statistics falls back to the pass over the tensor
+    rec2 = rec_cls("cuda")
+    y2 = rec2.gemm(rows(xa), wa.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), conv=dict(batch=B, hin=h, win=h, hout=h, wout=h), colstats=True, splitk=0)
+    assert rec2.colstats
+    rec2.gemm(rows(xa), wa.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda(), conv=dict(batch=B, hin=h, win=h, hout=h, wout=h), out=y2)
+    rec2.groupnorm(y2, gamma[:cout].cuda(), beta[:cout].cuda(), batch=B, hw=hw)
+    assert "pv_groupnorm_stats_from_colstats" not in [fn.__name__ for fn, _ in rec2.calls]
+
+
 @pytest.mark.parametrize("cols", [320, 640, 768, 1024, 1280])
 def test_layernorm(rec_cls, cols):
     rows = 77
