@@ -97,7 +97,9 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int NF, int WM, bool CONV, bool GEGLU>
+// CS: instantiation whose epilogue also produces the GroupNorm column statistics (pv_gemm_params.colstats).  Separate from the
+// plain kernel because the extra 40 accumulators cost the launches that do not want them 2-3 %.
+template <int NF, int WM, bool CONV, bool GEGLU, bool CS = false>
 __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int order) {
     using Cfg = TileCfg<NF, WM>;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const p
             }
         }
         // optional GroupNorm column statistics of the tile being written (pv_gemm_params.colstats)
-        const bool want_cs = (WM == 2) && p.colstats != nullptr && !p.out_f32;
+        const bool want_cs = CS && (WM == 2) && p.colstats != nullptr && !p.out_f32;
         float4_t cs[NF], cq[NF];
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) cs[ni] = cq[ni] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -750,14 +752,14 @@ __global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int split
     }
 }
 
-template <int NF, int WM, bool CONV, bool GEGLU>
+template <int NF, int WM, bool CONV, bool GEGLU, bool CS = false>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = TileCfg<NF, WM>;
     static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = gemm_conv_kernel<NF, WM, CONV, GEGLU>;
+    auto kern = gemm_conv_kernel<NF, WM, CONV, GEGLU, CS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::SMEM_BYTES);
@@ -785,9 +787,12 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
 // each other's DMA waits; eight lock-stepped waves do not), so the 256-row instantiation is kept for experiments only.
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
-    if (PV_FORCE_WM == 4 && !p.colstats) return launch<NF, 4, CONV, GEGLU>(p, stream);
+    if constexpr (!GEGLU) {
+        if (p.colstats) return launch<NF, 2, CONV, false, true>(p, stream);
+    }
+    if (PV_FORCE_WM == 4) return launch<NF, 4, CONV, GEGLU>(p, stream);
 #if PV_FORCE_WM != 2
-    if constexpr (!GEGLU) if (!p.colstats) {
+    if constexpr (!GEGLU) {
         // big tile when it still gives every CU two workgroups; convs: stride 1 / no upsample only
         const long tiles256 = (long)((p.M + 255) / 256) * (p.N / (NF * 32));
         const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);

@@ -10,6 +10,7 @@ torch is used for device memory and streams only; every arithmetic op is a HIP k
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -58,6 +59,9 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     t, wn, ni, e = p // 128, (p % 128) // 64, (p % 64) // 16, p % 16
     src = t * 64 + wn * 32 + (ni // 2) * 16 + e + (ni & 1) * n
     return weight[src].contiguous(), (None if bias is None else bias[src].contiguous())
+
+
+_NO_COLSTATS = bool(os.environ.get("PV_NO_COLSTATS"))   # A/B switch: GroupNorm statistics by a pass over the tensor
 
 
 class Recorder:
@@ -145,7 +149,7 @@ class Recorder:
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)
-        if colstats and splitk == 1 and not geglu and not out_f32 and ldc == n_out:
+        if colstats and splitk == 1 and not geglu and not out_f32 and ldc == n_out and not _NO_COLSTATS:
             cs = self.colstats[key] = self.empty(((M + 63) // 64, 2, N), torch.float32)
         else:
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
