@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 # analytic algorithmic FLOPs of one SD-v1.5 UNet forward per sample at 64x64 latents, P=1
 UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+DOMINANT_KERNEL = "gemm_conv_kernel<5, 2, true, false, true>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -123,9 +124,10 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the implicit-GEMM 3x3 conv instantiation; replay exactly its launches of one step and
+        # dominant kernel = the implicit-GEMM 3x3 conv instantiation (160-column tile, GroupNorm column statistics in the
+        # epilogue: every 3x3 conv of the 64x64 / 32x32 levels); replay exactly its launches of one step and
         # time them with HIP events on the launch stream
-        dom = "gemm_conv_kernel<5,true,false>"
+        dom = DOMINANT_KERNEL
         subs = [e.rec.subset(lambda t: t[0] == dom) for e in loop.engines_u + loop.engines_c]
         nl = sum(len(s) for s in subs)
         flops = sum(t[1] for s in subs for t in s.tags)
@@ -147,13 +149,13 @@ def main():
         # collected in their own runs, so the number is read from the committed summary, not measured in this process)
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r01_pmc_traffic.json: " + pmc.get("note", "")
+            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r01_d_pmc_traffic.json: " + pmc.get("note", "")
         except (OSError, ValueError):
             pass
         algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl
-        roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel<5, 2, true, false>", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "measured": "HIP events around a back-to-back replay of this kernel's launches of one step on one stream "
                                 "(in the timed loop the uncond/cond forwards are two overlapping graph branches, so rocprof "
                                 "per-dispatch durations of the default run include co-scheduling; `--one-stream` is the matching run)",
