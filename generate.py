@@ -52,12 +52,12 @@ def prepare_example(args, tokenizer):
         import numpy as np
         img = Image.open(args.input_image_path).convert("RGB")
         clip = img.resize((224, 224), Image.BICUBIC)
-        arr = torch.from_numpy(np.asarray(clip)).float().div(255).permute(2, 0, 1)
+        arr = torch.from_numpy(np.array(clip)).float().div(255).permute(2, 0, 1)
         mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])[:, None, None]
         std = torch.tensor([0.26862954, 0.26130258, 0.27577711])[:, None, None]
         example["pixel_values_clip"] = ((arr - mean) / std)[None].repeat(n, 1, 1, 1)
         big = img.resize((8 * args.latent_size, 8 * args.latent_size), Image.BICUBIC)
-        example["pixel_values"] = (torch.from_numpy(np.asarray(big)).float().div(255).permute(2, 0, 1) * 2 - 1)[None].repeat(n, 1, 1, 1)
+        example["pixel_values"] = (torch.from_numpy(np.array(big)).float().div(255).permute(2, 0, 1) * 2 - 1)[None].repeat(n, 1, 1, 1)
     return example
 
 

@@ -294,3 +294,29 @@ def test_ddim_table_reproduces_stepwise_ddim():
             ca, cb, cx, c0, _ = tab[i, :5]
             x = cx * x + c0 * (ca * x + cb * eps)
             assert ((x - xr).norm() / xr.norm()).item() < 1e-6
+
+
+def test_generate_prepare_example_from_image_file(tmp_path):
+    """generate.py: an image file -> CLIP pixels (224x224, CLIP mean/std) + VAE pixels in [-1,1] (generate.py:53-61 of the reference)."""
+    import argparse
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    from photoverse_amd.tokenizer import SyntheticCLIPTokenizer
+    spec = importlib.util.spec_from_file_location("pv_generate", os.path.join(ROOT, "generate.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = np.random.default_rng(0)
+    path = tmp_path / "face.png"
+    Image.fromarray(rng.integers(0, 256, (300, 200, 3), dtype=np.uint8)).save(path)
+    args = argparse.Namespace(num_of_samples=2, text="a photo of a {}", negative_prompt="blurry", synthetic_input=False,
+                              input_image_path=str(path), seed=None, latent_size=32)
+    ex = gen.prepare_example(args, SyntheticCLIPTokenizer())
+    assert ex["pixel_values_clip"].shape == (2, 3, 224, 224) and ex["pixel_values"].shape == (2, 3, 256, 256)
+    assert ex["pixel_values"].min() >= -1 and ex["pixel_values"].max() <= 1
+    assert torch.equal(ex["pixel_values_clip"][0], ex["pixel_values_clip"][1])
+    assert ex["text_input_ids"].shape == (2, 77) and ex["negative_text_input_ids"].shape == (2, 77)
+    assert ex["concept_placeholder_idx"].tolist() == [[5], [5]]          # "a photo of a *": 4 words + BOS
+    args.synthetic_input = True
+    ex2 = gen.prepare_example(args, SyntheticCLIPTokenizer())
+    assert ex2["pixel_values"].abs().sum() == 0 and ex2["pixel_values_clip"].shape == (2, 3, 224, 224)
