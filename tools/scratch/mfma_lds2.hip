@@ -16,7 +16,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
   M(0,s6,s0) M(1,s6,s1) R(r4,16384) M(2,s6,s2) M(3,s6,s3) R(r5,18432) M(4,s7,s0) M(5,s7,s1) R(r6,20480) M(6,s7,s2) M(7,s7,s3) R(r7,22528) \
   M(0,s8,s0) M(1,s8,s1) R(r8,24576) M(2,s8,s2) M(3,s8,s3)
 
-template <int MODE>   // 0 burst, 1 spread, 2 MFMA only, 3 reads only
+template <int MODE>   // 0 burst, 1 spread, 2 MFMA only, 3 reads only, 4 burst + drain + s_barrier, 5 burst + drain
 __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   for (int i = threadIdx.x; i < 36864 / 2; i += blockDim.x) { unsigned h = (unsigned)i * 2654435761u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
@@ -40,6 +40,14 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
     } else if (MODE == 1) {
       asm volatile("s_waitcnt lgkmcnt(0)\n" SPREAD(17,18,19,20,21,22,23,24,25, 8,9,10,11,12,13,14,15,16)
                    "s_waitcnt lgkmcnt(0)\n" SPREAD(8,9,10,11,12,13,14,15,16, 17,18,19,20,21,22,23,24,25) OPS);
+    } else if (MODE == 4) {   // as the real kernel: full drain + workgroup barrier between the two phases of a K-step
+      asm volatile(RD9(8,9,10,11,12,13,14,15,16) "s_waitcnt lgkmcnt(9)\n" MMA20(17,18,19,20,21,22,23,24,25)
+                   "s_waitcnt lgkmcnt(0)\n s_barrier\n"
+                   RD9(17,18,19,20,21,22,23,24,25) "s_waitcnt lgkmcnt(9)\n" MMA20(8,9,10,11,12,13,14,15,16) OPS);
+    } else if (MODE == 5) {   // full drain, no barrier
+      asm volatile(RD9(8,9,10,11,12,13,14,15,16) "s_waitcnt lgkmcnt(9)\n" MMA20(17,18,19,20,21,22,23,24,25)
+                   "s_waitcnt lgkmcnt(0)\n"
+                   RD9(17,18,19,20,21,22,23,24,25) "s_waitcnt lgkmcnt(9)\n" MMA20(8,9,10,11,12,13,14,15,16) OPS);
     } else if (MODE == 2) {
       asm volatile(MMA20(17,18,19,20,21,22,23,24,25) MMA20(8,9,10,11,12,13,14,15,16) OPS);
     } else {
@@ -64,8 +72,8 @@ template <int MODE> void run(const char* name, float* d, int blocks_per_cu, int 
   float h[4]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
   const double mf = (MODE == 3) ? 0.0 : 40.0 * iters * waves * blocks_per_cu * 256.0;
   const double rd = (MODE == 2) ? 0.0 : 18.0 * iters * waves * blocks_per_cu * 256.0;
-  printf("%-12s %d block(s)/CU x %d waves: %7.2f ms  %5.2f PFLOP/s  LDS reads %6.1f TB/s   ns/step %.0f  memtime/memrealtime*100MHz = %.2f GHz\n", name, blocks_per_cu, waves, ms,
-         mf * 16384.0 / (ms * 1e-3) / 1e15, rd * 1024.0 / (ms * 1e-3) / 1e12, ms * 1e6 / iters, h[2] / h[3] * 0.1);
+  printf("%-12s %d block(s)/CU x %d waves: %7.2f ms  %5.2f PFLOP/s  LDS reads %6.1f TB/s   ns/step %.0f  clock %.2f GHz  -> %.0f cycles/step\n", name, blocks_per_cu, waves, ms,
+         mf * 16384.0 / (ms * 1e-3) / 1e15, rd * 1024.0 / (ms * 1e-3) / 1e12, ms * 1e6 / iters, h[2] / h[3] * 0.1, ms * 1e6 / iters * h[2] / h[3] * 0.1);
 }
 int main() { float* d; hipMalloc(&d, 64);
   const int cfg[3][2] = {{1, 4}, {1, 8}, {2, 4}};
@@ -76,6 +84,9 @@ int main() { float* d; hipMalloc(&d, 64);
   run<0>("zeros", d, 2, 4, 0.f); run<0>("grid", d, 2, 4, 1.f); run<0>("rand 1", d, 2, 4, 1.5f); run<0>("rand 4", d, 2, 4, 6.f);
   printf("same, MFMA only (operands loaded once from that LDS image)\n");
   run<2>("zeros", d, 2, 4, 0.f); run<2>("grid", d, 2, 4, 1.f); run<2>("rand 1", d, 2, 4, 1.5f);
+  printf("drain / barrier between the phases (2 blocks/CU x 4 waves, random data)\n");
+  run<0>("burst", d, 2, 4, 1.5f); run<5>("burst+drain", d, 2, 4, 1.5f); run<4>("burst+drain+barrier", d, 2, 4, 1.5f);
+  run<0>("burst, zeros", d, 2, 4, 0.f); run<5>("burst+drain, zeros", d, 2, 4, 0.f); run<4>("burst+drain+barrier, zeros", d, 2, 4, 0.f);
   printf("same, spread\n");
   run<1>("zeros", d, 2, 4, 0.f); run<1>("rand 1", d, 2, 4, 1.5f);
   return 0; }
