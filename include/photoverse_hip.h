@@ -168,7 +168,8 @@ int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t 
 /* conv_in: NCHW fp32 latents (B,cin,H,W) -> NHWC fp16 (B,H,W,cout), 3x3 pad 1; w fp32 [cout][cin][3][3] */
 int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin,
                int32_t h, int32_t wd, int32_t cout, void* stream);
-/* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin]; cout 4 (UNet) or 3 (VAE) */
+/* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin]; cout 4 (UNet) or 3 (VAE);
+ * cin in {64, 128, 256, 320} */
 int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin,
                 int32_t h, int32_t wd, int32_t cout, void* stream);
 /* CFG combine (infer.py:116) + DPM-Solver++(2M) update (infer.py:119) on fp32 NCHW latents.

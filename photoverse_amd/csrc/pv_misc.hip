@@ -73,41 +73,99 @@ __global__ void conv_in_kernel(const float* __restrict__ x, const float* __restr
     }
 }
 
-// conv_out: NHWC fp16 -> NCHW fp32, 3x3 pad 1, cout <= 8.  One wave = one output pixel.
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+// conv_out: NHWC fp16 -> NCHW fp32, 3x3 pad 1, cout <= 8 (UNet 320 -> 4, VAE 128 -> 3).  Far too few output channels for the
+// MFMA tile: VALU kernel.  8 threads per output pixel, each owning the 16-byte channel chunks {sub, sub+8, ...} of all 9
+// taps (one pixel's 8 threads read 128 contiguous bytes; neighbouring pixels re-read the same rows out of L1); the whole
+// filter (cout*9*cin halfs, <= 23 KB) sits in LDS and is read as broadcasts; products by v_dot2_f32_f16; the 8 partial sums
+// of a pixel meet through three lane-xor steps.  (The first version - one wave per pixel, weights from global - spent
+// 109 us on the UNet's 65536 x 320 -> 4 launch.)
+// CPT: 16-byte channel chunks per thread (cin = 64 * CPT) - the chunk loads of a tap are issued together and the next tap's
+// loads are in flight while the current tap is multiplied (45 dependent load -> use round trips per thread otherwise).
+template <int COUT, int CPT>
+__global__ __launch_bounds__(256, 4) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int batch, int cin,
                                                        int h, int wd) {
-    const int lane = threadIdx.x & 63;
-    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= (long)batch * h * wd) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    half_t* sw = reinterpret_cast<half_t*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int wtot = COUT * 9 * cin;
+    for (int i = tid * 8; i < wtot; i += 256 * 8) *reinterpret_cast<half8_t*>(sw + i) = *reinterpret_cast<const half8_t*>(w + i);
+    __syncthreads();
+    const int sub = tid & 7;
+    const long total = (long)batch * h * wd;
+    // grid-stride over 32-pixel groups: the LDS filter fill (as many bytes as 36 pixels of input) is paid once per workgroup
+    for (long grp = blockIdx.x; grp * 32 < total; grp += gridDim.x) {
+    const long pix_raw = grp * 32 + (tid >> 3);
+    const bool ok = pix_raw < total;
+    const long pix = ok ? pix_raw : total - 1;
     const int b = (int)(pix / (h * wd));
     const int rem = (int)(pix - (long)b * h * wd);
     const int y = rem / wd, xx = rem - y * wd;
-    const int nchunk = cin >> 3;
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
+    auto load_tap = [&](int tap, half8_t (&v)[CPT]) {
         const int iy = y + tap / 3 - 1, ix = xx + tap % 3 - 1;
-        if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;  // wave-uniform
-        const half_t* xr = x + ((long)(b * h + iy) * wd + ix) * cin;
-        for (int ch = lane; ch < nchunk; ch += 64) {
-            const half8_t v = *reinterpret_cast<const half8_t*>(xr + ch * 8);
+        const bool in = iy >= 0 && iy < h && ix >= 0 && ix < wd;
+        const half_t* xr = x + ((long)(b * h + (in ? iy : y)) * wd + (in ? ix : xx)) * cin;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            v[i] = *reinterpret_cast<const half8_t*>(xr + (sub + i * 8) * 8);
+            if (!in) v[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto mac_tap = [&](int tap, const half8_t (&v)[CPT]) {
+        const half_t* wr = sw + tap * cin;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
 #pragma unroll
             for (int c = 0; c < COUT; ++c) {
-                const half8_t ww = *reinterpret_cast<const half8_t*>(w + ((long)c * 9 + tap) * cin + ch * 8);
+                const half8_t ww = *reinterpret_cast<const half8_t*>(wr + c * 9 * cin + (sub + i * 8) * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c] += (float)v[j] * (float)ww[j];
+                for (int j = 0; j < 4; ++j)
+                    acc[c] = __builtin_amdgcn_fdot2(half2_t{v[i][2 * j], v[i][2 * j + 1]}, half2_t{ww[2 * j], ww[2 * j + 1]}, acc[c], false);
             }
-        }
+    };
+    half8_t va[CPT], vb[CPT];
+    load_tap(0, va);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {      // rolled: fully unrolled, hipcc hoists every load / LDS read and spills (916 B scratch)
+        load_tap(min(tap + 1, 8), vb);
+        mac_tap(tap, va);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) va[i] = vb[i];
     }
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = pv_wave_sum(acc[c]);
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) out[(((long)b * COUT + c) * h + y) * wd + xx] = acc[c] + (bias ? bias[c] : 0.f);
+    for (int c = 0; c < COUT; ++c) {
+        acc[c] += __shfl_xor(acc[c], 1, 64);
+        acc[c] += __shfl_xor(acc[c], 2, 64);
+        acc[c] += __shfl_xor(acc[c], 4, 64);
     }
+    if (ok && sub < COUT) {
+        float v = acc[0];
+#pragma unroll
+        for (int c = 1; c < COUT; ++c) v = (sub == c) ? acc[c] : v;
+        out[(((long)b * COUT + sub) * h + y) * wd + xx] = v + (bias ? bias[sub] : 0.f);
+    }
+    }
+}
+
+template <int COUT>
+int launch_conv_out(const half_t* x, const half_t* w, const float* bias, float* out, int batch, int cin, int h, int wd, hipStream_t stream) {
+    const long pix = (long)batch * h * wd;
+    const size_t smem = (size_t)COUT * 9 * cin * sizeof(half_t);
+    const long groups = (pix + 31) / 32;
+    const long per_cu = smem ? (long)(160 * 1024 / smem) : 8;                     // workgroups per CU that fit (LDS, <= 8 by waves)
+    const long cap = 256 * (per_cu < 8 ? per_cu : 8);
+    const dim3 grid((unsigned)(groups < cap ? groups : cap)), block(256);
+    switch (cin / 64) {
+        case 1: hipLaunchKernelGGL((conv_out_kernel<COUT, 1>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
+        case 2: hipLaunchKernelGGL((conv_out_kernel<COUT, 2>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
+        case 4: hipLaunchKernelGGL((conv_out_kernel<COUT, 4>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
+        case 5: hipLaunchKernelGGL((conv_out_kernel<COUT, 5>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return PV_CHECK_LAUNCH();
 }
 
 __global__ void geglu_kernel(const half_t* x, int ldx, half_t* out, int ldo, int rows, int n) {
@@ -396,15 +454,11 @@ extern "C" int pv_conv_in(const float* x, const float* w, const float* bias, voi
 
 extern "C" int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t h,
                            int32_t wd, int32_t cout, void* stream) {
-    if (batch <= 0 || (cin % 8) || (cout != 4 && cout != 3) || !x || !w || !out) return (int)hipErrorInvalidValue;
-    const long pix = (long)batch * h * wd;
+    if (batch <= 0 || (cin % 64) || (cout != 4 && cout != 3) || !x || !w || !out) return (int)hipErrorInvalidValue;
+    // cin in {64, 128, 256, 320}: the filter (<= 23 KB) lives in LDS
     if (cout == 4)
-        hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
-    else
-        hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd);
-    return PV_CHECK_LAUNCH();
+        return launch_conv_out<4>(reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd, (hipStream_t)stream);
+    return launch_conv_out<3>(reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd, (hipStream_t)stream);
 }
 
 extern "C" int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, int32_t n, void* stream) {

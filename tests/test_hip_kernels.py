@@ -321,6 +321,10 @@ def test_conv_in_out_timestep(rec_cls):
     bo = torch.randn(4, generator=torch.Generator().manual_seed(35))
     z = rec.conv_out(xo.permute(0, 2, 3, 1).reshape(-1, 320).contiguous().cuda(), wo.permute(0, 2, 3, 1).reshape(4, -1).contiguous().cuda(),
                      bo.cuda(), batch=B, cin=320, h=h, wd=h, cout=4)
+    xv = h16(3, 128, 10, 10, seed=36)                    # VAE-shaped: 128 -> 3, pixel count not a multiple of the 32-pixel block
+    wv = h16(3, 128, 3, 3, scale=0.05, seed=37)
+    zv = rec.conv_out(xv.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().cuda(), wv.permute(0, 2, 3, 1).reshape(3, -1).contiguous().cuda(),
+                      None, batch=3, cin=128, h=10, wd=10, cout=3)
     ts = torch.tensor([951.0, 20.0, 500.0])
     te = rec.timestep_embedding(ts.cuda(), None, 3, 320)
     rec.run()
@@ -329,6 +333,7 @@ def test_conv_in_out_timestep(rec_cls):
     assert rel_l2(y, ref) < 5e-4
     refo = F.conv2d(xo.float(), wo.float(), bo, padding=1)
     assert rel_l2(z, refo) < 1e-5
+    assert rel_l2(zv, F.conv2d(xv.float(), wv.float(), None, padding=1)) < 1e-5
     half = 160
     freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
     emb = ts[:, None] * freq[None]

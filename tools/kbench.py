@@ -104,6 +104,16 @@ def ln(name, c, rows):
     cases.append((name, f))
 
 
+def conv_out(name, cin, cout, hw, b=B):
+    def f():
+        rec = Recorder(dev)
+        x = h16(b * hw * hw, cin)
+        w = h16(cout, 9 * cin, scale=0.02)
+        rec.conv_out(x, w, torch.zeros(cout, device=dev), batch=b, cin=cin, h=hw, wd=hw, cout=cout)
+        return rec, 2.0 * b * hw * hw * cout * 9 * cin, 2.0 * b * hw * hw * cin
+    cases.append((name, f))
+
+
 conv("conv3 320->320 @64", 320, 320, 64)
 conv("conv3 640+320->320 @64 (dual)", 640, 320, 64, c1=320)
 conv("conv3 320->320 @64 s2", 320, 320, 64, stride=2)
@@ -130,6 +140,8 @@ attn("attn d80 n1024", 80, 1024)
 attn("attn d160 n256", 160, 256)
 xattn("xattn d40 n4096", 40, 4096)
 xattn("xattn d80 n1024", 80, 1024)
+conv_out("conv_out 320->4 @64", 320, 4, 64)
+conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)
 gn("gn+silu 1280 @16", 1280, 16)
 ln("ln 320 x65536", 320, 65536)
