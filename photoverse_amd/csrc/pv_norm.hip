@@ -97,16 +97,17 @@ __global__ void gn_finalize_kernel(const pv_groupnorm_params p) {
 // (mean, rstd) per (image, group) from the per-64-row-block column sums the producing GEMM epilogues wrote
 // (pv_gemm_params.colstats: [block][2][c] fp32).  One wave per (image, group); lanes stride over (block, channel) pairs,
 // fixed shuffle tree: deterministic.  Replaces gn_stats_kernel + gn_finalize_kernel: no pass over the activations.
-__global__ void gn_colstats_finalize_kernel(const pv_groupnorm_params p) {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (idx >= p.batch * p.groups) return;
+__global__ __launch_bounds__(256) void gn_colstats_finalize_kernel(const pv_groupnorm_params p) {
+    // one 256-thread workgroup per (image, group): 2-3 independent load pairs per thread instead of 10 dependent trips of one wave
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x;
     const int b = idx / p.groups, g = idx - b * p.groups;
     const int C = p.c0 + p.c1;
     const int cpg = C / p.groups;
     const int R = p.hw >> 6;                       // 64-row blocks per image
     float a = 0.f, q = 0.f;
-    for (int i = lane; i < R * cpg; i += 64) {
+    for (int i = tid; i < R * cpg; i += 256) {
         const int r = i / cpg, c = g * cpg + (i - r * cpg);
         const size_t blk = (size_t)b * R + r;
         if (c < p.c0) {
@@ -121,7 +122,11 @@ __global__ void gn_colstats_finalize_kernel(const pv_groupnorm_params p) {
     }
     a = pv_wave_sum(a);
     q = pv_wave_sum(q);
-    if (lane == 0) {
+    if (lane == 0) { red[wave] = a; red[4 + wave] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        a = (red[0] + red[1]) + (red[2] + red[3]);          // fixed order: deterministic
+        q = (red[4] + red[5]) + (red[6] + red[7]);
         float* part = p.partial + ((size_t)b * p.splits * p.groups + g) * 2;
         const float n = (float)cpg * (float)p.hw;
         const float mean = a / n;
@@ -269,7 +274,7 @@ extern "C" int pv_groupnorm_stats_from_colstats(const pv_groupnorm_params* p, vo
         p->ld0 != p->c0 || (p->c1 > 0 && p->ld1 != p->c1))
         return (int)hipErrorInvalidValue;
     const int ng = p->batch * p->groups;
-    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3(ng), dim3(256), 0, (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }
 

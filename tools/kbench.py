@@ -95,6 +95,18 @@ def gn(name, c, hw):
     cases.append((name, f))
 
 
+def gn_cs(name, c, hw):
+    """GroupNorm whose statistics come from the producing GEMM's epilogue: times the finalize + apply launches only."""
+    def f():
+        rec = Recorder(dev)
+        a = h16(B * hw * hw, c)
+        x = rec.gemm(a, h16(c, c, scale=0.05), rows_per_image=hw * hw, colstats=True, splitk=0)
+        rec.groupnorm(x, torch.ones(c, device=dev), torch.zeros(c, device=dev), batch=B, hw=hw * hw, act=1)
+        rec.run()
+        return rec.subset(lambda t: "groupnorm" in t[0]), 0, 2.0 * 2 * B * hw * hw * c
+    cases.append((name, f))
+
+
 def ln(name, c, rows):
     def f():
         rec = Recorder(dev)
@@ -144,6 +156,8 @@ conv_out("conv_out 320->4 @64", 320, 4, 64)
 conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)
 gn("gn+silu 1280 @16", 1280, 16)
+gn_cs("gn(colstats)+silu 320 @64", 320, 64)
+gn_cs("gn(colstats)+silu 640 @32", 640, 32)
 ln("ln 320 x65536", 320, 65536)
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
