@@ -309,8 +309,11 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 constexpr int XKEYS = 96;
 constexpr int IP0 = 80;
 
-template <int D>
-__global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
+// qt_per_wg: 128-row query tiles one workgroup walks with ONE staging of the (b, h) K/V image (the staging and its barrier
+// were most of a 4096-workgroup launch's time at one tile each).
+template <int D, bool MULTI>
+__global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p, const int qt_per_wg_arg) {
+    const int qt_per_wg = MULTI ? qt_per_wg_arg : 1;      // MULTI = false is the straight one-tile kernel (no prefetch registers)
     using C = ACfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sK = reinterpret_cast<half_t*>(smem);
@@ -319,8 +322,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
     const int nqt = (p.nq + 127) / 128;
+    const int nqg = (nqt + qt_per_wg - 1) / qt_per_wg;   // query-tile groups per (b, h)
     const int rid = (int)blockIdx.x;     // K/V are 96 rows: no L2 affinity to gain from an XCD remap (measured slower)
-    const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
+    const int qg = rid % nqg, h = (rid / nqg) % p.heads, b = rid / (nqg * p.heads);
     const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
 
     // stage K and V (zero-filled pads)
@@ -350,22 +354,26 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
         }
     }
 
-    half8_t qf[2][C::KSTEPS];
+    half8_t qf[2][C::KSTEPS], qn[MULTI ? 2 : 1][MULTI ? C::KSTEPS : 1];
     int qrow[2];
+    auto load_q = [&](int qt, auto& dst) {
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
-        const int rc = min(qrow[qi], p.nq - 1);
+        for (int qi = 0; qi < 2; ++qi) {
+            const int rc = min(qt * 128 + wave * 32 + qi * 16 + fr, p.nq - 1);
 #pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ++ks) {
-            const int c = ks * 4 + fq;
-            qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const int c = ks * 4 + fq;
+                dst[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+            }
         }
-    }
+    };
+    const int qt0 = qg * qt_per_wg;
+    const int qt1 = min(qt0 + qt_per_wg, nqt);
+    if constexpr (MULTI) load_q(qt0, qn); else load_q(qt0, qf);
     __syncthreads();
 
     // to_v_ip_norm (attention_processor.py:397): ||Vip[b,p,h,:]||_2, once per (b,h)
-    if (p.vnorm && qt == 0 && tid < p.nip) {
+    if (p.vnorm && qg == 0 && tid < p.nip) {
         float a = 0.f;
         for (int d = 0; d < D; ++d) {
             const float v = (float)sV[(IP0 + tid) * C::VS + d];
@@ -375,6 +383,19 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
     }
 
     constexpr int NKB = XKEYS / 16;
+#pragma unroll 1
+    for (int qt = qt0; qt < (MULTI ? qt1 : qt0 + 1); ++qt) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) qf[qi][ks] = qn[qi][ks];
+        }
+    }
+    if constexpr (MULTI) {
+        if (qt + 1 < qt1) load_q(qt + 1, qn);      // next tile's queries are in flight during this tile's softmax
+    }
     float4_t s[NKB][2];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -466,6 +487,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p) {
             }
         }
     }
+    }   // query tiles of this workgroup
 }
 
 template <int D>
@@ -489,11 +511,18 @@ int launch_xattn(const pv_xattn_params& p, hipStream_t s) {
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (smem > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(xattn_kernel<D>, dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem, s, p);
+    const int nqt = (p.nq + 127) / 128;
+    const long wgs = (long)nqt * p.heads * p.batch;
+    int qt_per_wg = (int)(wgs / 1024);                       // keep >= ~1024 workgroups (4 per CU) in the launch
+    qt_per_wg = qt_per_wg < 1 ? 1 : (qt_per_wg > 4 ? 4 : qt_per_wg);
+    const int nqg = (nqt + qt_per_wg - 1) / qt_per_wg;
+    if (qt_per_wg > 1) hipLaunchKernelGGL((xattn_kernel<D, true>), dim3(nqg * p.heads * p.batch), dim3(256), smem, s, p, qt_per_wg);
+    else hipLaunchKernelGGL((xattn_kernel<D, false>), dim3(nqg * p.heads * p.batch), dim3(256), smem, s, p, 1);
     return PV_CHECK_LAUNCH();
 }
 
