@@ -159,6 +159,8 @@ gn("gn+silu 1280 @16", 1280, 16)
 gn_cs("gn(colstats)+silu 320 @64", 320, 64)
 gn_cs("gn(colstats)+silu 640 @32", 640, 32)
 ln("ln 320 x65536", 320, 65536)
+ln("ln 640 x16384", 640, 16384)
+ln("ln 1280 x4096", 1280, 4096)
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 print(f"{'case':40s} {'us':>10s} {'TFLOP/s':>9s} {'GB/s':>9s}")
