@@ -45,7 +45,11 @@ __device__ __forceinline__ float pv_erf_fast(float x) {
     const float r = fmaf(-poly * t, e, 1.0f);
     return copysignf(r, x);
 }
+#ifdef PV_GELU_IDENTITY   // timing experiment only (wrong results): what the erf costs the GEGLU epilogue
+__device__ __forceinline__ float pv_gelu_erf(float x) { return x; }
+#else
 __device__ __forceinline__ float pv_gelu_erf(float x) { return 0.5f * x * (1.0f + pv_erf_fast(x * 0.70710678118654752440f)); }
+#endif
 __device__ __forceinline__ float pv_apply_act(float x, int act) {
     switch (act) {
         case PV_ACT_SILU: return pv_silu(x);
