@@ -1,5 +1,7 @@
 """Oracle: DPM-Solver++(2M) as the reference uses it.  TEST INFRASTRUCTURE.
-**PARITY UNPINNED** ([EXT] ``diffusers==0.27.2`` ``DPMSolverMultistepScheduler``).
+**PARITY UNPINNED** against the library ([EXT] ``diffusers==0.27.2`` ``DPMSolverMultistepScheduler``, not installable);
+the algorithm itself is checked against the closed-form probability-flow solution for Gaussian data
+(``tests/test_oracle_pins.py::test_samplers_converge_to_the_exact_probability_flow_solution``).
 
 The reference rebuilds the sampler on every call with
 ``DPMSolverMultistepScheduler.from_config(scheduler.config)`` where

@@ -175,3 +175,52 @@ def test_scheduler_tables():
     for i, t in enumerate(s.timesteps):
         x = s.step(eps, t, x)
     torch.testing.assert_close(x, x0, rtol=1e-3, atol=1e-3)
+
+
+def test_samplers_converge_to_the_exact_probability_flow_solution():
+    """Known-answer test for the UNPINNED samplers (diffusers is not installable): for Gaussian data x0 ~ N(0, s^2 I) the optimal
+    epsilon-predictor is linear, eps*(x_t) = sigma_t x_t / (alpha_t^2 s^2 + sigma_t^2), and the probability-flow ODE it drives has
+    the closed form x_t = x_T sqrt(var_t / var_T).
+    (1) On a grid uniform in lambda = log(alpha/sigma) the DPM-Solver++(2M) update must converge to it at SECOND order - this pins
+        the data-prediction conversion and the multistep coefficients.
+    (2) On the reference's own grid ("leading" spacing, uniform in t, final jump to sigma = 0) the last steps have h = O(1) in
+        lambda whatever the step count (lambda ~ -1/2 log t), so the error only falls like 1/n - checked as monotone decrease, which
+        still pins the noise schedule and the timestep / sigma tables (a wrong table gives an error that does not shrink).
+    (3) DDIM: first order on its own grid."""
+    import numpy as np
+    from oracle.scheduler_ref import DDIMRef, DPMSolverMultistepRef
+    s2 = 0.25
+    x_init = torch.randn(64, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    rel = lambda x, exact: ((x - exact).norm() / exact.norm()).item()
+
+    def dpm(n, lam_grid):
+        sch = DPMSolverMultistepRef()
+        sch.set_timesteps(n)
+        if lam_grid:
+            sch.sigmas = np.exp(-np.linspace(-2.5, 3.0, n + 1))          # sigma/alpha = exp(-lambda); stops at lambda = 3 (no jump to 0)
+        var = lambda i: (lambda a, sg: a * a * s2 + sg * sg)(*sch._alpha_sigma(np.float64(sch.sigmas[i])))
+        x = x_init.clone()
+        for i, t in enumerate(sch.timesteps):
+            a, sg = sch._alpha_sigma(np.float64(sch.sigmas[i]))
+            x = sch.step(float(sg / (a * a * s2 + sg * sg)) * x, t, x)
+        return rel(x, x_init * float(np.sqrt(var(n) / var(0))))
+
+    e = {n: dpm(n, True) for n in (40, 80, 160)}
+    assert e[160] < 1e-4, e
+    assert 3.5 < e[40] / e[80] < 4.5 and 3.5 < e[80] / e[160] < 4.5, e          # second order: h/2 -> error/4
+    f = {n: dpm(n, False) for n in (20, 40, 80, 160)}
+    assert f[160] < 1.5e-2 and all(1.6 < f[n] / f[2 * n] < 2.4 for n in (20, 40, 80)), f
+
+    def ddim(n):
+        sch = DDIMRef()
+        sch.set_timesteps(n)
+        acp = sch.alphas_cumprod
+        var = lambda a: float(a) * s2 + (1.0 - float(a))
+        x = x_init.clone()
+        for t in sch.timesteps:
+            a = acp[int(t)]
+            x = sch.step(float((1 - a).sqrt() / var(a)) * x, t, x)
+        return rel(x, x_init * float(np.sqrt(var(acp[0]) / var(acp[int(sch.timesteps[0])]))))
+
+    d = {n: ddim(n) for n in (20, 40, 80, 160)}
+    assert d[160] < 2e-2 and all(1.5 < d[n] / d[2 * n] < 2.6 for n in (20, 40, 80)), d
