@@ -799,6 +799,7 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
         // measured (profiles/r01_kbench_c.txt): ~3 % faster on the 64x64-level 3x3 convs, not on the short-K Linear layers
         if (PV_BIG_TILES == 1 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 3, CONV>(p, stream);
         if (PV_BIG_TILES == 4 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);
+        if (PV_BIG_TILES == 6 && CONV && tiles256 >= 256 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);   // + one-workgroup-per-CU launches
         if (PV_BIG_TILES == 5 && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);   // + the Linear layers
         // experiment: 128-row tile with 32-deep stages -> three workgroups per CU
         if (PV_BIG_TILES == 2 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 2, CONV>(p, stream);
