@@ -168,7 +168,7 @@ def main():
                                                     "operands, no global traffic, holds 1.70 GHz (2.40 GHz / 2.45 PFLOP/s only with zeros)"}}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (contract); N > 1 runs stay short
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -190,6 +190,7 @@ def main():
         }
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()               # rank 0's roofline replay is over: every rank leaves the group together
         dist.destroy_process_group()
 
 
