@@ -30,6 +30,9 @@ parser.add_argument("--from_noised_image", action="store_true", help="Use noised
 parser.add_argument("--synthetic_input", action="store_true", help="Random CLIP pixels instead of an image file")
 parser.add_argument("--seed", type=int, default=None)
 parser.add_argument("--latent_size", type=int, default=64)
+parser.add_argument("--image_encoder_path", type=str, default=None,
+                    help="Local directory of openai/clip-vit-large-patch14 (default: <model_path>/image_encoder)")
+parser.add_argument("--tiny", action="store_true", help="Small random-init model (smoke tests of the CLI; needs --model_path random)")
 
 
 def prepare_example(args, tokenizer):
@@ -49,15 +52,14 @@ def prepare_example(args, tokenizer):
         example["pixel_values"] = torch.zeros(n, 3, 8 * args.latent_size, 8 * args.latent_size)
     else:
         from PIL import Image
-        import numpy as np
-        img = Image.open(args.input_image_path).convert("RGB")
-        clip = img.resize((224, 224), Image.BICUBIC)
-        arr = torch.from_numpy(np.array(clip)).float().div(255).permute(2, 0, 1)
-        mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])[:, None, None]
-        std = torch.tensor([0.26862954, 0.26130258, 0.27577711])[:, None, None]
-        example["pixel_values_clip"] = ((arr - mean) / std)[None].repeat(n, 1, 1, 1)
-        big = img.resize((8 * args.latent_size, 8 * args.latent_size), Image.BICUBIC)
-        example["pixel_values"] = (torch.from_numpy(np.array(big)).float().div(255).permute(2, 0, 1) * 2 - 1)[None].repeat(n, 1, 1, 1)
+        from photoverse_amd.image_utils import clip_image_processor, preprocess_image
+        raw_image = Image.open(args.input_image_path)
+        if raw_image.mode != "RGB":
+            raw_image = raw_image.convert("RGB")
+        # generate.py:57-58: CLIPImageProcessor (short side 224 bicubic + centre crop) and preprocess_image (short side `size`
+        # bicubic + centre crop, [-1, 1]); size = 8 * latent (512 for the reference's fixed latent_size 64)
+        example["pixel_values_clip"] = clip_image_processor(raw_image)[None].repeat(n, 1, 1, 1)
+        example["pixel_values"] = preprocess_image(raw_image, size=8 * args.latent_size, interpolation="bicubic")[None].repeat(n, 1, 1, 1)
     return example
 
 
@@ -66,8 +68,18 @@ if __name__ == "__main__":
     if not torch.cuda.is_available():
         raise SystemExit("generate.py needs a HIP device: photoverse_amd has no CPU path")
     device = torch.device("cuda")
+    cfg = {}
+    if args.tiny:
+        if args.model_path != "random":
+            raise SystemExit("--tiny builds a small random-init model: use it with --model_path random")
+        cfg = dict(unet_config=dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                                    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D")),
+                   vision_config=dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=max(args.encoder_layers_idx) + 1),
+                   text_config=dict(hidden_size=768, num_attention_heads=12, intermediate_size=512, num_hidden_layers=2),
+                   vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1))      # 4 levels: x8 like the real VAE
     tokenizer, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
-        None if args.model_path == "random" else args.model_path, args.extra_num_tokens, args.checkpoint_path)
+        None if args.model_path == "random" else args.model_path, args.extra_num_tokens, args.checkpoint_path,
+        image_encoder_path=args.image_encoder_path, **cfg)
     for m in (vae, unet, text_encoder, image_encoder, image_adapter, text_adapter):
         m.to(device)
     example = prepare_example(args, tokenizer)
@@ -76,8 +88,8 @@ if __name__ == "__main__":
                             args.encoder_layers_idx, latent_size=args.latent_size, guidance_scale=args.guidance_scale,
                             timesteps=args.num_timesteps, from_noised_image=args.from_noised_image, seed=args.seed)
     os.makedirs(args.results_dir, exist_ok=True)
-    from PIL import Image
-    imgs = ((out.float().cpu() + 1.0) / 2.0).clamp(0, 1).mul(255).round().to(torch.uint8)     # utils/image_utils.py:6-29 denormalize + to_pil
+    from photoverse_amd.image_utils import denormalize, to_pil
+    imgs = [to_pil(denormalize(img)) for img in out.float().cpu()]                            # generate.py:86
     for idx, img in enumerate(imgs):
-        Image.fromarray(img.permute(1, 2, 0).numpy()).save(os.path.join(args.results_dir, f"{args.output_image_path}{idx}.png"))
+        img.save(os.path.join(args.results_dir, f"{args.output_image_path}{idx}.png"))
     print(f"saved {len(imgs)} image(s) {tuple(out.shape[1:])} to {args.results_dir}/")

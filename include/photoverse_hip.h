@@ -158,8 +158,9 @@ int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, i
 
 /* ------------------------------------------------------------------------------------------
  * Step-state driven pieces of the denoising loop (infer.py:98-119).  `state` is a small device
- * block: int32 step index at state[0]; tables are indexed with it so that ONE captured HIP
- * graph can be replayed for every step.
+ * block of int32: step index at state[0], number of table rows at state[1] (0 = unknown); the
+ * tables are indexed with min(state[0], state[1]-1) so that ONE captured HIP graph can be
+ * replayed for every step and a step past the end of the schedule never reads beyond them.
  */
 /* sinusoidal timestep embedding (flip_sin_to_cos, shift 0) -> fp16 [rows][dim];
  * t taken from timesteps[state ? *state : 0 ... ] : rows>1 => per-row timesteps[row] */

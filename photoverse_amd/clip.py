@@ -218,6 +218,12 @@ class CLIPTextModel(_CachedPlans):
         if lo < 0 or hi >= self.config.vocab_size:
             raise IndexError(f"token id out of range [0, {self.config.vocab_size})")
         E = 0 if concept is None else concept.shape[1]
+        if E:
+            # the reference's slice assignment (clip.py:17-24) raises when the concept rows do not fit the sequence; the fused
+            # embed kernel would read out of bounds (negative index) or truncate silently - check on the host like the ids
+            plo, phi = int(pidx.min()), int(pidx.max())
+            if plo < 0 or phi + E > S:
+                raise IndexError(f"concept_placeholder_idx must satisfy 0 <= idx and idx + {E} <= {S} (got [{plo}, {phi}])")
         key = (B, S, E, ids.device)
         plan = self._plans.get(key)
         if plan is None:

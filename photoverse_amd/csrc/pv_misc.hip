@@ -12,13 +12,20 @@ extern "C" int pv_device_count(void) {
 
 namespace {
 
+// step index of the loop state block, clamped to the table length state[1] (0 = length unknown): a step() past the end of the
+// schedule re-reads the last row instead of reading beyond the tables (the host raises before that, pipeline.DenoiseLoop.step)
+__device__ __forceinline__ int pv_step_index(const int32_t* state) {
+    const int i = state[0], n = state[1];
+    return n > 0 ? min(i, n - 1) : i;
+}
+
 // [EXT] diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void timestep_embedding_kernel(const float* timesteps, const int32_t* state, int rows, int dim, half_t* out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * dim) return;
     const int row = idx / dim, i = idx - row * dim;
     const int half = dim >> 1;
-    const float t = state ? timesteps[state[0]] : timesteps[row];
+    const float t = state ? timesteps[pv_step_index(state)] : timesteps[row];
     const int k = i < half ? i : i - half;
     const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
     const float a = t * freq;
@@ -190,7 +197,7 @@ __global__ void cfg_dpm_step_kernel(const float* eu, const float* ec, float* lat
                                     const int32_t* state, float g, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    const float* c = coef + (long)state[0] * 8;
+    const float* c = coef + (long)pv_step_index(state) * 8;
     const float ca = c[0], cb = c[1], cx = c[2], c0 = c[3], c1 = c[4];
     const float4_t u = *reinterpret_cast<const float4_t*>(eu + i);
     const float4_t cc = *reinterpret_cast<const float4_t*>(ec + i);

@@ -9,26 +9,37 @@ device generator (``torch.manual_seed(seed)`` seeds it like the reference's, the
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import torch
 
 from .pipeline import DenoiseLoop
 from .scheduler import DPMSolverMultistepScheduler
 
 
+#: captured loops kept per UNet (each holds two engines of static activations: ~4 GB at bs=16) - least recently used evicted
+MAX_CACHED_LOOPS = 2
+
+
 def _loop_for(unet, batch, latent_size, n_ip, steps, guidance, scheduler) -> DenoiseLoop:
-    cache = unet.__dict__.setdefault("_denoise_loops", {})
+    cache = unet.__dict__.setdefault("_denoise_loops", OrderedDict())
     key = (batch, latent_size, n_ip, steps, float(guidance))
-    loop = cache.get(key)
+    loop = cache.pop(key, None)
     if loop is None or loop.unet_version != unet.__dict__.get("_pack_version", 0):
         loop = DenoiseLoop(unet, batch, latent_size, n_ip, steps, guidance, scheduler=scheduler)
         loop.unet_version = unet.__dict__.get("_pack_version", 0)
-        cache[key] = loop
+    cache[key] = loop                               # most recently used last
+    while len(cache) > MAX_CACHED_LOOPS:
+        cache.popitem(last=False)
     return loop
 
 
 def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, scheduler,
                   device, image_encoder_layers_idx, latent_size=64, guidance_scale=1, timesteps=100, token_index=0,
-                  disable_tqdm=False, seed=None, from_noised_image=False, training_mode=False):
+                  disable_tqdm=False, seed=None, from_noised_image=False, training_mode=False, *, noise=None):
+    """Same 11 positional + 8 keyword arguments as the reference.  ``noise`` (keyword-only, new): a caller-drawn start noise
+    ``(B, C, latent, latent)`` replacing the draw of ``infer.py:52-59`` - used by the batch-sharded pipeline, which draws the
+    global batch once and hands each rank its slice."""
     if training_mode:
         raise NotImplementedError("training_mode (grad through the last step, infer.py:99) belongs to the training row (SURVEY 8f-3)")
     device = torch.device(device)
@@ -42,7 +53,11 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
                                      return_tensors="pt").input_ids
 
     shape = (batch, unet.config.in_channels, latent_size, latent_size)                    # :52-59 noise on CPU, then moved
-    if seed is None:
+    if noise is not None:
+        if tuple(noise.shape) != shape:
+            raise ValueError(f"noise has shape {tuple(noise.shape)}, expected {shape}")
+        noise = noise.to(device)
+    elif seed is None:
         noise = torch.randn(shape).to(device)
     else:
         generator = torch.manual_seed(seed)
@@ -61,12 +76,12 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
     image_features = image_encoder(pixel_values_clip, output_hidden_states=True)          # :76-78
     uncond_image_features = image_encoder(torch.zeros_like(pixel_values_clip), output_hidden_states=True)
     image_embeddings = [image_features[0]] + [image_features[2][i] for i in image_encoder_layers_idx if i < len(image_features[2])]
-    uncond_image_emmbedings = [uncond_image_features[0]] + [uncond_image_features[2][i] for i in image_encoder_layers_idx
+    uncond_image_embeddings = [uncond_image_features[0]] + [uncond_image_features[2][i] for i in image_encoder_layers_idx
                                                             if i < len(uncond_image_features[2])]
 
     concept_text_embeddings = text_adapter(image_embeddings, token_index=token_index)     # :89-91
     encoder_hidden_states_image = image_adapter(image_embeddings, token_index=token_index)
-    uncond_encoder_hidden_states_image = image_adapter(uncond_image_emmbedings, token_index=token_index)
+    uncond_encoder_hidden_states_image = image_adapter(uncond_image_embeddings, token_index=token_index)
 
     uncond_embeddings = text_encoder({"text_input_ids": uncond_input_ids.to(device)})[0]  # :93-96
     encoder_hidden_states = text_encoder({"text_input_ids": example["text_input_ids"].to(device),

@@ -37,7 +37,9 @@ class DenoiseLoop:
         self.x0_prev = torch.zeros_like(self.latents)
         self.timesteps = sch.timesteps.to(device=dev, dtype=f32)
         self.coef = sch.coefficient_table().to(dev)
-        self.state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.state = torch.tensor([0, num_steps, 0, 0], dtype=torch.int32, device=dev)   # {step index, table rows, -, -}
+        self._state0 = self.state.clone()
+        self._host_step = 0
         self.text_c = torch.zeros((batch * n_text, xdim), dtype=f16, device=dev)
         self.text_u = torch.zeros_like(self.text_c)
         self.ip_c = torch.zeros((batch * n_ip, xdim), dtype=f16, device=dev)
@@ -83,7 +85,8 @@ class DenoiseLoop:
         """latents = noise * init_noise_sigma (``infer.py:70``); step counter to 0."""
         self.latents.copy_(noise.to(self.latents.device) * self.scheduler.init_noise_sigma)
         self.x0_prev.zero_()
-        self.state.zero_()
+        self.state.copy_(self._state0)
+        self._host_step = 0
 
     def _step_eager(self):
         if self.two_streams:
@@ -123,6 +126,11 @@ class DenoiseLoop:
         self.graph = g
 
     def step(self):
+        # the device tables have T rows: a step past the end of the schedule is a caller bug (the kernels clamp the index, so it
+        # could not read out of bounds, but the result would be meaningless)
+        if self._host_step >= self.T:
+            raise RuntimeError(f"DenoiseLoop.step(): all {self.T} steps of the schedule have run; call reset() first")
+        self._host_step += 1
         if self.use_graph:
             if self.graph is None:
                 self.capture()
@@ -150,9 +158,12 @@ def gather_latents(local: torch.Tensor, world: int, force: bool = False) -> torc
     import torch.distributed as dist
     if world == 1 and not force:
         return local
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    src = local.contiguous()
+    if src.is_cuda and dist.get_backend() == "gloo":     # gloo has no device all_gather (tests on a 1-GPU box): stage through the host
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(local.device)
 
 
 class PhotoVersePipeline:
@@ -187,8 +198,12 @@ class PhotoVersePipeline:
             n = example["pixel_values_clip"].shape[0]
             sl = shard_batch(n, rank, world)
             local = {k: (v[sl] if torch.is_tensor(v) and v.shape[:1] == (n,) else v) for k, v in example.items()}
-            if kw.get("seed") is not None:      # the global noise is drawn once with the reference's generator semantics and sliced
-                raise NotImplementedError("sharded calls take per-rank noise; draw the global noise with DenoiseLoop for exact 1-GPU parity")
+            if kw.get("seed") is not None:
+                # the noise of the GLOBAL batch is drawn once with the reference's generator semantics (infer.py:52-59: CPU global
+                # generator) on every rank and sliced, so sample i equals sample i of the seeded 1-GPU run
+                latent_size = kw.get("latent_size", 64)
+                generator = torch.manual_seed(kw["seed"])
+                kw["noise"] = torch.randn((n, self.unet.config.in_channels, latent_size, latent_size), generator=generator)[sl]
             out = run_inference(local, self.tokenizer, self.image_encoder, self.text_encoder, self.unet, self.text_adapter,
                                 self.image_adapter, self.vae, self.scheduler, self.device, list(image_encoder_layers_idx), **kw)
             return gather_latents(out, world, force=True)

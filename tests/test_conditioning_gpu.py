@@ -120,3 +120,92 @@ def test_run_inference_end_to_end_matches_oracle(need_gpu):
     with pytest.raises(NotImplementedError):
         run_inference(example, tok, image_encoder, text_encoder, unet, text_adapter, image_adapter, None, scheduler, "cuda", [1],
                       latent_size=16, timesteps=2, from_noised_image=True)
+
+
+def test_generate_cli_end_to_end(need_gpu, tmp_path):
+    """Row G: the CLI counterpart of /root/reference/generate.py runs as a program - load_models -> preprocessing ->
+    run_inference (CLIP, adapters, text encoder, graph loop, VAE decode) -> PNG files - once from synthetic pixels and once from
+    an image file through the reference-exact preprocessing (short-side resize + centre crop)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "generate.py"), "--model_path", "random", "--tiny", "--num_timesteps", "2", "--latent_size", "16",
+            "--num_of_samples", "2", "--seed", "3", "--guidance_scale", "2.0", "--encoder_layers_idx", "1", "2"]
+    out1 = tmp_path / "synthetic"
+    r = subprocess.run(base + ["--synthetic_input", "--results_dir", str(out1)], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    files = sorted(os.listdir(out1))
+    assert files == ["generated_image0.png", "generated_image1.png"]
+    a = np.asarray(Image.open(out1 / files[0]))
+    assert a.shape == (128, 128, 3) and a.dtype == np.uint8 and a.std() > 0
+    rng = np.random.default_rng(0)
+    face = tmp_path / "face.png"
+    Image.fromarray(rng.integers(0, 256, (300, 200, 3), dtype=np.uint8)).save(face)
+    out2 = tmp_path / "from_file"
+    r = subprocess.run(base + ["--input_image_path", str(face), "--results_dir", str(out2), "--from_noised_image", "--negative_prompt", "blurry"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sorted(os.listdir(out2)) == files
+    b = np.asarray(Image.open(out2 / files[1]))
+    assert b.shape == (128, 128, 3) and b.std() > 0
+
+
+def test_reference_layout_checkpoint_loads_into_hip_path(need_gpu, tmp_path):
+    """A `photoverse_000001.pt` in the reference's layout (modeling_utils.py:29-50: image_adapter, text_adapter, the attn2
+    to_q/to_k/to_v + processor subset WITH peft-style LoRA keys, lora_config) is loaded by load_models into a fresh HIP model; the
+    UNet forward and both adapters then match the oracle loaded from the SAME file (LoRA applied as W + alpha/r B A)."""
+    from oracle.adapters_ref import PhotoVerseAdapterRef
+    from oracle.unet_ref import TINY_CONFIG, UNet2DConditionModelRef, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_models, save_progress
+    cfg = LoraConfig(r=4, lora_alpha=8)
+    kw = dict(unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT)
+    # "trained" model: seeded init + non-zero LoRA B, written in the reference layout
+    _t, _te, _v, unet_a, _ie, ia_a, ta_a, _s, _ = load_models(None, 1, use_lora=True, lora_config=cfg, seed=11, **kw)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for n, p in unet_a.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    save_progress(ia_a, ta_a, unet_a, None, str(tmp_path), step=1, lora_config=cfg)
+    ck_path = str(tmp_path / "photoverse_000001.pt")
+    ck = torch.load(ck_path)
+    assert any("lora_A.default.weight" in k for k in ck["cross_attention_adapter"]) and ck["lora_config"]["r"] == 4
+    # fresh model (same base seed = the frozen SD weights, which the checkpoint does not carry) + the checkpoint, on the device
+    _t, _te, _v, unet_b, _ie, ia_b, ta_b, _s, lc = load_models(None, 1, ck_path, seed=11, **kw)
+    assert lc is not None and lc.r == 4
+    for m in (unet_b, ia_b, ta_b):
+        m.to("cuda")
+    # oracle from the same file: base weights of the same seed, cross-attention subset from the file with LoRA merged by hand
+    ref = UNet2DConditionModelRef(**TINY_CONFIG).eval()
+    set_visual_cross_attention_adapter_ref(ref, (2,))
+    base_sd = {k: v for k, v in unet_a.state_dict().items() if "lora_" not in k}
+    base_sd = {k.replace(".base_layer.", "."): v for k, v in base_sd.items()}
+    ca = ck["cross_attention_adapter"]
+    for k in list(ca):
+        if k.endswith("base_layer.weight"):
+            stem = k[: -len("base_layer.weight")]
+            base_sd[stem + "weight"] = ca[k] + (cfg.lora_alpha / cfg.r) * (ca[stem + "lora_B.default.weight"] @ ca[stem + "lora_A.default.weight"])
+        elif "lora_" not in k:
+            base_sd[k] = ca[k]
+    ref.load_state_dict(base_sd)
+    x, text, ip = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 768, generator=g), torch.randn(2, 2, 768, generator=g)
+    with torch.no_grad():
+        exp = ref(x, torch.tensor(400), encoder_hidden_states=(text, ip)).sample
+        got = unet_b(x.cuda(), torch.tensor(400), encoder_hidden_states=(text.cuda(), ip.cuda())).sample
+    assert rel_l2(got, exp) < 2.5e-3
+    # without the LoRA term the result must differ measurably (the test would otherwise not see a dropped adapter)
+    for k in list(ca):
+        if k.endswith("base_layer.weight"):
+            base_sd[k[: -len("base_layer.weight")] + "weight"] = ca[k]
+    ref.load_state_dict(base_sd)
+    with torch.no_grad():
+        assert rel_l2(got, ref(x, torch.tensor(400), encoder_hidden_states=(text, ip)).sample) > 3 * rel_l2(got, exp)
+    r_ia = PhotoVerseAdapterRef(256, 768, 2).eval(); r_ia.load_state_dict(ck["image_adapter"])
+    r_ta = PhotoVerseAdapterRef(256, 768, 2).eval(); r_ta.load_state_dict(ck["text_adapter"])
+    embs = [torch.randn(2, 17, 256, generator=g) for _ in range(2)]
+    with torch.no_grad():
+        assert rel_l2(ia_b([e.cuda() for e in embs]), r_ia(embs)) < 3e-3
+        assert rel_l2(ta_b([e.cuda() for e in embs], token_index=0), r_ta(embs, token_index=0)) < 3e-3

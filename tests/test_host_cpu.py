@@ -208,26 +208,110 @@ def test_checkpoint_layout_roundtrip_and_lora(tmp_path):
         load_models("runwayml/stable-diffusion-v1-5", 1)                                              # no network here
 
 
+def _write_synthetic_clip_vocab(d):
+    """A small CLIP-style vocabulary (byte alphabet, </w> forms, greedy merges of a tiny corpus): vocab.json + merges.txt."""
+    import json
+    from photoverse_amd.tokenizer import bytes_to_unicode
+    alphabet = list(bytes_to_unicode().values())
+    vocab = alphabet + [c + "</w>" for c in alphabet]
+    corpus = ("a photo of a person wearing sunglasses on the beach . the quick brown fox's 42 jumps over l'ete don't stop , "
+              "photo photos photographer").split()
+    words = [tuple(w[:-1]) + (w[-1] + "</w>",) for w in corpus]
+    merges = []
+    for _ in range(60):
+        cnt = {}
+        for w in words:
+            for a, b in zip(w, w[1:]):
+                cnt[(a, b)] = cnt.get((a, b), 0) + 1
+        if not cnt:
+            break
+        best = max(sorted(cnt), key=lambda k: cnt[k])
+        merges.append(best)
+        nw = []
+        for w in words:
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            nw.append(tuple(out))
+        words = nw
+    vocab += [a + b for a, b in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    enc = {t: i for i, t in enumerate(vocab)}
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "vocab.json"), "w") as fh:
+        json.dump(enc, fh)
+    with open(os.path.join(d, "merges.txt"), "w") as fh:
+        fh.write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    return enc, merges
+
+
+def test_bpe_tokenizer_matches_installed_transformers(tmp_path):
+    """photoverse_amd's CLIP BPE vs the installed transformers CLIPTokenizer built from the SAME vocabulary files."""
+    from photoverse_amd.tokenizer import CLIPBPETokenizer, SyntheticCLIPTokenizer, load_tokenizer
+    enc, merges = _write_synthetic_clip_vocab(str(tmp_path / "tokenizer"))
+    mine = load_tokenizer(str(tmp_path))
+    assert isinstance(mine, CLIPBPETokenizer) and isinstance(load_tokenizer(None), SyntheticCLIPTokenizer)
+    from transformers import CLIPTokenizer
+    hf = CLIPTokenizer(vocab=enc, merges=merges)
+    texts = ["a photo of a *", "A Photo of   a person's sunglasses, 42 foxes!", "", "the   beach .", "photographer l'ete don't", "x " * 100]
+    for t in texts:
+        a = mine(t, padding="max_length", max_length=77, return_tensors="pt").input_ids
+        b = hf(t, padding="max_length", truncation=True, max_length=77, return_tensors="pt").input_ids
+        assert a.shape == (1, 77) and torch.equal(a, b), t
+    batch = mine(texts[:3], padding="max_length", max_length=77, return_tensors="pt").input_ids
+    assert batch.shape == (3, 77) and batch[2, 0] == enc["<|startoftext|>"] and (batch[2, 1:] == enc["<|endoftext|>"]).all()
+
+
 def test_load_models_from_local_hf_layout(tmp_path):
     from safetensors.torch import save_file
     from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.tokenizer import CLIPBPETokenizer
     tok, te, vae, unet, ie, *_ = load_models(None, 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=7)
-    (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "image_encoder").mkdir(); (tmp_path / "vae").mkdir()
-    vsd = {k: v.contiguous() for k, v in vae.state_dict().items()}
-    assert "encoder.conv_in.weight" in vsd and "quant_conv.weight" in vsd     # the HF vae checkpoint layout: encoder included
+    (tmp_path / "unet").mkdir(); (tmp_path / "text_encoder").mkdir(); (tmp_path / "vae").mkdir()
+    clipdir = tmp_path / "clip-vit"                      # the reference pulls the image encoder from a separate repository
+    clipdir.mkdir()
+    # the published SD-v1.5 VAE file uses the deprecated attention names (query / key / value / proj_attn)
+    dep = {".to_q.": ".query.", ".to_k.": ".key.", ".to_v.": ".value.", ".to_out.0.": ".proj_attn."}
+    vsd = {}
+    for k, v in vae.state_dict().items():
+        if ".attentions." in k:
+            for new, old in dep.items():
+                k = k.replace(new, old)
+        vsd[k] = v.contiguous()
+    assert "encoder.conv_in.weight" in vsd and "quant_conv.weight" in vsd and any(".proj_attn." in k for k in vsd)
     save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
     plain = {k: v.contiguous() for k, v in unet.state_dict().items() if "processor" not in k}
     save_file(plain, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
     save_file({k: v.contiguous() for k, v in te.state_dict().items()}, str(tmp_path / "text_encoder" / "model.safetensors"))
-    save_file({k: v.contiguous() for k, v in ie.state_dict().items()}, str(tmp_path / "image_encoder" / "model.safetensors"))
-    tok2, te2, vae2, unet2, ie2, *_ = load_models(str(tmp_path), 1, unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=8)
+    full_clip = {k: v.contiguous() for k, v in ie.state_dict().items()}
+    full_clip["text_model.embeddings.token_embedding.weight"] = torch.zeros(4, 4)      # the CLIP repo holds both towers
+    full_clip["visual_projection.weight"] = torch.zeros(4, 4)
+    save_file(full_clip, str(clipdir / "model.safetensors"))
+    kw = dict(unet_config=TINY, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=8)
+    # loud, not silent: no tokenizer files / no image encoder where expected
+    with pytest.raises(FileNotFoundError, match="tokenizer"):
+        load_models(str(tmp_path), 1, image_encoder_path=str(clipdir), **kw)
+    _write_synthetic_clip_vocab(str(tmp_path / "tokenizer"))
+    with pytest.raises(FileNotFoundError, match="image encoder"):
+        load_models(str(tmp_path), 1, **kw)
+    tok2, te2, vae2, unet2, ie2, *_ = load_models(str(tmp_path), 1, image_encoder_path=str(clipdir), **kw)
+    assert isinstance(tok2, CLIPBPETokenizer)
     assert all(torch.equal(unet2.state_dict()[k], v) for k, v in plain.items())
     assert all(torch.equal(a, b) for a, b in zip(te2.state_dict().values(), te.state_dict().values()))
     assert all(torch.equal(a, b) for a, b in zip(ie2.state_dict().values(), ie.state_dict().values()))
-    assert all(torch.equal(a, b) for a, b in zip(vae2.state_dict().values(), vae.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(vae2.state_dict().values(), vae.state_dict().values()))     # deprecated names mapped
     assert not any(p.requires_grad for p in vae2.parameters())
     assert not any(p.requires_grad for p in unet2.conv_in.parameters())                # frozen (modeling_utils.py:63-66)
     assert all(p.requires_grad for n, p in unet2.named_parameters() if "processor" in n)   # created after the freeze
+    # a weight file that misses parameters raises; strict_load=False downgrades to warnings and keeps the seeded init
+    partial = {k: v for k, v in plain.items() if "mid_block" not in k}
+    save_file(partial, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(KeyError, match="UNet"):
+        load_models(str(tmp_path), 1, image_encoder_path=str(clipdir), **kw)
+    with pytest.warns(UserWarning, match="random-init"):
+        load_models(str(tmp_path), 1, image_encoder_path=str(clipdir), strict_load=False, **kw)
 
 
 def test_adapter_default_init_equals_real_reference(golden_dir):
@@ -255,6 +339,69 @@ def _gloo_worker(rank, world, port, q):
     ok = torch.equal(full, noise * 2.0 + 1.0)
     q.put((rank, ok, tuple(full.shape)))
     dist.destroy_process_group()
+
+
+def _gloo_pipeline_worker(rank, world, port, q):
+    """PhotoVersePipeline(shard=True, seed=...) under gloo: the host logic of the sharded entry point (example slicing, ONE global
+    noise draw sliced per rank, one gather) with the device part (run_inference) replaced by a stand-in that returns a function of
+    exactly what it was handed."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import photoverse_amd.infer as infer_mod
+    from photoverse_amd.pipeline import PhotoVersePipeline
+    from types import SimpleNamespace
+
+    def fake_run_inference(example, *a, noise=None, seed=None, latent_size=64, **kw):
+        assert noise is not None and seed is not None
+        return noise * 3.0 + example["pixel_values_clip"].mean(dim=(1, 2, 3)).view(-1, 1, 1, 1)
+
+    infer_mod.run_inference = fake_run_inference
+    unet = SimpleNamespace(config=SimpleNamespace(in_channels=4))
+    pipe = PhotoVersePipeline(None, None, None, unet, None, None, None, None)
+    g = torch.Generator().manual_seed(11)
+    example = {"pixel_values_clip": torch.randn(6, 3, 8, 8, generator=g), "concept_placeholder_idx": torch.zeros(6, 1, dtype=torch.int64),
+               "text": ["x"] * 6}
+    out = pipe(example, shard=True, seed=123, latent_size=16)
+    ref_noise = torch.randn((6, 4, 16, 16), generator=torch.manual_seed(123))     # the seeded 1-GPU draw (infer.py:52-59)
+    expect = ref_noise * 3.0 + example["pixel_values_clip"].mean(dim=(1, 2, 3)).view(-1, 1, 1, 1)
+    q.put((rank, bool(torch.equal(out, expect)), tuple(out.shape)))
+    dist.destroy_process_group()
+
+
+def test_sharded_pipeline_seeded_noise_equals_one_rank_draw_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, (6, 4, 16, 16)), (1, True, (6, 4, 16, 16))]
+
+
+def test_bench_self_launches_n_ranks_dry():
+    """`python bench.py --gpus N` spawns N ranks itself (no torchrun): distinct ranks / processes, n_gpus == world size;
+    with no GPUs it fails cleanly; a mismatching external launcher is refused."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-launch"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and sorted(line["ranks"]) == [0, 1, 2] and sorted(line["local_ranks"]) == [0, 1, 2] and line["distinct_pids"] == 3
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"], capture_output=True, text=True,
+                           env=env, timeout=300)
+        assert r.returncode != 0 and "only 0 HIP device" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True,
+                       env=dict(env, RANK="0", WORLD_SIZE="1"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
 def test_batch_shard_and_single_gather_gloo_world2():
@@ -294,6 +441,37 @@ def test_ddim_table_reproduces_stepwise_ddim():
             ca, cb, cx, c0, _ = tab[i, :5]
             x = cx * x + c0 * (ca * x + cb * eps)
             assert ((x - xr).norm() / xr.norm()).item() < 1e-6
+
+
+def test_image_preprocessing_matches_installed_clip_image_processor():
+    """generate.py:57-58 geometry: CLIP pixels = short side 224 (bicubic) + centre crop, NOT a squash; VAE pixels = short side
+    512 + centre crop in [-1, 1].  Pinned against the installed transformers CLIPImageProcessor (PIL backend)."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    from photoverse_amd.image_utils import clip_image_processor, denormalize, preprocess_image, to_pil
+    rng = np.random.default_rng(0)
+    for (h, w) in ((300, 200), (250, 640), (224, 224), (1024, 768)):
+        img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        exp = CLIPImageProcessor()(images=img, return_tensors="pt").pixel_values[0]
+        got = clip_image_processor(img)
+        assert got.shape == (3, 224, 224) and torch.allclose(got, exp, atol=1e-6), (h, w)
+        # the 512 path is the same pipeline with mean = std = 0.5 (torchvision Resize + CenterCrop + Normalize(0.5, 0.5));
+        # sizes chosen so that torchvision's round() and transformers' floor() crop offsets agree
+        proc = CLIPImageProcessor(size={"shortest_edge": 128}, crop_size={"height": 128, "width": 128}, image_mean=[0.5] * 3, image_std=[0.5] * 3)
+        exp2 = proc(images=img, return_tensors="pt").pixel_values[0]
+        got2 = preprocess_image(img, size=128, interpolation="bicubic")
+        assert got2.shape == (3, 128, 128) and got2.min() >= -1 and got2.max() <= 1
+        nw, nh = (128, int(128 * h / w)) if w < h else (int(128 * w / h), 128)
+        if (nh - 128) % 2 == 0 and (nw - 128) % 2 == 0:
+            assert torch.allclose(got2, exp2, atol=1e-6), (h, w)
+    # a 2:1 image: the centre crop keeps the middle, a squash would keep the borders
+    arr = np.zeros((100, 200, 3), dtype=np.uint8)
+    arr[:, :50] = 255
+    out = preprocess_image(Image.fromarray(arr), size=64)
+    assert out.max() < -0.8                                   # the white left quarter is cropped away (bicubic ringing only)
+    back = to_pil(denormalize(torch.full((3, 4, 4), 0.0)))
+    assert back.size == (4, 4) and np.asarray(back)[0, 0, 0] == 128
 
 
 def test_generate_prepare_example_from_image_file(tmp_path):

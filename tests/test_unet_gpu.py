@@ -28,8 +28,8 @@ def tiny_pair():
     return ref, hip
 
 
-# fp16-storage tolerance for ONE UNet forward vs the fp32 oracle (measured ~2e-3 on random-init weights)
-TOL_FWD = 5e-3
+# fp16-storage tolerance for ONE UNet forward vs the fp32 oracle (measured 1.2e-3 .. 2e-3 on random-init weights)
+TOL_FWD = 2.5e-3
 
 
 @pytest.mark.parametrize("B,hw,P,t", [(1, 16, 1, 500), (2, 16, 5, 981), (2, 32, 1, 20)])
@@ -96,8 +96,8 @@ def test_cpu_tensor_is_refused(tiny_pair):
         hip(torch.randn(1, 4, 16, 16), torch.tensor(1), encoder_hidden_states=(torch.randn(1, 77, 768), torch.randn(1, 1, 768)))
 
 
-# fp16-storage tolerance for a short denoise loop on the tiny config (latents, rel-L2 vs fp32 oracle)
-TOL_LOOP = 5e-3
+# fp16-storage tolerance for a short denoise loop on the tiny config (latents, rel-L2 vs fp32 oracle; measured <= 2e-3)
+TOL_LOOP = 2.5e-3
 
 
 @pytest.mark.parametrize("steps,P", [(3, 1), (4, 5)])
@@ -124,6 +124,12 @@ def test_denoise_loop_matches_oracle_and_graph_equals_eager(tiny_pair, steps, P)
     # replay again from the same noise: deterministic
     loop.reset(noise)
     assert torch.equal(loop.run().cpu(), outs[2])
+    # a step past the end of the schedule raises on the host (the device tables have exactly `steps` rows) until reset()
+    with pytest.raises(RuntimeError, match="reset"):
+        loop.step()
+    loop.reset(noise)
+    loop.step()
+    assert loop.state[0].item() == 1 and loop.state[1].item() == steps
 
 
 def test_full_sd15_unet_forward_matches_oracle():
@@ -200,3 +206,158 @@ def test_bench_contract_line():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.05 < rf["frac"] < 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# headline-config coverage that needs no oracle time: batch invariance at bs=16, full model size (BASELINE configs[1])
+def test_bs16_full_size_samples_match_bs1_runs():
+    """configs[1] beyond `finite`: 2 graph-replayed CFG steps at the headline shape (full SD-v1.5 size, bs=16, 64x64 latents,
+    guidance 7.5); sample i of the batch must equal the bs=1 run of the same sample.  Samples never interact inside the
+    UNet, so the only legitimate difference is the fp32 summation order of the split-K layers (the 16x16 / 8x8 levels split K
+    at bs=1 and not at bs=16), i.e. a few fp16 ulps on some activations."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from photoverse_amd.pipeline import DenoiseLoop
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    hip = UNet2DConditionModel()
+    set_visual_cross_attention_adapter(hip, (5,))
+    hip.to("cuda")
+    g = torch.Generator().manual_seed(77)
+    B, P, T = 16, 1, 2
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, 64, 64, generator=g)
+    big = DenoiseLoop(hip, B, 64, P, T, 7.5)
+    big.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+    big.reset(noise)
+    full = big.run().clone().cpu()
+    assert torch.isfinite(full).all()
+    del big
+    one = DenoiseLoop(hip, 1, 64, P, T, 7.5)
+    worst = 0.0
+    for i in (0, 7, 15):
+        one.set_conditioning(tuple(t[i:i + 1].cuda() for t in cond), tuple(t[i:i + 1].cuda() for t in uncond))
+        one.reset(noise[i:i + 1])
+        single = one.run().clone().cpu()
+        worst = max(worst, rel_l2(full[i:i + 1], single))
+    print(f"bs=16 sample vs its bs=1 run, 2 steps, full size: worst rel-L2 = {worst:.3e}")
+    assert worst < 3e-4
+    del one, hip
+
+
+def test_cfg4_per_rank_shape_forward_matches_oracle():
+    """BASELINE configs[4] per-rank shape at the full model size: B=4, 96x96 latents (768x768), P=6 image tokens
+    (len(encoder_layers_idx)+1): N=9216 self-attention, the 12x12 level whose 144 pixels are not a multiple of
+    64 (GroupNorm statistics fall back to the stats pass), 6 image-token K/V rows.  The oracle runs samples 0 and 3 at B=1."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.unet_ref import UNet2DConditionModelRef, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    ref = UNet2DConditionModelRef().eval()
+    set_visual_cross_attention_adapter_ref(ref, (17,))
+    hip = UNet2DConditionModel()
+    set_visual_cross_attention_adapter(hip, (17,))
+    hip.load_state_dict(ref.state_dict())
+    hip.to("cuda")
+    g = torch.Generator().manual_seed(44)
+    B, P = 4, 6
+    x, text, ip = torch.randn(B, 4, 96, 96, generator=g), torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g)
+    with torch.no_grad():
+        got = hip(x.cuda(), torch.tensor(321), encoder_hidden_states=(text.cuda(), ip.cuda())).sample.cpu()
+        for i in (0, 3):
+            exp = ref(x[i:i + 1], torch.tensor(321), encoder_hidden_states=(text[i:i + 1], ip[i:i + 1])).sample
+            err = rel_l2(got[i:i + 1], exp)
+            print(f"cfg4 shape (B=4, 96x96, P=6) sample {i}: rel-L2 vs fp32 oracle = {err:.3e}")
+            assert err < TOL_FWD
+    del hip, ref
+
+
+def test_full_size_ten_step_loop_within_north_star_tolerance():
+    """The north_star number: latents within 1e-3 rel-L2 of the fp32 reference path.  FULL model size (859.5 M parameters), B=1,
+    64x64 latents, guidance 7.5, 10 DPM-Solver++ steps = 20 UNet forwards on each side (the error saturates from ~step 10 on:
+    3.5e-4 after step 1, 8.4e-4 after step 10, 9.0e-4 after step 50, profiles/r01_full_parity.txt).  ~2 min of host time."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.infer_ref import denoise_ref, draw_noise_ref
+    from oracle.unet_ref import UNet2DConditionModelRef, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.pipeline import DenoiseLoop
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    ref = UNet2DConditionModelRef().eval()
+    set_visual_cross_attention_adapter_ref(ref, (5,))
+    hip = UNet2DConditionModel()
+    set_visual_cross_attention_adapter(hip, (5,))
+    hip.load_state_dict(ref.state_dict())
+    hip.to("cuda")
+    g = torch.Generator().manual_seed(31)
+    B, P, T = 1, 1, 10
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = draw_noise_ref(B, 4, 64, seed=6)
+    loop = DenoiseLoop(hip, B, 64, P, T, 7.5)
+    loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+    loop.reset(noise)
+    got = loop.run().clone().cpu()
+    exp = denoise_ref(ref, noise, cond, uncond, guidance_scale=7.5, timesteps=T)
+    err = rel_l2(got, exp)
+    print(f"full-size 10-step latents rel-L2 vs fp32 oracle: {err:.3e}")
+    assert err < 1e-3
+    del hip, ref, loop
+
+
+def _two_rank_loop_worker(rank, world, port, q):
+    """One rank of the batch-sharded path on the REAL HIP loop: shard of the CPU-drawn global batch -> DenoiseLoop -> the single
+    gather (gloo here: both test ranks share the box's one GPU, where RCCL refuses duplicate devices)."""
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.unet_ref import TINY_CONFIG
+    from photoverse_amd.pipeline import DenoiseLoop, gather_latents, shard_batch
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    hip = UNet2DConditionModel(**TINY_CONFIG)
+    set_visual_cross_attention_adapter(hip, (5,))
+    hip.to("cuda:0")
+    g = torch.Generator().manual_seed(55)
+    GB, P, T = 4, 1, 3
+    cond = (torch.randn(GB, 77, 768, generator=g), torch.randn(GB, P, 768, generator=g))
+    uncond = (torch.randn(GB, 77, 768, generator=g), torch.randn(GB, P, 768, generator=g))
+    noise = torch.randn(GB, 4, 16, 16, generator=torch.manual_seed(9))        # global draw, infer.py:52-59 semantics
+    sl = shard_batch(GB, rank, world)
+    loop = DenoiseLoop(hip, GB // world, 16, P, T, 7.5)
+    loop.set_conditioning(tuple(t[sl].cuda() for t in cond), tuple(t[sl].cuda() for t in uncond))
+    loop.reset(noise[sl])
+    full = gather_latents(loop.run(), world, force=True).cpu()
+    err = None
+    if rank == 0:       # the 1-rank run of the whole batch
+        one = DenoiseLoop(hip, GB, 16, P, T, 7.5)
+        one.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        one.reset(noise)
+        ref = one.run().cpu()
+        err = ((full.double() - ref.double()).norm() / ref.double().norm()).item()
+    q.put((rank, tuple(full.shape), err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_loop_equals_one_rank_run():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_two_rank_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+    assert [r[:2] for r in res] == [(0, (4, 4, 16, 16)), (1, (4, 4, 16, 16))]
+    print(f"2-rank sharded loop vs 1-rank run: rel-L2 = {res[0][2]:.3e}")
+    assert res[0][2] < 3e-4          # same kernels; only the split-K summation order differs with the per-rank batch
