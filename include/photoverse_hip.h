@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 3
+#define PV_ABI_VERSION 4
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -166,9 +166,6 @@ int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, i
  * t taken from timesteps[state ? *state : 0 ... ] : rows>1 => per-row timesteps[row] */
 int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t rows, int32_t dim,
                           void* out, void* stream);
-/* conv_in: NCHW fp32 latents (B,cin,H,W) -> NHWC fp16 (B,H,W,cout), 3x3 pad 1; w fp32 [cout][cin][3][3] */
-int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin,
-               int32_t h, int32_t wd, int32_t cout, void* stream);
 /* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin]; cout 4 (UNet) or 3 (VAE);
  * cin in {64, 128, 256, 320} */
 int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin,

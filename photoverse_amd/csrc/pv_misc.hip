@@ -32,54 +32,6 @@ __global__ void timestep_embedding_kernel(const float* timesteps, const int32_t*
     out[idx] = (half_t)(i < half ? cosf(a) : sinf(a));
 }
 
-// conv_in: NCHW fp32 -> NHWC fp16, 3x3 pad 1.  One thread = one pixel x 8 output channels.
-__global__ void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                               half_t* __restrict__ out, int batch, int cin, int h, int wd, int cout) {
-    extern __shared__ float sw[];  // [cin*9][cout]
-    const int ktot = cin * 9;
-    for (int i = threadIdx.x; i < ktot * cout; i += blockDim.x) {
-        const int co = i / ktot, k = i - co * ktot;  // w is [cout][cin][3][3]
-        sw[k * cout + co] = w[i];
-    }
-    __syncthreads();
-    const int nchunk = cout >> 3;
-    const long total = (long)batch * h * wd * nchunk;
-    // grid-stride: each workgroup stages the weights in LDS once and walks many (pixel, 8-channel chunk) items
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int chunk = (int)(idx % nchunk);
-        const long pix = idx / nchunk;
-        const int b = (int)(pix / (h * wd));
-        const int rem = (int)(pix - (long)b * h * wd);
-        const int y = rem / wd, xx = rem - y * wd;
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[chunk * 8 + j] : 0.f;
-        for (int ci = 0; ci < cin; ++ci) {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = y + ky - 1;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = xx + kx - 1;
-                    if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
-                    const float v = x[(((long)b * cin + ci) * h + iy) * wd + ix];
-                    const float4_t w0 = *reinterpret_cast<const float4_t*>(sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8);
-                    const float4_t w1 = *reinterpret_cast<const float4_t*>(sw + (ci * 9 + ky * 3 + kx) * cout + chunk * 8 + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[j] += v * w0[j];
-                        acc[j + 4] += v * w1[j];
-                    }
-                }
-            }
-        }
-        half8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-        *reinterpret_cast<half8_t*>(out + pix * cout + chunk * 8) = o;
-    }
-}
-
 // conv_out: NHWC fp16 -> NCHW fp32, 3x3 pad 1, cout <= 8 (UNet 320 -> 4, VAE 128 -> 3).  Far too few output channels for the
 // MFMA tile: VALU kernel.  8 threads per output pixel, each owning the 16-byte channel chunks {sub, sub+8, ...} of all 9
 // taps (one pixel's 8 threads read 128 contiguous bytes; neighbouring pixels re-read the same rows out of L1); the whole
@@ -446,16 +398,6 @@ extern "C" int pv_timestep_embedding(const float* timesteps, const int32_t* stat
     const int n = rows * dim;
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timesteps, state, rows,
                        dim, reinterpret_cast<half_t*>(out));
-    return PV_CHECK_LAUNCH();
-}
-
-extern "C" int pv_conv_in(const float* x, const float* w, const float* bias, void* out, int32_t batch, int32_t cin, int32_t h,
-                          int32_t wd, int32_t cout, void* stream) {
-    if (batch <= 0 || cin <= 0 || (cout % 8) || cin * 9 * cout * 4 > 64 * 1024 || !x || !w || !out) return (int)hipErrorInvalidValue;
-    const long total = (long)batch * h * wd * (cout / 8);
-    const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), cin * 9 * cout * sizeof(float),
-                       (hipStream_t)stream, x, w, bias, reinterpret_cast<half_t*>(out), batch, cin, h, wd, cout);
     return PV_CHECK_LAUNCH();
 }
 

@@ -157,8 +157,8 @@ class Recorder:
                        _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
-        # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, WM, CONV, GEGLU, CS>
-        name = (f"gemm_conv_kernel<{nf}, 2, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
+        # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS>
+        name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
                 f"{'true' if cs is not None else 'false'}>")
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
@@ -226,12 +226,6 @@ class Recorder:
         out = self.empty((rows, dim), torch.float16)
         self.keep.extend(t for t in (timesteps, state) if t is not None)
         self._add(self.lib.pv_timestep_embedding, _ptr(timesteps), _ptr(state), rows, dim, _ptr(out))
-        return out
-
-    def conv_in(self, x, w, bias, *, batch, cin, h, wd, cout):
-        out = self.empty((batch * h * wd, cout), torch.float16)
-        self.keep.extend((x, w, bias))
-        self._add(self.lib.pv_conv_in, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, h, wd, cout)
         return out
 
     def softmax_rows(self, x, *, scale):

@@ -28,10 +28,10 @@ def h16(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).half()
 
 
-# the last three shapes give >= 256 tiles of 256 rows and take the 8-wave / 3-stage instantiation (incl. an M tail)
+# small, ragged (M tail) and large-M shapes; K from one K-step to 64 of them
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 640, 768), (16, 1280, 1280), (130, 128, 64), (128, 1024, 4096),
                                    (16384, 640, 640), (32700, 320, 64), (8192, 1024, 128),
-                                   (65536, 320, 128), (33000, 640, 192), (32768, 512, 64)])   # >= 512 tiles of 256 rows: big-tile kernel
+                                   (65536, 320, 128), (33000, 640, 192), (32768, 512, 64)])
 def test_gemm_bias_residual_act(rec_cls, M, N, K):
     from photoverse_amd import ops
     a, w, res = h16(M, K, seed=1), h16(N, K, scale=K ** -0.5, seed=2), h16(M, N, seed=3)
@@ -106,7 +106,7 @@ def test_gemm_geglu_fused_matches_unfused(rec_cls):
                                                      (320, 640, 8, 1, 1, 2), (64, 128, 5, 1, 0, 2),
                                                      (64, 320, 64, 1, 0, 8), (128, 128, 32, 1, 1, 4),
                                                      (1280, 1280, 8, 1, 0, 4), (640, 1280, 8, 2, 0, 2),   # split-K heuristic
-                                                     (64, 320, 64, 1, 0, 16), (128, 256, 64, 1, 0, 8)])   # big-tile kernel
+                                                     (64, 320, 64, 1, 0, 16), (128, 256, 64, 1, 0, 8)])   # M = 65536 / 32768
 def test_conv3x3(rec_cls, cin, cout, h, stride, ups, B):
     x = h16(B, cin, h, h, seed=11)
     w = h16(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=12)
@@ -315,7 +315,11 @@ def test_conv_in_out_timestep(rec_cls):
     w = torch.randn(320, 4, 3, 3, generator=torch.Generator().manual_seed(31)) * 0.2
     b = torch.randn(320, generator=torch.Generator().manual_seed(32))
     rec = rec_cls("cuda")
-    y = rec.conv_in(x.cuda(), w.cuda(), b.cuda(), batch=B, cin=4, h=h, wd=h, cout=320)
+    # conv_in as the UNet plan runs it: im2col to K = 36 (zero padded to 64) + the MFMA GEMM
+    cols = rec.im2col3x3(x.cuda(), batch=B, cin=4, h=h, wd=h, kpad=64)
+    w_in = torch.zeros(320, 64, dtype=torch.float16)
+    w_in[:, :36] = w.reshape(320, 36).half()
+    y = rec.gemm(cols, w_in.cuda(), bias=b.cuda(), rows_per_image=h * h)
     xo = h16(B, 320, h, h, seed=33)
     wo = h16(4, 320, 3, 3, scale=0.02, seed=34)
     bo = torch.randn(4, generator=torch.Generator().manual_seed(35))
@@ -329,8 +333,8 @@ def test_conv_in_out_timestep(rec_cls):
     te = rec.timestep_embedding(ts.cuda(), None, 3, 320)
     rec.run()
     torch.cuda.synchronize()
-    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
-    assert rel_l2(y, ref) < 5e-4
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
+    assert rel_l2(y, ref) < 1e-3
     refo = F.conv2d(xo.float(), wo.float(), bo, padding=1)
     assert rel_l2(z, refo) < 1e-5
     assert rel_l2(zv, F.conv2d(xv.float(), wv.float(), None, padding=1)) < 1e-5

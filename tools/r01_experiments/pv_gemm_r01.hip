@@ -2,7 +2,7 @@
 //
 //   out[M][N] = epilogue( A[M][K] * W[N][K]^T )           fp16 in, fp32 accumulate
 //
-// Kernel (gemm_conv_kernel<NF, CONV, GEGLU, CS>): tile 128 (M) x BN (N) x 64 (K), BN = 160 (NF=5) or 128
+// Dispatched kernel (gemm_conv_kernel<NF, 2, CONV, GEGLU>): tile 128 (M) x BN (N) x 64 (K), BN = 160 (NF=5) or 128
 // (NF=4); 256 threads = 4 waves in a 2x2 grid, each wave owns 64 x (BN/2) outputs as 4 x NF fragments of
 // v_mfma_f32_16x16x32_f16; two workgroups per CU.  Operands are passed swapped (W as MFMA-A, activations as MFMA-B), so a
 // lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one row; fragment pairs are traded between lane rows
@@ -17,9 +17,25 @@
 // halves of the step, so the fragment reads of one half overlap the MFMAs of the other and the next stage's DMA is issued
 // behind a counted vmcnt.  Small-M layers split K over several workgroups (fp32 slabs reduced in fixed order).
 //
-// Larger tiles (256-row / one wave per SIMD, 256 x 160 x 32 with three stages) were built and measured in round 1 and lost
-// to this kernel on every UNet shape; that code and its timing ablations live in tools/r01_experiments/ (DESIGN.md section 4).
+// Also in this file, measured and NOT dispatched by default: the 256-row instantiation <NF, 4, ...>
+// (one wave per SIMD, AGPR accumulators, 3 stages) and gemm_big_kernel (32-deep stages; 256-row / 2 workgroups per CU or
+// 128-row / 3 per CU).
 #include "pv_common.h"
+
+#ifndef PV_ABLATE
+#define PV_ABLATE 0   // timing-only builds (wrong results), see tools/ablate.sh / tools/ablate2.sh
+#endif
+// 1 no MFMA | 2 no DMA | 3 DMA only | 4 A staged for 2 of 9 taps | 5 W staged every other step | 6 MFMA only | 7 LDS reads only
+#define PV_AB_NO_MFMA (PV_ABLATE == 1 || PV_ABLATE == 3 || PV_ABLATE == 7)
+#define PV_AB_NO_DMA (PV_ABLATE == 2 || PV_ABLATE == 6 || PV_ABLATE == 7)
+#define PV_AB_NO_READ (PV_ABLATE == 3 || PV_ABLATE == 6)
+#ifndef PV_BIG_TILES
+#define PV_BIG_TILES 0 // 1: dispatch the 256-row big-tile kernel for the 64x64-level 3x3 convs (measured +3 % there; off so that
+                       //    every 3x3 conv is ONE kernel in the profiles and the roofline accounting)
+#endif
+#ifndef PV_FORCE_WM
+#define PV_FORCE_WM 0 // 2 or 4: force the tile variant (experiments)
+#endif
 
 namespace {
 
@@ -31,16 +47,17 @@ struct pv_gemm_params_dev : pv_gemm_params {
     uint32_t a0_bytes, a1_bytes, w_bytes;
 };
 
-// 128-row tile, wave tile 64 x BN/2, 2 LDS stages, 2 workgroups / CU (two waves per SIMD)
-template <int NF>
+// WM=2 -> 128-row tile, wave tile  64 x BN/2, 2 LDS stages, 2 workgroups / CU (two waves per SIMD)
+// WM=4 -> 256-row tile, wave tile 128 x BN/2, 3 LDS stages, 1 workgroup / CU (ONE wave per SIMD, up to 512 registers)
+template <int NF, int WM>
 struct TileCfg {
-    static constexpr int MI = 4;                   // 16-row M fragments per wave
+    static constexpr int MI = WM * 2;              // 16-row M fragments per wave: 4 (128-row tile) or 8 (256-row tile)
     static constexpr int BM = 2 * MI * 16;
     static constexpr int BN = NF * 32;
-    static constexpr int NWAVES = 4;               // 2 x 2 waves
+    static constexpr int NWAVES = 4;               // 2 x 2 waves; WM=4: one wave per SIMD with a 128 x (BN/2) register tile
     static constexpr int THREADS = NWAVES * 64;
     static constexpr int A_PER_WAVE = BM / 8 / NWAVES;   // 8-row LDS-DMA pieces of the activation tile per wave
-    static constexpr int STAGES = 2;
+    static constexpr int STAGES = WM == 4 ? 3 : 2;
     static constexpr int A_BYTES = BM * ROW_BYTES;
     static constexpr int B_BYTES = BN * ROW_BYTES;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -67,6 +84,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef PV_CLOCKPROBE   // diagnostic build: shader clock of the main loop = s_memtime ticks / s_memrealtime (100 MHz) ticks
+__device__ unsigned long long pv_clock_probe[4];
+#endif
 
 // all-reduce over the 16 lanes of a DPP row (row_ror:8,4,2,1)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -79,16 +99,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // CS: instantiation whose epilogue also produces the GroupNorm column statistics (pv_gemm_params.colstats).  Separate from the
 // plain kernel because the extra 40 accumulators cost the launches that do not want them 2-3 %.
-template <int NF, bool CONV, bool GEGLU, bool CS = false>
-__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
+template <int NF, int WM, bool CONV, bool GEGLU, bool CS = false>
+__global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int order) {
-    using Cfg = TileCfg<NF>;
+    using Cfg = TileCfg<NF, WM>;
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NWAVES;
     constexpr int MI = Cfg::MI;
     constexpr int AP = Cfg::A_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef PV_CLOCKPROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
     const int bid = (order & 2) ? (int)blockIdx.x : pv_xcd_remap((int)blockIdx.x, nblk);
@@ -177,6 +201,9 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
         const int sc2 = (first ? c : c - p.c0) * 2;   // scalar byte offset of the slab inside the source row
         const int ky = tap / 3, kx = tap - ky * 3;
         const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;   // fast path: centre pixel -> tap pixel
+#if PV_ABLATE == 4   // timing experiment: A staged for 2 of the 9 taps only (what a halo-reuse patch would move)
+        if (!CONV || tap == 0 || tap == 4)
+#endif
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             unsigned off;
@@ -193,6 +220,9 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * NW) * 8 * ROW_BYTES), 16, (int)off, 0, 0, 0);
         }
         const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+#if PV_ABLATE == 5   // timing experiment: W staged for every other K-step only
+        if (kt & 1)
+#endif
 #pragma unroll
         for (int i = 0; i < Cfg::B_PER_WAVE; ++i) {
             if (i < Cfg::B_PER_WAVE - 1 || b_full)
@@ -230,11 +260,18 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
         for (int ni = 0; ni < NF; ++ni) wb[ni] = lds_frag(sb, wn * (NF * 16) + ni * 16 + fr, ks * 4 + fq);
     };
     auto mma_half = [&](const half8_t (&xa)[MI], const half8_t (&wb)[NF]) {
+#if PV_AB_NO_MFMA   // timing experiment: LDS reads without the MFMAs
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xa[mi]));
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(wb[ni]));
+#else
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+#endif
     };
 
 #pragma unroll
@@ -252,12 +289,23 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
     asm volatile("" ::: "memory");
 
     half8_t xa0[MI], wb0[NF], xa1[MI], wb1[NF];
+#if PV_AB_NO_READ   // timing experiments without LDS reads: opaque, finite register contents
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { xa0[i] = half8_t{(half_t)lane}; xa1[i] = xa0[i]; asm volatile("" : "+v"(xa0[i]), "+v"(xa1[i])); }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { wb0[i] = half8_t{(half_t)wave}; wb1[i] = wb0[i]; asm volatile("" : "+v"(wb0[i]), "+v"(wb1[i])); }
+#else
     if (nk > 0) read_half(xa0, wb0, 0, 0);
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+#if !PV_AB_NO_READ
         read_half(xa1, wb1, kt, 1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
+#if PV_ABLATE != 3
         mma_half(xa0, wb0);
         __builtin_amdgcn_sched_barrier(0);
+#endif
         if (kt + 1 < nk) {
             // stage kt+1 landed: all younger issued stages (kt+2 .. kt+S-1) may stay in flight, if they were all issued
             if (S == 3 && kt + S - 1 < nk) {
@@ -266,17 +314,34 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
                 wait_vmcnt<0>();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer kt % S are retired
+#ifndef PV_NOBAR   // timing experiment only
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
+#if !PV_AB_NO_DMA
             if (kt + S < nk) stage(kt + S, kt % S);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if !PV_AB_NO_READ
             read_half(xa0, wb0, kt + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#if PV_ABLATE != 3
         mma_half(xa1, wb1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 
+#ifdef PV_CLOCKPROBE
+    {
+        const unsigned long long probe_t1 = __builtin_amdgcn_s_memtime(), probe_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {   // a workgroup from the middle of the launch
+            pv_clock_probe[0] = probe_t1 - probe_t0; pv_clock_probe[1] = probe_r1 - probe_r0;
+        }
+    }
+#endif
     // ---- epilogue ---------------------------------------------------------------------------
     if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
         float* slab = p.splitk_ws + (size_t)blockIdx.y * p.M * p.N;
@@ -342,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
             }
         }
         // optional GroupNorm column statistics of the tile being written (pv_gemm_params.colstats)
-        const bool want_cs = CS && p.colstats != nullptr && !p.out_f32;
+        const bool want_cs = CS && (WM == 2) && p.colstats != nullptr && !p.out_f32;
         float4_t cs[NF], cq[NF];
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) cs[ni] = cq[ni] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -422,6 +487,242 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
     }
 }
 
+// =================================================================================================================
+// Big-tile variant for the large-M layers: 256 x BN x 32 tile, 4 waves (2 x 2, wave tile 128 x BN/2: 8 x NF fragments,
+// accumulators in the AGPR half of the register file -> ONE wave per SIMD per workgroup), THREE LDS stages of 32-deep
+// K-steps (26.6 KB each at BN = 160) so that TWO workgroups still fit a CU: two independent workgroups per CU keep the
+// latency hiding of the 128-row kernel, while the tile's arithmetic intensity against the L2->LDS path rises from 71 to
+// 98 flop/B (that path, ~70 GB/s per CU, is what bounds the 128-row kernel: profiles/r01_ablate_gemm.txt).
+// Fragments are double-buffered in registers ACROSS K-steps: the ds_reads of step kt+1 are issued before the MFMAs of kt.
+// LDS rows are 64 B; bank-conflict swizzle: 16-B chunk ^= SWZ[(row >> 2) & 3], SWZ = {0,3,2,1} (conflict-free for the
+// 16-lane groups of ds_read_b128), applied on the per-lane DMA source offset and on the read.
+constexpr int BIG_BK = 32;
+constexpr int BIG_ROWB = BIG_BK * 2;   // 64 B per LDS row
+
+__device__ __forceinline__ int big_swz(int g) { return (4 - g) & 3; }   // {0,3,2,1}
+
+__device__ __forceinline__ half8_t big_frag(const char* base, int row, int q) {
+    return *reinterpret_cast<const half8_t*>(base + row * BIG_ROWB + ((q ^ big_swz((row >> 2) & 3)) << 4));
+}
+
+// MI = M fragments per wave (8: 256-row tile, 2 workgroups / CU;  4: 128-row tile, 3 workgroups / CU), BIG_S = LDS stages
+template <int NF, int MI, int BIG_S, bool CONV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 8 ? 2 : 3, MI == 8 ? 2 : 3))) void gemm_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk, const int m_fast) {
+    constexpr int BN = NF * 32;
+    constexpr int BIG_BM = 2 * MI * 16;
+    constexpr int STAGE_BYTES = (BIG_BM + BN) * BIG_ROWB;
+    constexpr int A_BYTES = BIG_BM * BIG_ROWB;
+    constexpr int AP = BIG_BM / 16 / 4;                 // 16-row DMA pieces of the activation tile per wave (4)
+    constexpr int B_PIECES = BN / 16;                   // 10 (NF=5) or 8 (NF=4)
+    constexpr int BP = (B_PIECES + 3) / 4;              // max pieces per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = pv_lane_id();
+    const int wave = pv_wave_id();
+    const int bid = pv_xcd_remap((int)blockIdx.x, nblk);
+    const int tiles_m = nblk / tiles_n;
+    const int tile_m = m_fast ? bid % tiles_m : bid / tiles_n;
+    const int tile_n = m_fast ? bid / tiles_m : bid % tiles_n;
+    const int m0 = tile_m * BIG_BM;
+    const int n0 = tile_n * BN;
+    const int cin = p.c0 + p.c1;
+    const int K = p.taps * cin;
+    const int nk = K / BIG_BK;
+
+    const int lrow = lane >> 2;                                  // row inside the 16-row piece
+    const int lane_cc2 = ((lane & 3) ^ big_swz(lane >> 4)) * 16; // swizzled source chunk, bytes inside the 64-B slab
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int hw_out = p.hout * p.wout;
+
+    unsigned a_off0[AP], a_off1[AP], a_mask[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + (wave + i * 4) * 16 + lrow;
+        const bool ok = m < p.M;
+        if (CONV) {   // stride 1, no upsample (the launcher only routes those here)
+            const int b = m / hw_out;
+            const int rem = m - b * hw_out;
+            const int y = rem / p.wout, x = rem - y * p.wout;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                if (ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win) mask |= 1u << t;
+            }
+            a_mask[i] = mask;
+            const unsigned pix = (unsigned)((b * p.hin + y) * p.win + x);
+            a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
+            a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
+        } else {
+            a_mask[i] = 1u;
+            a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
+            a_off1[i] = ok ? (unsigned)m * (unsigned)(p.lda1 * 2) + lane_cc2 : OOB;
+        }
+    }
+    unsigned w_off[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + min(wave + i * 4, B_PIECES - 1) * 16 + lrow;
+        w_off[i] = (unsigned)n * (unsigned)(K * 2) + lane_cc2;
+    }
+    const bool b_full = (B_PIECES % 4 == 0) || (wave + (BP - 1) * 4 < B_PIECES);
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+        // K order: 64-channel slab major, filter tap, then the two 32-channel halves of the slab
+        const int half = kt & 1;
+        const int kt2 = kt >> 1;
+        const int slab = CONV ? kt2 / 9 : kt2;
+        const int tap = CONV ? kt2 - slab * 9 : 0;
+        const int c = slab * 64 + half * 32;
+        const bool first = c < p.c0;
+        const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
+        const int ld2 = (first ? p.lda0 : p.lda1) * 2;
+        const int sc2 = (first ? c : c - p.c0) * 2;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            unsigned off;
+            if (!CONV) off = (first ? a_off0[i] : a_off1[i]) + (unsigned)sc2;
+            else off = ((a_mask[i] >> tap) & 1u) ? (first ? a_off0[i] : a_off1[i]) + (unsigned)tap_delta : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * 4) * 16 * BIG_ROWB), 16, (int)off, 0, 0, 0);
+        }
+        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            if (i < BP - 1 || b_full)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + i * 4) * 16 * BIG_ROWB), 16, (int)(w_off[i] + wk2), 0, 0, 0);
+        }
+    };
+
+    float4_t acc[NF][MI];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // One K-step (32 deep) with ONE fragment register set (two workgroups per CU need <= 256 registers per lane):
+    //   wait stage kt landed, barrier, refill the buffer of step kt-1 with stage kt+S-1,
+    //   read W[NF] + A[0..3], issue the reads of A[4..7], MFMA W x A[0..3]  (covers those reads), MFMA W x A[4..7]
+    half8_t xa[MI], wb[NF];
+#pragma unroll
+    for (int s = 0; s < BIG_S - 1; ++s)
+        if (s < nk) stage(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + BIG_S - 2 < nk) {   // stage kt+1 (.. kt+S-2) was issued and may stay in flight
+            if (b_full) wait_vmcnt<(AP + BP) * (BIG_S - 2)>(); else wait_vmcnt<(AP + BP - 1) * (BIG_S - 2)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();   // stage kt visible to all; every wave has consumed (lgkmcnt) the fragments of step kt-1
+        asm volatile("" ::: "memory");
+        if (kt + BIG_S - 1 < nk) stage(kt + BIG_S - 1, (kt + BIG_S - 1) % BIG_S);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sa = smem + (kt % BIG_S) * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) wb[ni] = big_frag(sb, wn * (NF * 16) + ni * 16 + fr, fq);
+#pragma unroll
+        for (int mi = 0; mi < MI / 2; ++mi) xa[mi] = big_frag(sa, wm * (MI * 16) + mi * 16 + fr, fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = MI / 2; mi < MI; ++mi) xa[mi] = big_frag(sa, wm * (MI * 16) + mi * 16 + fr, fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI / 2; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = MI / 2; mi < MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (bias, time-embedding row, activation, residual; loads batched ahead of the stores) ----
+    const int nbase = n0 + wn * (NF * 16) + fq * 4;
+    float4_t bias_v[NF];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+        bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mh = 0; mh < MI / 4; ++mh) {       // groups of 4 M-fragments: bounds the registers of the batched residual
+        half4_t res[NF][4];
+        if (p.residual) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = min(m0 + wm * (MI * 16) + (mh * 4 + mi) * 16 + fr, p.M - 1);
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    res[ni][mi] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + nbase + ni * 16);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * (MI * 16) + (mh * 4 + mi) * 16 + fr;
+            if (m >= p.M) continue;
+            const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) {
+                float4_t v = acc[ni][mh * 4 + mi] + bias_v[ni];
+                if (radd) v += *reinterpret_cast<const float4_t*>(radd + ni * 16);
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[ni][mi][r];
+                }
+                const int n = nbase + ni * 16;
+                if (p.out_f32) {
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                    *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NF, int MI, int BIG_S, bool CONV>
+int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
+    constexpr int BN = NF * 32;
+    constexpr int BIG_BM = 2 * MI * 16;
+    constexpr int SMEM = BIG_S * (BIG_BM + BN) * BIG_ROWB;
+    static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
+    auto kern = gemm_big_kernel<NF, MI, BIG_S, CONV>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    const size_t wbytes = (size_t)p.N * p.taps * (p.c0 + p.c1) * 2;
+    const int m_fast = (wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), SMEM, stream, p, tiles_n, nblk, m_fast);
+    return PV_CHECK_LAUNCH();
+}
+
 // sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue
 __global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int splits) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,14 +752,14 @@ __global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int split
     }
 }
 
-template <int NF, bool CONV, bool GEGLU, bool CS = false>
+template <int NF, int WM, bool CONV, bool GEGLU, bool CS = false>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
-    using Cfg = TileCfg<NF>;
+    using Cfg = TileCfg<NF, WM>;
     static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = gemm_conv_kernel<NF, CONV, GEGLU, CS>;
+    auto kern = gemm_conv_kernel<NF, WM, CONV, GEGLU, CS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::SMEM_BYTES);
@@ -481,17 +782,40 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     return PV_CHECK_LAUNCH();
 }
 
-// One tile shape (128 x BN x 64, two workgroups per CU) for every layer: larger tiles lost on every UNet shape (see the header).
+// Tile choice.  Measured on MI355X (profiles/r01_ablate_gemm.txt): the 128-row / 4-wave / 2-workgroups-per-CU variant
+// beats the 256-row / 8-wave / 3-stage one on every UNet shape (two independent workgroups de-synchronise and overlap
+// each other's DMA waits; eight lock-stepped waves do not), so the 256-row instantiation is kept for experiments only.
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
     if constexpr (!GEGLU) {
-        if (p.colstats) return launch<NF, CONV, false, true>(p, stream);
+        if (p.colstats) return launch<NF, 2, CONV, false, true>(p, stream);
     }
-    return launch<NF, CONV, GEGLU>(p, stream);
+    if (PV_FORCE_WM == 4) return launch<NF, 4, CONV, GEGLU>(p, stream);
+#if PV_FORCE_WM != 2
+    if constexpr (!GEGLU) {
+        // big tile when it still gives every CU two workgroups; convs: stride 1 / no upsample only
+        const long tiles256 = (long)((p.M + 255) / 256) * (p.N / (NF * 32));
+        const bool plain_conv = !CONV || (p.stride == 1 && !p.upsample);
+        // measured (profiles/r01_kbench_c.txt): ~3 % faster on the 64x64-level 3x3 convs, not on the short-K Linear layers
+        if (PV_BIG_TILES == 1 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 3, CONV>(p, stream);
+        if (PV_BIG_TILES == 4 && CONV && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);
+        if (PV_BIG_TILES == 6 && CONV && tiles256 >= 256 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);   // + one-workgroup-per-CU launches
+        if (PV_BIG_TILES == 5 && tiles256 >= 512 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 8, 2, CONV>(p, stream);   // + the Linear layers
+        // experiment: 128-row tile with 32-deep stages -> three workgroups per CU
+        if (PV_BIG_TILES == 2 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 2, CONV>(p, stream);
+        if (PV_BIG_TILES == 3 && plain_conv && !(p.splitk > 1 && p.splitk_ws)) return launch_big<NF, 4, 3, CONV>(p, stream);
+    }
+#endif
+    return launch<NF, 2, CONV, GEGLU>(p, stream);
 }
 
 }  // namespace
 
+#ifdef PV_CLOCKPROBE
+extern "C" int pv_debug_clock_probe(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pv_clock_probe), 2 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     pv_gemm_params_dev p;
