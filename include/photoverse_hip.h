@@ -153,6 +153,38 @@ typedef struct pv_xattn_params {
 } pv_xattn_params;
 int pv_cross_attention(const pv_xattn_params* p, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole attn2 branch of a BasicTransformerBlock as ONE launch (C = heads*d = 320, d = 40):
+ *   out = hs + to_out( w_text*softmax(q Kt^T/sqrt(d)) Vt + w_ip*softmax(q Kip^T/sqrt(d)) Vip ) + bias_o,
+ *   q = to_q(LayerNorm(hs))
+ * = BasicTransformerBlock.norm2 [EXT diffusers] -> PhotoVerseAttnProcessor2_0.__call__
+ * (attention_processor.py:297 to_q, :307-322 text SDPA, :392-420 image-token SDPA + fusion rule,
+ * :423 to_out[0]) -> the block's residual add.  Replaces pv_layernorm + pv_gemm_conv +
+ * pv_cross_attention + pv_gemm_conv.  nq % 128 == 0.
+ *
+ * pv_xattn_pack_kv (once per conditioning) turns the projected text / image-token K,V rows into
+ * the kernel's K / V images (kimg: batch*heads*96*64 halfs, vimg: batch*(C/80)*96*80 halfs) and
+ * emits to_v_ip_norm (:397).  wo is to_out[0].weight with its COLUMNS reordered: column slot s of
+ * the packed matrix holds natural column pv_xattn_fused_wo_slot(s).
+ */
+typedef struct pv_xattn_fused_params {
+    const void* hs; int32_t ld_hs;             /* fp16 [batch*nq][C]: block input (pre-norm2) = residual */
+    const float* ln_gamma; const float* ln_beta; float ln_eps;   /* norm2; ln_gamma NULL: hs is used un-normalised */
+    const void* wq;                            /* fp16 [C][C] to_q.weight */
+    const void* wo;                            /* fp16 [C][C] to_out[0].weight, columns in slot order */
+    const float* bias_o;                       /* fp32 [C] or NULL */
+    const void* kimg; const void* vimg;        /* from pv_xattn_pack_kv */
+    void* out; int32_t ld_out;                 /* fp16 [batch*nq][C] */
+    int32_t batch, nq, heads, d, nt, nip;
+    float w_text, w_ip;                        /* branch weights: (1,1) no_grad; (2,0) / (0,2) / (1,1) grad mode */
+    const float* fusion;                       /* optional DEVICE pair overriding (w_text, w_ip): graph-safe grad-mode fusion */
+} pv_xattn_fused_params;
+int pv_cross_attention_fused(const pv_xattn_fused_params* p, void* stream);
+int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt, const void* kip, const void* vip,
+                     int32_t ldkip, int32_t ldvip, void* kimg, void* vimg, float* vnorm, int32_t batch,
+                     int32_t heads, int32_t d, int32_t nt, int32_t nip, void* stream);
+int pv_xattn_fused_wo_slot(int32_t slot);
+
 /* GEGLU gate (diffusers GEGLU, exact-erf GELU): out[m][j] = x[m][j] * gelu(x[m][n+j]) */
 int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, int32_t n, void* stream);
 

@@ -38,13 +38,16 @@ def conditioning_ref(example, image_encoder, text_encoder, text_adapter, image_a
 
 
 @torch.no_grad()
-def denoise_ref(unet, noise, cond, uncond, guidance_scale=1.0, timesteps=100, collect=None):
+def denoise_ref(unet, noise, cond, uncond, guidance_scale=1.0, timesteps=100, collect=None, max_steps=None):
     """``infer.py:39-40,70,98-119``: two UNet forwards per step (uncond, then
-    cond, each at batch B), CFG combine, ``scheduler.step``."""
+    cond, each at batch B), CFG combine, ``scheduler.step``.  ``max_steps`` (test
+    aid): stop after that many steps of the ``timesteps``-step schedule."""
     sch = DPMSolverMultistepRef()
     sch.set_timesteps(timesteps)
     latents = noise * sch.init_noise_sigma
-    for t in sch.timesteps:
+    for i, t in enumerate(sch.timesteps):
+        if max_steps is not None and i >= max_steps:
+            break
         x = sch.scale_model_input(latents, t)
         eps_u = unet(x, t, encoder_hidden_states=uncond).sample
         eps_c = unet(x, t, encoder_hidden_states=cond).sample

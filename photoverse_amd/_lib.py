@@ -47,6 +47,13 @@ class XAttnParams(C.Structure):
                 ("d", c_int), ("w_text", c_float), ("w_ip", c_float)]
 
 
+class XAttnFusedParams(C.Structure):
+    _fields_ = [("hs", c_void_p), ("ld_hs", c_int), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+                ("wq", c_void_p), ("wo", c_void_p), ("bias_o", c_void_p), ("kimg", c_void_p), ("vimg", c_void_p),
+                ("out", c_void_p), ("ld_out", c_int), ("batch", c_int), ("nq", c_int), ("heads", c_int), ("d", c_int),
+                ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
+
+
 #: every symbol ``include/photoverse_hip.h`` declares: name -> (restype, argtypes)
 SIGNATURES = {
     "pv_abi_version": (c_int, []),
@@ -58,6 +65,10 @@ SIGNATURES = {
     "pv_layernorm": (c_int, [C.POINTER(LayerNormParams), c_void_p]),
     "pv_attention": (c_int, [C.POINTER(AttnParams), c_void_p]),
     "pv_cross_attention": (c_int, [C.POINTER(XAttnParams), c_void_p]),
+    "pv_cross_attention_fused": (c_int, [C.POINTER(XAttnFusedParams), c_void_p]),
+    "pv_xattn_pack_kv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_xattn_fused_wo_slot": (c_int, [c_int]),
     "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AttnParams, GemmParams, GroupNormParams, LayerNormParams, XAttnParams
+from ._lib import AttnParams, GemmParams, GroupNormParams, LayerNormParams, XAttnFusedParams, XAttnParams
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
@@ -211,6 +211,41 @@ class Recorder:
                         _rows(vip)[0], _ptr(out), _rows(out)[0], _ptr(vnorm), batch, heads, nq, nt, nip, d, float(w_text), float(w_ip))
         self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm) if t is not None)
         self._add(self.lib.pv_cross_attention, p)
+        return out, p
+
+    # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual), C = 320 / d = 40 layers ----
+    @staticmethod
+    def xattn_fused_supported(C: int, heads: int, nq: int, nt: int, nip: int) -> bool:
+        return C == 320 and heads == 8 and nq % 128 == 0 and 0 < nt <= 80 and 0 < nip <= 16
+
+    def pack_wo_for_fused(self, wo: torch.Tensor) -> torch.Tensor:
+        """to_out[0].weight [C][C] with its columns in the fused kernel's context-slot order (pv_xattn_fused_wo_slot)."""
+        C = wo.shape[1]
+        idx = torch.tensor([self.lib.pv_xattn_fused_wo_slot(s) for s in range(C)], device=wo.device)
+        return wo[:, idx].contiguous()
+
+    def xattn_pack_kv(self, kt, vt, kip, vip, *, batch, heads, d, nt, nip, vnorm=None):
+        """K / V images of the fused kernel (once per conditioning) + to_v_ip_norm."""
+        C = heads * d
+        kimg = self.empty((batch * heads * 96 * 64,), torch.float16)
+        vimg = self.empty((batch * (C // 80) * 96 * 80,), torch.float16)
+        self.keep.extend(t for t in (kt, vt, kip, vip, vnorm) if t is not None)
+        self._add(self.lib.pv_xattn_pack_kv, _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0],
+                  _rows(vip)[0], _ptr(kimg), _ptr(vimg), _ptr(vnorm), batch, heads, d, nt, nip)
+        return kimg, vimg
+
+    def cross_attention_fused(self, hs, wq, wo_packed, bias_o, kimg, vimg, *, batch, nq, heads, d, nt, nip, ln_gamma=None, ln_beta=None,
+                              ln_eps=1e-5, w_text=1.0, w_ip=1.0, fusion=None, out=None):
+        C = heads * d
+        if out is None:
+            out = self.empty((batch * nq, C), torch.float16)
+        p = XAttnFusedParams(_ptr(hs), _rows(hs)[0], _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), _ptr(wq), _ptr(wo_packed), _ptr(bias_o),
+                             _ptr(kimg), _ptr(vimg), _ptr(out), _rows(out)[0], batch, nq, heads, d, nt, nip, float(w_text), float(w_ip),
+                             _ptr(fusion))
+        self.keep.extend(t for t in (hs, wq, wo_packed, bias_o, kimg, vimg, ln_gamma, ln_beta, fusion, out) if t is not None)
+        M = batch * nq
+        flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
+        self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320>", flops, 2.0 * (3 * M * C + 2 * C * C)))
         return out, p
 
     def geglu(self, x, out=None):

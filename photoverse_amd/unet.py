@@ -13,6 +13,7 @@ NHWC fp16 buffers built once per input shape; see DESIGN.md.  No CPU path exists
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, Optional, Tuple
 
@@ -164,6 +165,10 @@ class TimestepEmbedding(_Holder):
         self.linear_2 = nn.Linear(dim, dim)
 
 
+#: A/B switch: PV_NO_XFUSED=1 runs attn2 as the four separate launches (LayerNorm, to_q GEMM, dual-branch SDPA, to_out GEMM)
+USE_XFUSED = not os.environ.get("PV_NO_XFUSED")
+
+
 def _f16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float16).contiguous()
 
@@ -243,18 +248,28 @@ class UNetEngine:
         # --- attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435) ---
         a2 = blk.attn2
         proc = a2.processor
-        n2 = rec.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
-        q = rec.gemm(n2, _f16(a2.to_q.weight), rows_per_image=n)
         wkv = torch.cat([_f16(a2.to_k.weight), _f16(a2.to_v.weight)], 0).contiguous()
         kvt = self.rec_cond.gemm(self.text, wkv, rows_per_image=self.NT)
         wkvip = torch.cat([_f16(proc.to_k_ip[0].weight), _f16(proc.to_v_ip[0].weight)], 0).contiguous()
         kvip = self.rec_cond.gemm(self.ip, wkvip, rows_per_image=self.P)
         vnorm = rec.empty((b, heads, self.P), torch.float32)
         self.vnorms[name] = vnorm
-        xa, xp = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n, nt=self.NT,
-                                     nip=self.P, d=d, vnorm=vnorm)
-        self.xattn_params[name] = xp
-        hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
+        if USE_XFUSED and Recorder.xattn_fused_supported(C, heads, n, self.NT, self.P):
+            # ONE launch for norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual (pv_xfused.hip); the K / V images and
+            # to_v_ip_norm depend on the conditioning only (rec_cond)
+            kimg, vimg = self.rec_cond.xattn_pack_kv(kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, d=d, nt=self.NT,
+                                                     nip=self.P, vnorm=vnorm)
+            hs, xp = rec.cross_attention_fused(hs, _f16(a2.to_q.weight), rec.pack_wo_for_fused(_f16(a2.to_out[0].weight)),
+                                               _f32(a2.to_out[0].bias), kimg, vimg, batch=b, nq=n, heads=heads, d=d, nt=self.NT, nip=self.P,
+                                               ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias), ln_eps=blk.norm2.eps)
+            self.xattn_params[name] = xp
+        else:
+            n2 = rec.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
+            q = rec.gemm(n2, _f16(a2.to_q.weight), rows_per_image=n)
+            xa, xp = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n, nt=self.NT,
+                                         nip=self.P, d=d, vnorm=vnorm)
+            self.xattn_params[name] = xp
+            hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         # --- GEGLU feed-forward ---
         n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
         wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))

@@ -309,6 +309,53 @@ def test_cross_attention_dual_branch(rec_cls, d, n, p, wt, wi):
     torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
 
 
+@pytest.mark.parametrize("n,p,wt,wi,ln,fus", [(4096, 1, 1.0, 1.0, True, False), (128, 5, 1.0, 1.0, True, False), (256, 6, 2.0, 0.0, False, False),
+                                             (128, 16, 0.0, 2.0, True, True)])
+def test_cross_attention_fused_branch(rec_cls, n, p, wt, wi, ln, fus):
+    """pv_cross_attention_fused (norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual in ONE launch, C = 320 / d = 40)
+    vs an fp32 torch reference on the same fp16-rounded operands, and vs the four-launch path it replaces."""
+    from photoverse_amd import ops
+    B, H, d, NT = 2, 8, 40, 77
+    C = H * d
+    hs = h16(B * n, C, seed=40)
+    hs[:, ::7] += 1.5                                   # non-zero row means: LayerNorm has something to remove
+    kvt, kvip = h16(B * NT, 2 * C, seed=41), h16(B * p, 2 * C, seed=42)
+    wq, wo = h16(C, C, scale=C ** -0.5, seed=43), h16(C, C, scale=C ** -0.5, seed=44)
+    bo = torch.randn(C, generator=torch.Generator().manual_seed(45))
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(46))
+    beta = 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(47))
+    assert ops.Recorder.xattn_fused_supported(C, H, n, NT, p)
+    rec = rec_cls("cuda")
+    dhs, dt, di = hs.cuda(), kvt.cuda(), kvip.cuda()
+    vn = torch.zeros(B, H, p, device="cuda")
+    kimg, vimg = rec.xattn_pack_kv(dt[:, :C], dt[:, C:], di[:, :C], di[:, C:], batch=B, heads=H, d=d, nt=NT, nip=p, vnorm=vn)
+    fusion = torch.tensor([wt, wi], device="cuda") if fus else None
+    out, _ = rec.cross_attention_fused(dhs, wq.cuda(), rec.pack_wo_for_fused(wo.cuda()), bo.cuda(), kimg, vimg, batch=B, nq=n, heads=H, d=d,
+                                       nt=NT, nip=p, ln_gamma=gamma.cuda() if ln else None, ln_beta=beta.cuda() if ln else None,
+                                       w_text=-7.0 if fus else wt, w_ip=-7.0 if fus else wi, fusion=fusion)
+    # the four-launch path
+    n2 = rec.layernorm(dhs, gamma.cuda(), beta.cuda()) if ln else dhs
+    q = rec.gemm(n2, wq.cuda(), rows_per_image=n)
+    xa, _ = rec.cross_attention(q, dt[:, :C], dt[:, C:], di[:, :C], di[:, C:], batch=B, heads=H, nq=n, nt=NT, nip=p, d=d, w_text=wt, w_ip=wi)
+    unf = rec.gemm(xa, wo.cuda(), bias=bo.cuda(), residual=dhs, rows_per_image=n)
+    rec.run()
+    torch.cuda.synchronize()
+    x = hs.float()
+    xn = F.layer_norm(x, (C,), gamma, beta, 1e-5) if ln else x
+    hv = lambda t, m: t.float().view(B, m, H, d).transpose(1, 2)
+    qq = hv(xn @ wq.float().t(), n)
+    ot = F.scaled_dot_product_attention(qq, hv(kvt[:, :C], NT), hv(kvt[:, C:], NT))
+    vip = hv(kvip[:, C:], p)
+    oi = F.scaled_dot_product_attention(qq, hv(kvip[:, :C], p), vip)
+    ctx = (wt * ot + wi * oi).transpose(1, 2).reshape(B * n, C)
+    ref = ctx @ wo.float().t() + bo + x
+    assert torch.isfinite(out).all()
+    # the branch (out - hs) is what the kernel computes; the residual only adds an exactly representable term
+    assert rel_l2(out.float().cpu() - x, ref - x) < 3e-3 and rel_l2(out, ref) < 1e-3
+    assert rel_l2(unf, ref) < 1e-3 and rel_l2(out, unf) < 1e-3
+    torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
+
+
 def test_conv_in_out_timestep(rec_cls):
     B, h = 2, 16
     x = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(30))
