@@ -160,7 +160,7 @@ int pv_cross_attention(const pv_xattn_params* p, void* stream);
  * = BasicTransformerBlock.norm2 [EXT diffusers] -> PhotoVerseAttnProcessor2_0.__call__
  * (attention_processor.py:297 to_q, :307-322 text SDPA, :392-420 image-token SDPA + fusion rule,
  * :423 to_out[0]) -> the block's residual add.  Replaces pv_layernorm + pv_gemm_conv +
- * pv_cross_attention + pv_gemm_conv.  nq % 128 == 0.
+ * pv_cross_attention + pv_gemm_conv.  nq % 128 == 0, 64 < nt <= 80, nip <= 16.
  *
  * pv_xattn_pack_kv (once per conditioning) turns the projected text / image-token K,V rows into
  * the kernel's K / V images (kimg: batch*heads*96*64 halfs, vimg: batch*(C/80)*96*80 halfs) and
@@ -169,8 +169,10 @@ int pv_cross_attention(const pv_xattn_params* p, void* stream);
  */
 typedef struct pv_xattn_fused_params {
     const void* hs; int32_t ld_hs;             /* fp16 [batch*nq][C]: block input (pre-norm2) = residual */
-    const float* ln_gamma; const float* ln_beta; float ln_eps;   /* norm2; ln_gamma NULL: hs is used un-normalised */
-    const void* wq;                            /* fp16 [C][C] to_q.weight */
+    int32_t ln; float ln_eps;                  /* ln != 0: q = to_q((hs - mean) * rstd) - norm2 WITHOUT its affine part, which the */
+                                               /* caller folds into wq (gamma scales its columns) and q_bias (= to_q.weight . beta) */
+    const void* wq;                            /* fp16 [C][C] to_q.weight (x diag(gamma) when ln) */
+    const float* q_bias;                       /* fp32 [C] added to q, or NULL */
     const void* wo;                            /* fp16 [C][C] to_out[0].weight, columns in slot order */
     const float* bias_o;                       /* fp32 [C] or NULL */
     const void* kimg; const void* vimg;        /* from pv_xattn_pack_kv */

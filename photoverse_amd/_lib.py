@@ -48,8 +48,8 @@ class XAttnParams(C.Structure):
 
 
 class XAttnFusedParams(C.Structure):
-    _fields_ = [("hs", c_void_p), ("ld_hs", c_int), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
-                ("wq", c_void_p), ("wo", c_void_p), ("bias_o", c_void_p), ("kimg", c_void_p), ("vimg", c_void_p),
+    _fields_ = [("hs", c_void_p), ("ld_hs", c_int), ("ln", c_int), ("ln_eps", c_float),
+                ("wq", c_void_p), ("q_bias", c_void_p), ("wo", c_void_p), ("bias_o", c_void_p), ("kimg", c_void_p), ("vimg", c_void_p),
                 ("out", c_void_p), ("ld_out", c_int), ("batch", c_int), ("nq", c_int), ("heads", c_int), ("d", c_int),
                 ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
 

@@ -8,18 +8,20 @@
 // read of hs and one write of out.  Built for the C = 320 / d = 40 layers (64x64 and larger levels: 63 % of attn2's launches'
 // time at 512x512), where M = B*N is large and the GEMMs are too short-K to run well on their own.
 //
-// Structure: one workgroup = 128 query rows x ALL heads, 4 waves, each wave owns 32 rows (two 16-row MFMA columns) for the
-// whole chain, so no activation ever leaves the register file:
+// Structure: one workgroup = 128 query rows x ALL heads = 8 waves in a 4 (rows) x 2 (features) grid, one workgroup per CU with
+// all 160 KiB of LDS.  A wave owns 32 query rows (two 16-column MFMA operands) and half of the features (two groups of two
+// heads) for the whole chain; activations stay in registers except one exchange of the context fragments between the two wave
+// columns before to_out:
 //
 //   phase 0  X^T (B operand of v_mfma_f32_16x16x32_f16: lane = query, 8 consecutive channels per k-group) is loaded straight
 //            into registers; LayerNorm statistics are 80 in-lane adds + a 4-lane swap reduction; normalised in place.
-//   phase 1  Q^T[n][q] = Wq[n][:] . X^T : Wq streams through a 4-stage LDS ring (80 rows x 64 k per stage, LDS-DMA, counted
-//            vmcnt, one raw s_barrier per stage); the accumulator layout (lane = query, 4 consecutive features per k-group)
+//   phase 1  Q^T[n][q] = Wq[n][:] . X^T : Wq streams through a 4-stage LDS ring (one 80-row x 64-k tile per wave column and
+//            stage, LDS-DMA, counted vmcnt, one raw s_barrier per stage); the accumulator layout (lane = query, 4 consecutive features per k-group)
 //            IS the next product's B operand once converted to fp16 - with a permuted contraction order, which the K image
 //            and the columns of Wo are pre-permuted to match on the host / in pv_xattn_pack_kv.
 //   phase 2  per 80-feature group (= 2 heads of 40): S^T = K.Q^T (K image rows from LDS), two independent softmaxes in
-//            registers, O^T = V^T.P^T (V^T fragments by ds_read_b64_tr_b16); K/V images of the (sample, group) are LDS-DMA
-//            double-buffered.  The 2.5-fragment head boundary needs no padding: fragment 2 of a group is computed for both
+//            registers, O^T = V^T.P^T (V^T fragments by ds_read_b64_tr_b16); the K/V images of the sample are prefetched by
+//            LDS-DMA (first pair at kernel start, second pair into the idle Wq ring).  The 2.5-fragment head boundary needs no padding: fragment 2 of a group is computed for both
 //            heads and merged by lane group.
 //   phase 3  out^T[n][q] = Wo'[n][:] . ctx^T through the same ring; epilogue adds bias + residual and stores fp16.
 #include "pv_common.h"
@@ -126,24 +128,30 @@ struct pv_xfused_params_dev : pv_xattn_fused_params {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const pv_xfused_params_dev p) {
-    static_assert(C % GF == 0 && C % 64 == 0, "C must be a multiple of 80 and of 64");
+__global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_params_dev p) {
+    static_assert(C == 4 * GF, "the 4 x 2 wave grid splits exactly four 80-feature groups over two wave columns");
     constexpr int D = 40;
-    constexpr int NG = C / GF;        // feature groups (pairs of heads)
-    constexpr int NFR = C / 16;       // 16-feature fragments per row
-    constexpr int KK = C / 32;        // 32-deep contraction steps over C
-    constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk
-    constexpr int NT = NG * KT;       // ring stages per GEMM phase
+    constexpr int NG = C / GF;        // feature groups (pairs of heads): 4
+    constexpr int LF = 10;            // 16-feature fragments one wave column owns (two groups)
+    constexpr int NFR = C / 16;       // fragments per row: 20
+    constexpr int KK = C / 32;        // 32-deep contraction steps over C: 10
+    constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk: 5
+    constexpr int NT = 2 * KT;        // ring stages per GEMM phase (two 80-row chunks per wave column): 10
     constexpr int S = 4;              // ring depth
     constexpr int TILE_BYTES = GF * 128;                   // 80 weight rows x 64 k
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;            // one tile per wave column
     constexpr int KIMG_BYTES = XK * KROW;                  // one head
     constexpr int VIMG_BYTES = XK * GF * 2;
-    constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;
-    constexpr int GROUP_PIECES = GROUP_BYTES / 1024;       // 39
-    static_assert(GROUP_BYTES % 1024 == 0 && S * TILE_BYTES <= 2 * GROUP_BYTES, "LDS plan");
+    constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;   // 39 KiB
+    constexpr int GROUP_PIECES = GROUP_BYTES / 1024;
+    constexpr int REGION = S * STAGE_BYTES;                // 80 KiB; the kernel uses two such regions = all 160 KiB of the CU
+    static_assert(GROUP_BYTES % 1024 == 0 && 2 * GROUP_BYTES <= REGION && 4 * NFR * 2 * 64 * 8 <= REGION, "LDS plan");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const regA = smem;             // phase 1: Wq ring | phase 2 step 1: K/V images | exchange of the context fragments
+    char* const regB = smem + REGION;    // phase 2 step 0: K/V images | phase 3: Wo ring
 
     const int lane = pv_lane_id(), wave = pv_wave_id();
+    const int wm = wave >> 1, wn = wave & 1;    // 4 x 2 wave grid: wm = 32-row block, wn = half of the features (two groups)
     const int fr = lane & 15, g = lane >> 4;
     const int m0 = (int)blockIdx.x * 128;
     const int b = m0 / p.nq;
@@ -156,149 +164,200 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const pv_xfused_par
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.kimg), 0, (int)p.kimg_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vimg), 0, (int)p.vimg_bytes, 0x00020000);
 
-    // ---- LDS-DMA issue helpers ------------------------------------------------------------------------------------------
-    // weight ring stage t: rows [80 nc, +80) x k [64 kt, +64) of a [C][C] matrix; piece j = 8 rows x 128 B; waves 0,1 issue 3
-    // pieces, waves 2,3 issue 2.  Swizzle on the source: LDS position (lane & 7) of row r holds chunk (lane & 7) ^ (r & 7).
+    // ---- LDS-DMA issue helpers (one piece = one wave instruction = 1 KiB) -----------------------------------------------
+    // Ring stage t of a [C][C] weight: for wave column c in {0,1} the tile rows [80 (2c + t/KT), +80) x k [64 (t%KT), +64) at
+    // stage offset c * TILE_BYTES.  20 pieces of 8 rows x 128 B.  Swizzle on the source:
+    // LDS position (lane & 7) of row r holds chunk (lane & 7) ^ (r & 7).
     const int lrow = lane >> 3;
     const unsigned w_lane_off = (unsigned)lrow * (unsigned)(C * 2) + (unsigned)(((lane & 7) ^ lrow) << 4);
-    auto issue_tile = [&](const __amdgpu_buffer_rsrc_t& rw, int t) {
-        const int nc = t / KT, kt = t - nc * KT;
-        char* dst = smem + (t % S) * TILE_BYTES;
-        const unsigned base = (unsigned)(nc * GF) * (unsigned)(C * 2) + (unsigned)(kt * 128) + w_lane_off;
+    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rw, char* region, int t) {
+        if (wave >= 4) return;                                // waves 0-3 are the DMA issuers (5 pieces each), see below
+        const int kt = t % KT, half = t / KT;
+        char* dst = region + (t % S) * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = wave + 4 * i;
-            if (i < 2 || wave < 2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + j * 1024), 16, (int)(base + (unsigned)(j * 8) * (unsigned)(C * 2)), 0, 0, 0);
+        for (int i = 0; i < 5; ++i) {
+            const int j = wave + 4 * i;                       // piece 0..19
+            const int col = j / 10, pj = j - col * 10;        // wave column, 8-row piece inside its tile
+            const unsigned row = (unsigned)((2 * col + half) * GF + pj * 8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + j * 1024), 16, (int)(row * (unsigned)(C * 2) + (unsigned)(kt * 128) + w_lane_off), 0, 0, 0);
         }
     };
-    // K/V images of (sample b, group grp): a linear 39-KiB copy (the images are stored in LDS order); piece j = 1 KiB
-    auto issue_group = [&](int grp, int buf) {
-        char* dst = smem + buf * GROUP_BYTES;
-        const unsigned kbase = (unsigned)((b * (NG * 2) + 2 * grp) * KIMG_BYTES) + (unsigned)lane * 16u;
-        const unsigned vbase = (unsigned)((b * NG + grp) * VIMG_BYTES) + (unsigned)lane * 16u;
+    // K/V images of step st: group st (wave column 0) at offset 0, group 2 + st (wave column 1) at GROUP_BYTES; linear copies
+    // (the images are stored in LDS order).  78 pieces: waves 0,1 issue 20, waves 2,3 issue 19.
+    // Only waves 0-3 issue LDS-DMA: each SIMD hosts waves w and w + 4, which run the same program between the same barriers; if both
+    // stopped to issue (an LDS-DMA piece costs the issuing wave ~70 cycles) the SIMD's matrix pipe would idle - this way wave w + 4
+    // keeps issuing MFMAs while wave w feeds the ring.
+    auto issue_kv = [&](char* region, int st) {
+        if (wave >= 4) return;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 20; ++i) {
             const int j = wave + 4 * i;
-            if (j < 2 * KIMG_BYTES / 1024)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(dst + j * 1024), 16, (int)(kbase + (unsigned)j * 1024u), 0, 0, 0);
-            else if (j < GROUP_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(dst + j * 1024), 16, (int)(vbase + (unsigned)(j - 2 * KIMG_BYTES / 1024) * 1024u), 0, 0, 0);
+            if (j < 2 * GROUP_PIECES) {
+                const int col = j / GROUP_PIECES, pj = j - col * GROUP_PIECES;
+                const int grp = 2 * col + st;
+                if (pj < 2 * KIMG_BYTES / 1024)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(region + j * 1024), 16,
+                                                             (int)((unsigned)((b * (NG * 2) + 2 * grp) * KIMG_BYTES) + (unsigned)pj * 1024u + (unsigned)lane * 16u), 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(region + j * 1024), 16,
+                                                             (int)((unsigned)((b * NG + grp) * VIMG_BYTES) + (unsigned)(pj - 2 * KIMG_BYTES / 1024) * 1024u + (unsigned)lane * 16u), 0, 0, 0);
+            }
         }
     };
-    // wait until this wave's pieces of everything but the `y` youngest ring stages have landed
-    auto wait_tiles = [&](int y) {
-        if (wave < 2) { if (y == 2) xf_wait_vmcnt<6>(); else if (y == 1) xf_wait_vmcnt<3>(); else xf_wait_vmcnt<0>(); }
-        else          { if (y == 2) xf_wait_vmcnt<4>(); else if (y == 1) xf_wait_vmcnt<2>(); else xf_wait_vmcnt<0>(); }
+    // wait until this wave's pieces of everything but the `y` youngest ring stages have landed (issuing waves only)
+    auto wait_stages = [&](int y) {
+        if (wave < 4) { if (y >= 4) xf_wait_vmcnt<20>(); else if (y == 3) xf_wait_vmcnt<15>(); else if (y == 2) xf_wait_vmcnt<10>(); else if (y == 1) xf_wait_vmcnt<5>(); else xf_wait_vmcnt<0>(); }
+    };
+    auto wg_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads / writes are retired
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
-    // ---- phase 0: X^T into registers (+ LayerNorm) -----------------------------------------------------------------------
-    issue_tile(rq, 0);
-    issue_tile(rq, 1);
-    issue_tile(rq, 2);
+    // ---- phase 0: X^T into registers (+ LayerNorm); the first Wq stages and the first K/V images are already on their way ---
     half8_t xf[KK][2];
     int mrow[2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        mrow[qi] = m0 + wave * 32 + qi * 16 + fr;
+        mrow[qi] = m0 + wm * 32 + qi * 16 + fr;
         const half_t* src = hs + (size_t)mrow[qi] * p.ld_hs + g * 8;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = *reinterpret_cast<const half8_t*>(src + kk * 32);
     }
-    if (p.ln_gamma) {
-        float mean[2], rstd[2];
+    issue_kv(regB, 0);
+    issue_stage(rq, regA, 0);
+    issue_stage(rq, regA, 1);
+    issue_stage(rq, regA, 2);
+    issue_stage(rq, regA, 3);
+    if (p.ln) {
+        // LayerNorm WITHOUT its affine part (the caller folds gamma into the columns of wq and beta into q_bias):
+        // x^ = x * rstd - mean * rstd, one mixed-precision FMA per element (fp16 in, fp32 math, fp16 out).  Statistics: the row sum
+        // by v_dot2_f32_f16 against (1, 1); the centred sum of squares from d = x - fp16(mean) (packed fp16 subtract, the rounding
+        // of d averages out over the 320 terms) by v_dot2_f32_f16(d, d), corrected exactly for the rounding of the mean.
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        const h2_t ones = h2_t{(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             float sum = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum += (float)xf[kk][qi][j];
-            mean[qi] = pv_quad_sum(sum) * (1.0f / (float)C);
+                for (int j = 0; j < 4; ++j) sum = __builtin_amdgcn_fdot2(h2_t{xf[kk][qi][2 * j], xf[kk][qi][2 * j + 1]}, ones, sum, false);
+            const float mean = pv_quad_sum(sum) * (1.0f / (float)C);
+            const half_t mh = (half_t)mean;
+            const h2_t nm = h2_t{(half_t)(-mh), (half_t)(-mh)};
             float sq = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d = (float)xf[kk][qi][j] - mean[qi];
-                    sq += d * d;
+                for (int j = 0; j < 4; ++j) {
+                    const h2_t d = h2_t{xf[kk][qi][2 * j], xf[kk][qi][2 * j + 1]} + nm;
+                    sq = __builtin_amdgcn_fdot2(d, d, sq, false);
                 }
-            rstd[qi] = rsqrtf(pv_quad_sum(sq) * (1.0f / (float)C) + p.ln_eps);
-        }
+            const float dm = mean - (float)mh;
+            const float var = pv_quad_sum(sq) * (1.0f / (float)C) - dm * dm;
+            const float rstd = rsqrtf(fmaxf(var, 0.f) + p.ln_eps);
+            const float nmr = -mean * rstd;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const float4_t g0 = *reinterpret_cast<const float4_t*>(p.ln_gamma + kk * 32 + g * 8);
-            const float4_t g1 = *reinterpret_cast<const float4_t*>(p.ln_gamma + kk * 32 + g * 8 + 4);
-            const float4_t b0 = *reinterpret_cast<const float4_t*>(p.ln_beta + kk * 32 + g * 8);
-            const float4_t b1 = *reinterpret_cast<const float4_t*>(p.ln_beta + kk * 32 + g * 8 + 4);
+            for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gm = j < 4 ? g0[j & 3] : g1[j & 3], bt = j < 4 ? b0[j & 3] : b1[j & 3];
-                    xf[kk][qi][j] = (half_t)(((float)xf[kk][qi][j] - mean[qi]) * rstd[qi] * gm + bt);
-                }
+                for (int j = 0; j < 8; ++j) xf[kk][qi][j] = (half_t)fmaf((float)xf[kk][qi][j], rstd, nmr);
         }
     }
+    // The register loads above made the compiler wait; make the hand-counted DMA bookkeeping start from a known state too:
+    // everything issued so far (K/V step 0 included) has landed after this wait.
+    xf_wait_vmcnt<0>();
 
-    // ---- phase 1: Q^T = Wq . X^T -----------------------------------------------------------------------------------------
-    // qf[f][qi]: fp16 of fragment f (features 16f + 4g + r) for this lane's query, pre-scaled by log2(e)/sqrt(d)
-    half4_t qf[NFR][2];
+    // ---- phase 1: Q^T = Wq . X^T for this wave column's 160 features -----------------------------------------------------
+    // qf[l][qi]: fp16 of local fragment l (features 160 wn + 16 l + 4g + r) for this lane's query, pre-scaled by log2(e)/sqrt(d)
+    half4_t qf[LF][2];
     const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
+    // Ring schedule (phases 1 and 3), as in the GEMM kernel: a 64-deep stage is two 32-deep halves H0 / H1 and the workgroup
+    // barrier sits BETWEEN them, so the fragment reads of one half overlap the MFMAs of the other:
+    //     read H1(t) | MFMA H0(t)  ->  stage t+1 landed, lgkmcnt(0), s_barrier, refill buffer t with stage t+S  ->  read H0(t+1) | MFMA H1(t)
+    // Fragment reads of the ring: row 16 i + fr, chunk (4 ks + g) ^ (fr & 7) - every address is one of two per-lane bases (ks = 0 / 1)
+    // plus a compile-time offset (stage, fragment), so each read is ONE instruction (ds_read_b128 with an immediate offset < 64 KiB);
+    // left to itself the compiler rebuilt most addresses with VALU / SALU adds and the ring stages were instruction-issue bound.
+    const int ring_lane[2] = {wn * TILE_BYTES + fr * 128 + ((g ^ (fr & 7)) << 4), wn * TILE_BYTES + fr * 128 + (((4 + g) ^ (fr & 7)) << 4)};
+    auto read_half = [&](half8_t (&a)[5], const char* region, int t, int ks) {
+        const char* base = region + ring_lane[ks];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8_t*>(base + (t % S) * STAGE_BYTES + i * 2048);
+    };
     {
         float4_t acc[5][2];
+        half8_t a0[5], a1[5];
+        wg_barrier();                      // stage 0 (drained above) is visible to every wave
+        read_half(a0, regA, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int nc = t / KT, kt = t % KT;
+            const int kt = t % KT;
             if (kt == 0) {
+                // accumulators start from the query bias (beta of the folded LayerNorm pushed through to_q), rows 4g..4g+3 of each fragment
 #pragma unroll
-                for (int i = 0; i < 5; ++i) acc[i][0] = acc[i][1] = float4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 5; ++i)
+                    acc[i][0] = acc[i][1] = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + (2 * wn + t / KT) * GF + i * 16 + g * 4)
+                                                      : float4_t{0.f, 0.f, 0.f, 0.f};
             }
-            wait_tiles(NT - 1 - t < 2 ? NT - 1 - t : 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + 3 < NT) issue_tile(rq, t + 3);
-            const char* sw = smem + (t % S) * TILE_BYTES;
+            read_half(a1, regA, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const half8_t a = ld_frag128(sw, i * 16 + fr, ks * 4 + g);
+                for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], xf[2 * kt][qi], acc[i][qi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < NT) {
+                wait_stages((t + S - 1 < NT ? t + S - 1 : NT - 1) - (t + 1));   // stage t+1 landed; the later issued ones may be in flight
+                wg_barrier();                                                     // ... for every wave, and buffer t % S is read out
+                if (t + S < NT) issue_stage(rq, regA, t + S);
+                __builtin_amdgcn_sched_barrier(0);
+                read_half(a0, regA, t + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[2 * kt + ks][qi], acc[i][qi], 0, 0, 0);
-                }
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], xf[2 * kt + 1][qi], acc[i][qi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (kt == KT - 1) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) qf[nc * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
+                        for (int r = 0; r < 4; ++r) qf[(t / KT) * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
             }
         }
     }
 
-    // ---- phase 2: dual-branch attention, one 80-feature group (two heads) at a time -------------------------------------
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // every wave is done with the weight ring
-    asm volatile("" ::: "memory");
-    issue_group(0, 0);
-    issue_group(1, 1);
-    half4_t cf[NFR][2];                    // context fragments, same layout as qf
+    // ---- phase 2: dual-branch attention; this wave column's two 80-feature groups (two heads each) ------------------------
+    wg_barrier();                          // every wave is done with the Wq ring (region A)
+    issue_kv(regA, 1);                     // K/V images of step 1 land while step 0 computes out of region B
+    half4_t cf[LF][2];                     // context fragments, same layout as qf
+    bool tmask[4], imask[4];               // validity of this lane's keys in fragment 4 (text tail) and fragment 5 (image tokens)
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
-        if (grp + 1 < NG) { if (wave < 3) xf_wait_vmcnt<10>(); else xf_wait_vmcnt<9>(); }
-        else xf_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* sbuf = smem + (grp & 1) * GROUP_BYTES;
+    for (int r = 0; r < 4; ++r) {
+        tmask[r] = 64 + g * 4 + r < p.nt;
+        imask[r] = g * 4 + r < p.nip;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        if (st == 1) {
+            wg_barrier();                  // every wave is done with region B: prefetch the first Wo stages into it
+            issue_stage(ro, regB, 0);
+            issue_stage(ro, regB, 1);
+            issue_stage(ro, regB, 2);
+            issue_stage(ro, regB, 3);
+            wait_stages(4);                // all but the four Wo stages: the K/V images of step 1 landed
+            wg_barrier();
+        }
+        const char* sbuf = (st == 0 ? regB : regA) + wn * GROUP_BYTES;
         const half_t* sV = reinterpret_cast<const half_t*>(sbuf + 2 * KIMG_BYTES);
         float4_t o2_h0[2];                 // head 0's fragment 2 (its rows 0-7 are head 0's features 32..39)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const char* sK = sbuf + hh * KIMG_BYTES;
-            const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
+            const int fa = st * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = st * 5 + 2;
             float4_t s[6][2];
 #pragma unroll
             for (int kb = 0; kb < 6; ++kb) s[kb][0] = s[kb][1] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -314,38 +373,37 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const pv_xfused_par
                     for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
                 }
             }
-            // two independent softmaxes over the key axis (registers r, fragments kb, and the 4 lane groups)
+            // two independent softmaxes over the key axis (registers r, fragments kb, and the 4 lane groups).  Text keys are
+            // fragments 0..4 (keys 0..79; only the tail of fragment 4 can be padding), image-token keys are fragment 5.
             half8_t pb[3][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
                 float mt = -INFINITY, mi = -INFINITY;
 #pragma unroll
-                for (int kb = 0; kb < 6; ++kb)
+                for (int r = 0; r < 4; ++r) {
+                    if (!tmask[r]) s[4][qi][r] = -INFINITY;
+                    if (!imask[r]) s[5][qi][r] = -INFINITY;
+                    mi = fmaxf(mi, s[5][qi][r]);
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kb * 16 + g * 4 + r;
-                        const float v = s[kb][qi][r];
-                        if (key < p.nt) mt = fmaxf(mt, v);
-                        if (key >= XIP0 && key < XIP0 + p.nip) mi = fmaxf(mi, v);
-                    }
+                for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kb][qi][r]);
                 mt = pv_quad_max(mt);
                 mi = pv_quad_max(mi);
                 float lt = 0.f, li = 0.f;
 #pragma unroll
-                for (int kb = 0; kb < 6; ++kb)
+                for (int kb = 0; kb < 5; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = kb * 16 + g * 4 + r;
-                        float e = 0.f;
-                        if (key < p.nt) {
-                            e = PV_EXP2(s[kb][qi][r] - mt);
-                            lt += e;
-                        } else if (key >= XIP0 && key < XIP0 + p.nip) {
-                            e = PV_EXP2(s[kb][qi][r] - mi);
-                            li += e;
-                        }
-                        s[kb][qi][r] = e;
+                        s[kb][qi][r] = PV_EXP2(s[kb][qi][r] - mt);       // exp2(-inf) = 0 for the padding keys
+                        lt += s[kb][qi][r];
                     }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[5][qi][r] = PV_EXP2(s[5][qi][r] - mi);
+                    li += s[5][qi][r];
+                }
                 lt = pv_quad_sum(lt);
                 li = pv_quad_sum(li);
                 const float ft = w_text / lt, fi = w_ip / li;
@@ -353,9 +411,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const pv_xfused_par
                 for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int k0 = (2 * s2) * 16 + g * 4 + r, k1 = k0 + 16;
-                        pb[s2][qi][r] = (half_t)(s[2 * s2][qi][r] * (k0 < XIP0 ? ft : fi));
-                        pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * (k1 < XIP0 ? ft : fi));
+                        pb[s2][qi][r] = (half_t)(s[2 * s2][qi][r] * ft);
+                        pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * (s2 == 2 ? fi : ft));
                     }
             }
             // O^T = V^T . P^T for this head's three fragments of the group's 80 value columns
@@ -375,80 +432,94 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const pv_xfused_par
                 if (hh == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cf[grp * 5 + 0][qi][r] = (half_t)o[0][qi][r];
-                        cf[grp * 5 + 1][qi][r] = (half_t)o[1][qi][r];
+                        cf[st * 5 + 0][qi][r] = (half_t)o[0][qi][r];
+                        cf[st * 5 + 1][qi][r] = (half_t)o[1][qi][r];
                     }
                     o2_h0[qi] = o[2][qi];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cf[grp * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
-                        cf[grp * 5 + 3][qi][r] = (half_t)o[1][qi][r];
-                        cf[grp * 5 + 4][qi][r] = (half_t)o[2][qi][r];
+                        cf[st * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
+                        cf[st * 5 + 3][qi][r] = (half_t)o[1][qi][r];
+                        cf[st * 5 + 4][qi][r] = (half_t)o[2][qi][r];
                     }
                 }
             }
         }
-        if (grp + 2 < NG) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave is done with this buffer
-            asm volatile("" ::: "memory");
-            issue_group(grp + 2, grp & 1);
-        }
     }
 
-    // ---- phase 3: out^T = Wo' . ctx^T, + bias + residual ----------------------------------------------------------------
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_tile(ro, 0);
-    issue_tile(ro, 1);
-    issue_tile(ro, 2);
+    // ---- exchange: every wave needs the context fragments of BOTH wave columns for the to_out contraction -----------------
+    wg_barrier();                          // every wave is done with the K/V images in region A
+    {
+        half4_t* xch = reinterpret_cast<half4_t*>(regA) + (size_t)wm * (NFR * 2 * 64) + lane;   // [wm][fragment][qi][lane]
+#pragma unroll
+        for (int l = 0; l < LF; ++l)
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) xch[((wn * LF + l) * 2 + qi) * 64] = cf[l][qi];
+    }
+    wg_barrier();
+    half4_t ca[NFR][2];
+    {
+        const half4_t* xch = reinterpret_cast<const half4_t*>(regA) + (size_t)wm * (NFR * 2 * 64) + lane;
+#pragma unroll
+        for (int f = 0; f < NFR; ++f)
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) ca[f][qi] = xch[(f * 2 + qi) * 64];
+    }
+
+    // ---- phase 3: out^T = Wo' . ctx^T for this wave column's 160 output features, + bias + residual ----------------------
     {
         half_t* outp = reinterpret_cast<half_t*>(p.out);
         float4_t acc[5][2];
+        half4_t res[5][2];
+        half8_t a0[5], a1[5];
+        // stages 0..3 were issued during phase 2 (into region B)
+        wait_stages(3);
+        wg_barrier();
+        read_half(a0, regB, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int nc = t / KT, kt = t % KT;
+            const int kt = t % KT;
+            const int nb = (2 * wn + t / KT) * GF + g * 4;
             if (kt == 0) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) acc[i][0] = acc[i][1] = float4_t{0.f, 0.f, 0.f, 0.f};
-            }
-            wait_tiles(NT - 1 - t < 2 ? NT - 1 - t : 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + 3 < NT) issue_tile(ro, t + 3);
-            const char* sw = smem + (t % S) * TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                half8_t bc[2];
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) bc[qi] = cat4(cf[2 * (2 * kt + ks)][qi], cf[2 * (2 * kt + ks) + 1][qi]);
+                // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const half8_t a = ld_frag128(sw, i * 16 + fr, ks * 4 + g);
-#pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bc[qi], acc[i][qi], 0, 0, 0);
-                }
-            }
-            if (kt == KT - 1) {
-                const int nb = nc * GF + g * 4;
-                half4_t res[5][2];
-                float4_t bias[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    bias[i] = p.bias_o ? *reinterpret_cast<const float4_t*>(p.bias_o + nb + i * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+                    acc[i][0] = acc[i][1] = p.bias_o ? *reinterpret_cast<const float4_t*>(p.bias_o + nb + i * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int qi = 0; qi < 2; ++qi) res[i][qi] = *reinterpret_cast<const half4_t*>(hs + (size_t)mrow[qi] * p.ld_hs + nb + i * 16);
                 }
+            }
+            read_half(a1, regB, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], cat4(ca[4 * kt][qi], ca[4 * kt + 1][qi]), acc[i][qi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < NT) {
+                wait_stages((t + S - 1 < NT ? t + S - 1 : NT - 1) - (t + 1));
+                wg_barrier();
+                if (t + S < NT) issue_stage(ro, regB, t + S);
+                __builtin_amdgcn_sched_barrier(0);
+                read_half(a0, regB, t + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], cat4(ca[4 * kt + 2][qi], ca[4 * kt + 3][qi]), acc[i][qi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == KT - 1) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int qi = 0; qi < 2; ++qi) {
                         half4_t ov;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(acc[i][qi][r] + bias[i][r] + (float)res[i][qi][r]);
+                        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(acc[i][qi][r] + (float)res[i][qi][r]);
                         *reinterpret_cast<half4_t*>(outp + (size_t)mrow[qi] * p.ld_out + nb + i * 16) = ov;
                     }
             }
@@ -482,14 +553,14 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     static_cast<pv_xattn_fused_params&>(p) = *pp;
     const int C = p.heads * p.d;
     if (!p.hs || !p.wq || !p.wo || !p.kimg || !p.vimg || !p.out || p.batch <= 0 || p.nq <= 0 || (p.nq % 128) || p.d != 40 || C != 320 ||
-        p.nt <= 0 || p.nt > XIP0 || p.nip <= 0 || p.nip > XK - XIP0 || (p.ld_hs % 8) || (p.ld_out % 4) || (p.ln_gamma && !p.ln_beta))
+        p.nt <= 64 || p.nt > XIP0 || p.nip <= 0 || p.nip > XK - XIP0 || (p.ld_hs % 8) || (p.ld_out % 4))
         return (int)hipErrorInvalidValue;
     p.w_bytes = (uint32_t)C * C * 2;
     const size_t kb = (size_t)p.batch * p.heads * XK * KROW, vb = (size_t)p.batch * (C / GF) * XK * GF * 2;
     if (kb >= (1ull << 31) || vb >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
-    constexpr int SMEM = 2 * (2 * XK * KROW + XK * GF * 2);
+    constexpr int SMEM = 2 * 4 * 2 * GF * 128;   // two 80-KiB regions (xattn_fused_kernel): all of the CU's LDS, one workgroup per CU
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -500,6 +571,6 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)p.batch * p.nq / 128)), dim3(256), SMEM, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)p.batch * p.nq / 128)), dim3(512), SMEM, (hipStream_t)stream, p);
     return PV_CHECK_LAUNCH();
 }

@@ -216,7 +216,7 @@ class Recorder:
     # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual), C = 320 / d = 40 layers ----
     @staticmethod
     def xattn_fused_supported(C: int, heads: int, nq: int, nt: int, nip: int) -> bool:
-        return C == 320 and heads == 8 and nq % 128 == 0 and 0 < nt <= 80 and 0 < nip <= 16
+        return C == 320 and heads == 8 and nq % 128 == 0 and 64 < nt <= 80 and 0 < nip <= 16
 
     def pack_wo_for_fused(self, wo: torch.Tensor) -> torch.Tensor:
         """to_out[0].weight [C][C] with its columns in the fused kernel's context-slot order (pv_xattn_fused_wo_slot)."""
@@ -236,13 +236,20 @@ class Recorder:
 
     def cross_attention_fused(self, hs, wq, wo_packed, bias_o, kimg, vimg, *, batch, nq, heads, d, nt, nip, ln_gamma=None, ln_beta=None,
                               ln_eps=1e-5, w_text=1.0, w_ip=1.0, fusion=None, out=None):
+        """``wq``: to_q.weight fp16 [C][C].  With ``ln_gamma`` / ``ln_beta`` the kernel applies norm2 in front of to_q; its affine part
+        is folded here, once at plan-build time: gamma scales the columns of wq, beta becomes a bias on q (= wq . beta)."""
         C = heads * d
         if out is None:
             out = self.empty((batch * nq, C), torch.float16)
-        p = XAttnFusedParams(_ptr(hs), _rows(hs)[0], _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), _ptr(wq), _ptr(wo_packed), _ptr(bias_o),
+        q_bias = None
+        if ln_gamma is not None:
+            w32 = wq.float()
+            q_bias = (w32 @ ln_beta.float()).contiguous()
+            wq = (w32 * ln_gamma.float()[None, :]).to(torch.float16).contiguous()
+        p = XAttnFusedParams(_ptr(hs), _rows(hs)[0], int(ln_gamma is not None), float(ln_eps), _ptr(wq), _ptr(q_bias), _ptr(wo_packed), _ptr(bias_o),
                              _ptr(kimg), _ptr(vimg), _ptr(out), _rows(out)[0], batch, nq, heads, d, nt, nip, float(w_text), float(w_ip),
                              _ptr(fusion))
-        self.keep.extend(t for t in (hs, wq, wo_packed, bias_o, kimg, vimg, ln_gamma, ln_beta, fusion, out) if t is not None)
+        self.keep.extend(t for t in (hs, wq, q_bias, wo_packed, bias_o, kimg, vimg, fusion, out) if t is not None)
         M = batch * nq
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
         self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320>", flops, 2.0 * (3 * M * C + 2 * C * C)))

@@ -27,13 +27,6 @@ def timeit(rec, reps=10):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
-    if os.environ.get("PV_CLOCKPROBE"):   # diagnostic build (-DPV_CLOCKPROBE): shader clock inside the GEMM main loop
-        import ctypes
-        from photoverse_amd import _lib
-        out = (ctypes.c_ulonglong * 2)()
-        fn = getattr(_lib.load(), "pv_debug_clock_probe", None)
-        if fn is not None and fn(out) == 0 and out[1]:
-            print(f"      main loop of a mid-launch workgroup: {out[1] * 10e-3:.1f} us at {out[0] / out[1] * 0.1:.2f} GHz")
     return us
 
 
@@ -83,6 +76,30 @@ def xattn(name, d, n, p=1):
         q, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
         rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, nq=n, nt=77, nip=p, d=d)
         return rec, 4.0 * B * n * (77 + p) * C, 2.0 * 2 * B * n * C
+    cases.append((name, f))
+
+
+def xfused(name, n, p=1, fused=True):
+    """attn2 branch at C = 320: the fused launch, or the four launches it replaces (LayerNorm, to_q, dual SDPA, to_out + residual)."""
+    def f():
+        rec = Recorder(dev)
+        C, d = 320, 40
+        hs, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
+        wq, wo, bo = h16(C, C, scale=0.05), h16(C, C, scale=0.05), torch.zeros(C, device=dev)
+        g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        if fused:
+            pk = Recorder(dev)
+            kimg, vimg = pk.xattn_pack_kv(kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, d=d, nt=77, nip=p)
+            pk.run()
+            rec.keep.append(pk)
+            rec.cross_attention_fused(hs, wq, rec.pack_wo_for_fused(wo), bo, kimg, vimg, batch=B, nq=n, heads=8, d=d, nt=77, nip=p, ln_gamma=g, ln_beta=bt)
+        else:
+            n2 = rec.layernorm(hs, g, bt)
+            q = rec.gemm(n2, wq, rows_per_image=n)
+            xa, _ = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, nq=n, nt=77, nip=p, d=d)
+            rec.gemm(xa, wo, bias=bo, residual=hs, rows_per_image=n)
+        M = B * n
+        return rec, 4.0 * M * C * C + 4.0 * M * (77 + p) * C, 2.0 * 3 * M * C
     cases.append((name, f))
 
 
@@ -152,6 +169,9 @@ attn("attn d80 n1024", 80, 1024)
 attn("attn d160 n256", 160, 256)
 xattn("xattn d40 n4096", 40, 4096)
 xattn("xattn d80 n1024", 80, 1024)
+xfused("attn2 branch C320 n4096 FUSED", 4096)
+xfused("attn2 branch C320 n4096 4 launches", 4096, fused=False)
+xfused("attn2 branch C320 n4096 P5 FUSED", 4096, p=5)
 conv_out("conv_out 320->4 @64", 320, 4, 64)
 conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)
