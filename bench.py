@@ -240,6 +240,35 @@ def main():
                                           "source": "profiles/r01_mfma_power_probe.txt: this kernel's MFMA + ds_read mix on random fp16 "
                                                     "operands, no global traffic, holds 1.70 GHz (2.40 GHz / 2.45 PFLOP/s only with zeros)"}}
 
+    # the north_star's named target: MFMA utilisation of the adapter cross-attention kernel.  SURVEY 0.1 #8 defines it as the fused
+    # to_q + dual-branch SDPA + to_out kernel; it exists for the C = 320 layers (pv_xfused.hip), the other levels run the four-launch
+    # path.  Same measurement as the roofline object: back-to-back replay of this kernel's launches of one step, HIP events.
+    xfused = None
+    if rank == 0 and not args.no_roofline:
+        name = "xattn_fused_kernel<320>"
+        subs = [e.rec.subset(lambda t: t[0] == name) for e in loop.engines_u + loop.engines_c]
+        nl = sum(len(s_) for s_ in subs)
+        if nl:
+            flops = sum(t[1] for s_ in subs for t in s_.tags)
+            for s_ in subs:
+                s_.run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            for _ in range(5):
+                for s_ in subs:
+                    s_.run()
+            e1.record(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            ach = flops / (ms * 1e-3) / 1e12
+            xfused = {"kernel": name, "what": "norm2 -> to_q -> text + image-token SDPA (two softmaxes) -> to_out + bias + residual, one launch "
+                                              "(C = 320 / d = 40 cross-attention layers; the 640 / 1280-channel layers run four launches)",
+                      "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                      "north_star_target_frac": 0.40, "launches_per_step": nl, "avg_launch_us": round(ms * 1e3 / nl, 2),
+                      "flops_per_launch": flops / nl,
+                      "flops_counted": "algorithmic: 4 M C^2 (to_q + to_out) + 4 M (77 + P) C (both SDPA products), M = B * 4096"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (contract); N > 1 runs stay short
         cpu = cpu_baseline()
@@ -259,7 +288,7 @@ def main():
                        "launches_per_step": loop.launches_per_step},
             "finite": finite,
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:
