@@ -110,6 +110,7 @@ def main():
                     help="run the uncond / cond forwards back to back on one stream instead of as two parallel graph branches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train-forward", action="store_true", help="skip the separately labelled training-shaped forward measurement")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test (no GPU): every rank reports its RANK / WORLD_SIZE and exits")
     args = ap.parse_args()
@@ -269,6 +270,43 @@ def main():
                       "flops_per_launch": flops / nl,
                       "flops_counted": "algorithmic: 4 M C^2 (to_q + to_out) + 4 M (77 + P) C (both SDPA products), M = B * 4096"}
 
+    # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
+    # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.
+    # The backward is not built; this is NOT part of `value`.
+    train_fwd = None
+    launches_per_step = loop.launches_per_step
+    if rank == 0 and world == 1 and not args.no_train_forward and S == 64:
+        loop = subs = None          # release the loop's ~8 GB of static buffers before building the training-shaped engine
+        torch.cuda.empty_cache()
+        set_visual_cross_attention_adapter(unet, (5,))
+        unet.to(dev)
+        eng = unet.engine(B, S, S, 5, B, device_fusion="always", fusion_seed=1)
+        gt = torch.Generator().manual_seed(99)
+        eng.x_in.copy_(torch.randn(B, 4, S, S, generator=gt))
+        eng.text.copy_(torch.randn(B * 77, 768, generator=gt))
+        eng.ip.copy_(torch.randn(B * 5, 768, generator=gt))
+        eng.timesteps.copy_(torch.randint(0, 1000, (B,), generator=gt).float())
+        eng.run()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            eng.rec_cond.run()          # a training step re-projects the conditioning every iteration (adapters are being trained)
+            eng.rec.run()
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            gr.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        tfl = B * 0.8043
+        train_fwd = {"workload": "configs[3], forward only: SD-v1.5 UNet + PhotoVerse processors, bs=16, 64x64 latents, P=5 image tokens, "
+                                 "per-sample timesteps, grad-mode branch fusion drawn on the device (no host sync), K/V projections included",
+                     "ms_per_forward": round(ms, 3), "tflop_per_forward": round(tfl, 3), "achieved_tflops": round(tfl / (ms * 1e-3), 1),
+                     "mfma_frac": round(tfl / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(eng.out).all().item()),
+                     "launches": len(eng.rec) + len(eng.rec_cond), "backward": "not built"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (contract); N > 1 runs stay short
         cpu = cpu_baseline()
@@ -285,10 +323,10 @@ def main():
             "config": {"workload": "configs[1]: SD-v1.5 UNet + PhotoVerse processors, 50-step loop, bs=16/GPU, 512x512 (64x64 latents), fp16",
                        "per_gpu_batch": B, "global_batch": GB, "latent": S, "ip_tokens": P, "guidance_scale": args.guidance,
                        "parallelism": f"dp{world} (batch-sharded, 1 all_gather)", "hip_graph": not args.no_graph, "graph_branches": 1 if args.one_stream else 2 * args.batch_splits,
-                       "launches_per_step": loop.launches_per_step},
+                       "launches_per_step": launches_per_step},
             "finite": finite,
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "xattn_fused": xfused, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "train_forward": train_fwd, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:

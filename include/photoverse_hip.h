@@ -150,6 +150,7 @@ typedef struct pv_xattn_params {
     float* vnorm;                                          /* [B][H][nip] or NULL */
     int32_t batch, heads, nq, nt, nip, d;
     float w_text, w_ip;
+    const float* fusion;                                   /* optional DEVICE pair overriding (w_text, w_ip), see pv_fusion_draw */
 } pv_xattn_params;
 int pv_cross_attention(const pv_xattn_params* p, void* stream);
 
@@ -210,6 +211,16 @@ int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int
 int pv_cfg_dpm_step(const float* eps_uncond, const float* eps_cond, float* latents, float* x0_prev,
                     const float* coef, const int32_t* state, float guidance, int64_t n, void* stream);
 int pv_step_advance(int32_t* state, void* stream);
+
+/* Grad-mode branch fusion of PhotoVerseAttnProcessor2_0 (attention_processor.py:413-420) WITHOUT the reference's per-layer
+ * host sync (`torch.rand(1).item()`): one tiny launch draws u ~ U(0,1) per cross-attention layer on the device
+ * (Philox4x32-10, key = rng[0..1], counter = {rng[2] = launch count, layer}) and writes out[layer] = (w_text, w_ip):
+ * u < rule1 -> (scale, 0); u > rule2 -> (0, scale); else (1, 1).  rng[2] advances by one per launch, so a captured graph draws
+ * fresh numbers on every replay.  forced (optional, [n_layers]): entries >= 0 replace the drawn u (tests).
+ * only_last_step != 0 with state != NULL: the rule applies only when state[0] == state[1] - 1 (run_inference's
+ * training_mode, infer.py:99: grad is enabled on the last denoising step only), otherwise every layer gets (1, 1). */
+int pv_fusion_draw(const int32_t* state, uint32_t* rng, const float* forced, float* out, int32_t n_layers, float rule1,
+                   float rule2, float scale, int32_t only_last_step, void* stream);
 
 /* small helpers */
 int pv_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);

@@ -44,7 +44,7 @@ class XAttnParams(C.Structure):
     _fields_ = [("q", c_void_p), ("ldq", c_int), ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int),
                 ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int), ("out", c_void_p), ("ldo", c_int),
                 ("vnorm", c_void_p), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nt", c_int), ("nip", c_int),
-                ("d", c_int), ("w_text", c_float), ("w_ip", c_float)]
+                ("d", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
 
 
 class XAttnFusedParams(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_cfg_dpm_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "pv_step_advance": (c_int, [c_void_p, c_void_p]),
+    "pv_fusion_draw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "pv_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pv_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pv_rows_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p, con
             }
         lt = pv_quad_sum(lt);
         li = pv_quad_sum(li);
-        const float ft = p.w_text / lt, fi = p.w_ip / li;
+        const float ft = (p.fusion ? p.fusion[0] : p.w_text) / lt, fi = (p.fusion ? p.fusion[1] : p.w_ip) / li;
 #pragma unroll
         for (int s2 = 0; s2 < NKB / 2; ++s2)
 #pragma unroll

@@ -168,6 +168,36 @@ __global__ void cfg_dpm_step_kernel(const float* eu, const float* ec, float* lat
 
 __global__ void step_advance_kernel(int32_t* state) { state[0] += 1; }
 
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so one launch = one independent draw per layer with no stored stream
+__device__ __forceinline__ uint32_t philox_first_word(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1) {
+    uint32_t c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__global__ void fusion_draw_kernel(const int32_t* state, uint32_t* rng, const float* forced, float* out, int n, float r1, float r2,
+                                   float scale, int only_last) {
+    const int i = threadIdx.x;
+    const uint32_t call = rng[2];
+    float wt = 1.f, wi = 1.f;
+    const bool on = !(only_last && state) || state[0] == state[1] - 1;
+    if (i < n && on) {
+        float u = (float)(philox_first_word(rng[0], rng[1], call, (uint32_t)i) >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+        if (forced && forced[i] >= 0.f) u = forced[i];
+        if (u < r1) { wt = scale; wi = 0.f; }
+        else if (u > r2) { wt = 0.f; wi = scale; }
+    }
+    if (i < n) { out[2 * i] = wt; out[2 * i + 1] = wi; }
+    __syncthreads();
+    if (i == 0) rng[2] = call + 1u;
+}
+
 __global__ void cast_f32_f16_kernel(const float* x, half_t* y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = (half_t)x[i];
@@ -429,6 +459,14 @@ extern "C" int pv_cfg_dpm_step(const float* eps_uncond, const float* eps_cond, f
 extern "C" int pv_step_advance(int32_t* state, void* stream) {
     if (!state) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_fusion_draw(const int32_t* state, uint32_t* rng, const float* forced, float* out, int32_t n_layers, float rule1, float rule2,
+                              float scale, int32_t only_last_step, void* stream) {
+    if (!rng || !out || n_layers <= 0 || n_layers > 256) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(fusion_draw_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, rng, forced, out, n_layers, rule1, rule2, scale,
+                       only_last_step);
     return PV_CHECK_LAUNCH();
 }
 

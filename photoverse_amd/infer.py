@@ -21,12 +21,13 @@ from .scheduler import DPMSolverMultistepScheduler
 MAX_CACHED_LOOPS = 2
 
 
-def _loop_for(unet, batch, latent_size, n_ip, steps, guidance, scheduler) -> DenoiseLoop:
+def _loop_for(unet, batch, latent_size, n_ip, steps, guidance, scheduler, training_mode=False, fusion_seed=0) -> DenoiseLoop:
     cache = unet.__dict__.setdefault("_denoise_loops", OrderedDict())
-    key = (batch, latent_size, n_ip, steps, float(guidance))
+    key = (batch, latent_size, n_ip, steps, float(guidance), bool(training_mode), int(fusion_seed))
     loop = cache.pop(key, None)
     if loop is None or loop.unet_version != unet.__dict__.get("_pack_version", 0):
-        loop = DenoiseLoop(unet, batch, latent_size, n_ip, steps, guidance, scheduler=scheduler)
+        loop = DenoiseLoop(unet, batch, latent_size, n_ip, steps, guidance, scheduler=scheduler, training_mode=training_mode,
+                           fusion_seed=fusion_seed)
         loop.unet_version = unet.__dict__.get("_pack_version", 0)
     cache[key] = loop                               # most recently used last
     while len(cache) > MAX_CACHED_LOOPS:
@@ -40,8 +41,12 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
     """Same 11 positional + 8 keyword arguments as the reference.  ``noise`` (keyword-only, new): a caller-drawn start noise
     ``(B, C, latent, latent)`` replacing the draw of ``infer.py:52-59`` - used by the batch-sharded pipeline, which draws the
     global batch once and hands each rank its slice."""
-    if training_mode:
-        raise NotImplementedError("training_mode (grad through the last step, infer.py:99) belongs to the training row (SURVEY 8f-3)")
+    if training_mode and torch.is_grad_enabled():
+        # the reference back-propagates through the last denoising step (infer.py:99); the backward kernels are not built (SURVEY 8f-3).
+        # Under torch.no_grad() the FORWARD semantics of that mode are available: the last step's forwards draw the grad-mode branch
+        # fusion of every cross-attention layer (attention_processor.py:413-420), on the device, inside the captured step.
+        raise NotImplementedError("training_mode with autograd needs the backward kernels (SURVEY 8f-3); call under torch.no_grad() for the "
+                                  "forward semantics of the mode (random branch fusion on the last step)")
     device = torch.device(device)
     # infer.py:39-40 - the sampler is rebuilt from the loaded scheduler's config on every call
     sch = DPMSolverMultistepScheduler.from_config(scheduler.config)
@@ -88,7 +93,8 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
                                           "concept_text_embeddings": concept_text_embeddings,
                                           "concept_placeholder_idx": placeholder_idx})[0]
 
-    loop = _loop_for(unet, batch, latent_size, encoder_hidden_states_image.shape[1], timesteps, guidance_scale, sch)   # :98-119
+    loop = _loop_for(unet, batch, latent_size, encoder_hidden_states_image.shape[1], timesteps, guidance_scale, sch,     # :98-119
+                     training_mode=training_mode, fusion_seed=0 if seed is None else int(seed))
     loop.set_conditioning((encoder_hidden_states, encoder_hidden_states_image), (uncond_embeddings, uncond_encoder_hidden_states_image))
     loop.reset(noise)
     latents = loop.run().clone()

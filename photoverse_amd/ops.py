@@ -204,12 +204,13 @@ class Recorder:
         self._add(self.lib.pv_attention, p)
         return out
 
-    def cross_attention(self, q, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, vnorm=None, out=None):
+    def cross_attention(self, q, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, vnorm=None, out=None, fusion=None):
         if out is None:
             out = self.empty((batch * nq, heads * d), torch.float16)
         p = XAttnParams(_ptr(q), _rows(q)[0], _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0],
-                        _rows(vip)[0], _ptr(out), _rows(out)[0], _ptr(vnorm), batch, heads, nq, nt, nip, d, float(w_text), float(w_ip))
-        self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm) if t is not None)
+                        _rows(vip)[0], _ptr(out), _rows(out)[0], _ptr(vnorm), batch, heads, nq, nt, nip, d, float(w_text), float(w_ip),
+                        _ptr(fusion))
+        self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm, fusion) if t is not None)
         self._add(self.lib.pv_cross_attention, p)
         return out, p
 
@@ -345,6 +346,12 @@ class Recorder:
         self.keep.extend((eps_u, eps_c, latents, x0_prev, coef, state))
         self._add(self.lib.pv_cfg_dpm_step, _ptr(eps_u), _ptr(eps_c), _ptr(latents), _ptr(x0_prev), _ptr(coef), _ptr(state),
                   float(guidance), latents.numel())
+
+    def fusion_draw(self, state, rng, forced, out, *, n_layers, rule1, rule2, scale, only_last_step):
+        """Device-side grad-mode fusion draw (attention_processor.py:413-420 without the host sync): fills out[n_layers][2]."""
+        self.keep.extend(t for t in (state, rng, forced, out) if t is not None)
+        self._add(self.lib.pv_fusion_draw, _ptr(state), _ptr(rng), _ptr(forced), _ptr(out), n_layers, float(rule1), float(rule2), float(scale),
+                  int(only_last_step))
 
     def step_advance(self, state):
         self.keep.append(state)

@@ -21,12 +21,17 @@ from .scheduler import DPMSolverMultistepScheduler
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
-                 two_streams: bool = True, batch_splits: int = 1):
+                 two_streams: bool = True, batch_splits: int = 1, training_mode: bool = False, fusion_seed: int = 0):
+        """``training_mode``: the reference enables grad on the LAST denoising step only (infer.py:99), where every cross-attention
+        layer of both forwards then draws its branch fusion (attention_processor.py:413-420).  Here the draw runs on the device inside
+        the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps; the backward itself is
+        not built - this is the forward semantics of that mode."""
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
         self.unet, self.B, self.S, self.P, self.T = unet, batch, latent_size, n_ip, num_steps
         self.guidance = float(guidance_scale)
+        self.training_mode = bool(training_mode)
         sch = scheduler if scheduler is not None else DPMSolverMultistepScheduler()
         sch.set_timesteps(num_steps)
         self.scheduler = sch
@@ -55,10 +60,14 @@ class DenoiseLoop:
         for i in range(batch_splits):
             sl = slice(i * sb, (i + 1) * sb)
             kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text)
+            if training_mode:
+                kw.update(device_fusion="last_step")
+            fs = dict(fusion_seed=fusion_seed * 4096 + 2 * i) if training_mode else {}
+            fs2 = dict(fusion_seed=fusion_seed * 4096 + 2 * i + 1) if training_mode else {}
             self.engines_u.append(unet.engine(sb, latent_size, latent_size, n_ip, 1, text=self.text_u[i * sb * n_text:(i + 1) * sb * n_text],
-                                              ip=self.ip_u[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_u[sl], **kw))
+                                              ip=self.ip_u[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_u[sl], **kw, **fs))
             self.engines_c.append(unet.engine(sb, latent_size, latent_size, n_ip, 1, text=self.text_c[i * sb * n_text:(i + 1) * sb * n_text],
-                                              ip=self.ip_c[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_c[sl], **kw))
+                                              ip=self.ip_c[i * sb * n_ip:(i + 1) * sb * n_ip], out=self.eps_c[sl], **kw, **fs2))
         self.eng_u, self.eng_c = self.engines_u[0], self.engines_c[0]
         self.tail = Recorder(dev)
         self.tail.cfg_dpm_step(self.eps_u, self.eps_c, self.latents, self.x0_prev, self.coef, self.state, self.guidance)

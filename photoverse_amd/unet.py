@@ -192,7 +192,12 @@ class UNetEngine:
     def __init__(self, unet: "UNet2DConditionModel", batch: int, h: int, w: int, n_ip: int, t_rows: int, device,
                  timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
                  latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
-                 ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+                 ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, device_fusion: Optional[str] = None,
+                 fusion_seed: int = 0):
+        """``device_fusion``: None - branch weights (w_text, w_ip) are launch parameters patched by the host (``_set_fusion``);
+        ``"always"`` - every forward draws them on the device (grad-mode semantics of attention_processor.py:413-420, graph-safe);
+        ``"last_step"`` - drawn only when the loop state says this is the last denoising step (``run_inference(training_mode=True)``,
+        infer.py:99), (1, 1) otherwise."""
         self.unet, self.B, self.H, self.W, self.P, self.NT = unet, batch, h, w, n_ip, n_text
         cfg = unet.config
         rec = self.rec = Recorder(device)
@@ -210,6 +215,22 @@ class UNetEngine:
         self.out_buf = out
         self.vnorms: Dict[str, torch.Tensor] = {}
         self.xattn_params: Dict[str, object] = {}   # per-layer launch records: (w_text, w_ip) are patched per call in grad mode
+        self.device_fusion = device_fusion
+        self.fusion_tab = self.fusion_rng = self.fusion_forced = None
+        self.fusion_names = []
+        if device_fusion is not None:
+            if device_fusion not in ("always", "last_step"):
+                raise ValueError("device_fusion must be None, 'always' or 'last_step'")
+            procs = [m.processor for _, m in unet.named_modules() if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0)]
+            nl = len(procs)
+            self.fusion_tab = rec.hold(torch.ones((nl, 2), dtype=torch.float32, device=rec.device))
+            import numpy as np
+            key = np.array([fusion_seed & 0xFFFFFFFF, (fusion_seed >> 32) & 0xFFFFFFFF, 0, 0], dtype=np.uint32).view(np.int32)
+            self.fusion_rng = rec.hold(torch.from_numpy(key.copy()).to(rec.device))      # {key lo, key hi, launch count, -}
+            self.fusion_forced = rec.hold(torch.full((nl,), -1.0, dtype=torch.float32, device=rec.device))   # entries >= 0 replace the drawn u (tests)
+            p0 = procs[0]
+            rec.fusion_draw(self.state if device_fusion == "last_step" else None, self.fusion_rng, self.fusion_forced, self.fusion_tab, n_layers=nl,
+                            rule1=p0.fusion_rule1, rule2=p0.fusion_rule2, scale=float(p0.scale[0]), only_last_step=device_fusion == "last_step")
         self._build()
 
     # ------------------------------------------------------------------ blocks
@@ -254,6 +275,10 @@ class UNetEngine:
         kvip = self.rec_cond.gemm(self.ip, wkvip, rows_per_image=self.P)
         vnorm = rec.empty((b, heads, self.P), torch.float32)
         self.vnorms[name] = vnorm
+        fus = None
+        if self.fusion_tab is not None:                      # this layer's (w_text, w_ip) slot of the device-side draw
+            fus = self.fusion_tab[len(self.fusion_names)]
+            self.fusion_names.append(name)
         if USE_XFUSED and Recorder.xattn_fused_supported(C, heads, n, self.NT, self.P):
             # ONE launch for norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual (pv_xfused.hip); the K / V images and
             # to_v_ip_norm depend on the conditioning only (rec_cond)
@@ -261,13 +286,13 @@ class UNetEngine:
                                                      nip=self.P, vnorm=vnorm)
             hs, xp = rec.cross_attention_fused(hs, _f16(a2.to_q.weight), rec.pack_wo_for_fused(_f16(a2.to_out[0].weight)),
                                                _f32(a2.to_out[0].bias), kimg, vimg, batch=b, nq=n, heads=heads, d=d, nt=self.NT, nip=self.P,
-                                               ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias), ln_eps=blk.norm2.eps)
+                                               ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias), ln_eps=blk.norm2.eps, fusion=fus)
             self.xattn_params[name] = xp
         else:
             n2 = rec.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
             q = rec.gemm(n2, _f16(a2.to_q.weight), rows_per_image=n)
             xa, xp = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n, nt=self.NT,
-                                         nip=self.P, d=d, vnorm=vnorm)
+                                         nip=self.P, d=d, vnorm=vnorm, fusion=fus)
             self.xattn_params[name] = xp
             hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         # --- GEGLU feed-forward ---
@@ -431,6 +456,8 @@ class UNet2DConditionModel(nn.Module):
     def _set_fusion(self, eng: UNetEngine):
         """Per-layer branch weights: (1,1) under no_grad (attention_processor.py:411-412); in grad mode every cross-attn
         layer draws its own u~U(0,1) per call (:413-420) - host-side, like the reference's ``torch.rand(1).item()``."""
+        if eng.device_fusion is not None:
+            return
         for name, m in self.named_modules():
             if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0):
                 xp = eng.xattn_params[name.rsplit(".transformer_blocks", 1)[0]]

@@ -90,6 +90,85 @@ def test_processor_protocol_standalone(tiny_pair):
         assert rel_l2(ha1(h.cuda()), ra1(h)) < 2e-3
 
 
+def test_training_shaped_forward_with_device_side_fusion(tiny_pair):
+    """The forward a training step needs (train.py:495-506): P = 5 image tokens, per-sample timesteps (B,), and the grad-mode branch
+    fusion of every cross-attention layer (attention_processor.py:413-420) drawn ON THE DEVICE (pv_fusion_draw) instead of the
+    reference's per-layer `torch.rand(1).item()` host sync.  Forced u values per layer -> parity with the oracle in grad mode; free
+    draws -> valid, changing, seed-reproducible."""
+    ref, hip = tiny_pair
+    g = torch.Generator().manual_seed(17)
+    B, P = 2, 5
+    x, text, ip = torch.randn(B, 4, 16, 16, generator=g), torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g)
+    t = torch.tensor([37, 911])
+    eng = hip.engine(B, 16, 16, P, B, device_fusion="always", fusion_seed=1234)
+    assert len(eng.fusion_names) == 4 and eng.fusion_tab.shape == (4, 2)
+    eng.x_in.copy_(x); eng.text.copy_(text.reshape(-1, 768)); eng.ip.copy_(ip.reshape(-1, 768)); eng.timesteps.copy_(t.float())
+    forced = [0.1, 0.5, 0.9, 0.3]                                   # -> (2,0), (1,1), (0,2), (2,0)
+    eng.fusion_forced.copy_(torch.tensor(forced))
+    got = eng.run().clone().cpu()
+    assert eng.fusion_tab.cpu().tolist() == [[2.0, 0.0], [1.0, 1.0], [0.0, 2.0], [2.0, 0.0]]
+    mods = dict(ref.named_modules())
+    for name, u in zip(eng.fusion_names, forced):
+        mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = u
+    try:
+        with torch.enable_grad():
+            exp = ref(x, t, encoder_hidden_states=(text, ip)).sample.detach()
+    finally:
+        for name in eng.fusion_names:
+            mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = None
+    assert rel_l2(got, exp) < TOL_FWD
+    with torch.no_grad():                                           # and it is NOT the no_grad result
+        assert rel_l2(got, ref(x, t, encoder_hidden_states=(text, ip)).sample) > 10 * TOL_FWD
+    # free draws: every row follows the rule, the pattern changes between launches, and is a function of (seed, launch index)
+    eng.fusion_forced.fill_(-1.0)
+    valid = {(2.0, 0.0), (0.0, 2.0), (1.0, 1.0)}
+    seq = []
+    for _ in range(12):
+        eng.run()
+        rows = [tuple(r) for r in eng.fusion_tab.cpu().tolist()]
+        assert set(rows) <= valid
+        seq.append(tuple(rows))
+    assert len(set(seq)) > 3 and eng.fusion_rng[2].item() == 13
+    counts = {v: sum(r == v for rows in seq for r in rows) for v in valid}
+    assert all(c >= 4 for c in counts.values()), counts             # 48 draws, three outcomes of probability 1/3 each
+    eng2 = hip.engine(B, 16, 16, P, B, device_fusion="always", fusion_seed=1234)
+    eng2.x_in.copy_(x); eng2.text.copy_(text.reshape(-1, 768)); eng2.ip.copy_(ip.reshape(-1, 768)); eng2.timesteps.copy_(t.float())
+    eng2.run()                                                      # launch 0 was the forced one above
+    seq2 = []
+    for _ in range(3):
+        eng2.run()
+        seq2.append(tuple(tuple(r) for r in eng2.fusion_tab.cpu().tolist()))
+    assert seq2 == seq[:3]
+
+
+def test_training_mode_loop_fuses_on_the_last_step_only(tiny_pair):
+    """run_inference(training_mode=True) forward semantics (infer.py:99): only the LAST denoising step runs its forwards in grad
+    mode.  One captured graph serves all steps; the device-side draw is keyed on the step counter."""
+    from photoverse_amd.pipeline import DenoiseLoop
+    _, hip = tiny_pair
+    g = torch.Generator().manual_seed(23)
+    B, P, T = 2, 5, 3
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    plain = DenoiseLoop(hip, B, 16, P, T, 3.0)
+    plain.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+    plain.reset(noise)
+    train = DenoiseLoop(hip, B, 16, P, T, 3.0, training_mode=True, fusion_seed=5)
+    train.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+    train.reset(noise)
+    ones = [[1.0, 1.0]] * 4
+    for step in range(T):
+        plain.step(); train.step()
+        tabs = [e.fusion_tab.cpu().tolist() for e in train.engines_u + train.engines_c]
+        if step < T - 1:
+            assert all(tb == ones for tb in tabs)
+            assert torch.equal(plain.latents, train.latents)        # identical until the last step
+        else:
+            assert any(tb != ones for tb in tabs) and tabs[0] != tabs[1]     # 8 draws: uncond / cond forwards draw independently
+            assert not torch.equal(plain.latents, train.latents) and torch.isfinite(train.latents).all()
+
+
 def test_cpu_tensor_is_refused(tiny_pair):
     _, hip = tiny_pair
     with pytest.raises(RuntimeError, match="no CPU path"):
