@@ -77,7 +77,8 @@ typedef struct pv_gemm_params {
     float* splitk_ws;      /* fp32 workspace [splitk][M][N] for the partial slabs, reduced in fixed order */
     float* colstats;       /* optional fp32 [ceil(M/64)][2][N]: per 64-row block and output column, the sum and the sum of
                               squares of the (fp16-rounded) outputs - GroupNorm statistics of the tensor being written,
-                              consumed by pv_groupnorm_stats_from_colstats.  NULL = off.  fp16 output, no geglu, splitk <= 1. */
+                              consumed by pv_groupnorm_stats_from_colstats.  NULL = off.  fp16 output, no geglu (with splitk > 1 the
+                              reduce launch produces them). */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 

@@ -422,32 +422,68 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
     }
 }
 
-// sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue
-__global__ void splitk_reduce_kernel(const pv_gemm_params_dev p, const int splits) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nq = p.N >> 2;
-    if (idx >= (long)p.M * nq) return;
-    const int m = (int)(idx / nq), n = (int)(idx - (long)m * nq) * 4;
-    float4_t v = float4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const float4_t*>(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
-    if (p.bias) v += *reinterpret_cast<const float4_t*>(p.bias + n);
-    if (p.rowadd) v += *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(m / (p.hout * p.wout)) * p.rowadd_ld + n);
-    if (p.act) {
+// Sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue.  One workgroup = 64 rows x 64 columns
+// (thread = 4 rows x 4 columns), so that it can also leave the GroupNorm column statistics of its block behind
+// (pv_gemm_params.colstats: per 64-row block and column, sum and sum of squares of the fp16-rounded outputs) - the split-K layers
+// (16x16 / 8x8 levels) then need no statistics pass either.
+// An in-kernel reduction by the tile's last-arriving K-slice (arrival ticket + agent-scope release / acquire) was built and
+// measured in round 2: correct and deterministic, but the 80-KB-per-slice slab hand-off made the 8x8-level convs 2x slower
+// (104 vs 50 us) - the "splitk-seam" result of MI355X_MICROARCH.md; the separate launch stays.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const pv_gemm_params_dev p, const int splits) {
+    __shared__ float red[2][16][64];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;           // column quad, row group
+    const int n = (int)blockIdx.x * 64 + cq * 4;
+    const int mb = (int)blockIdx.y * 64 + rg * 4;
+    const bool ncol = n < p.N;
+    float4_t cs = float4_t{0.f, 0.f, 0.f, 0.f}, cq2 = float4_t{0.f, 0.f, 0.f, 0.f};
+    if (ncol) {
+        const float4_t bias = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + n) : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + r;
+            if (m >= p.M) break;
+            float4_t v = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const float4_t*>(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
+            v += bias;
+            if (p.rowadd) v += *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(m / (p.hout * p.wout)) * p.rowadd_ld + n);
+            if (p.act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = epi_act(v[j], p.act);
+            }
+            if (p.residual) {
+                const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+            }
+            if (p.out_f32) {
+                *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+            } else {
+                half4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (half_t)v[j];
+                    const float f = (float)o[j];
+                    cs[j] += f;
+                    cq2[j] += f * f;
+                }
+                *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+            }
+        }
     }
-    if (p.residual) {
-        const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)m * p.ldr + n);
+    if (p.colstats == nullptr) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+    for (int j = 0; j < 4; ++j) {
+        red[0][rg][cq * 4 + j] = cs[j];
+        red[1][rg][cq * 4 + j] = cq2[j];
     }
-    if (p.out_f32) {
-        *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
-    } else {
-        half4_t o;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+        for (int g = 0; g < 16; ++g) a += red[which][g][col];            // fixed order
+        const int nn = (int)blockIdx.x * 64 + col;
+        if (nn < p.N) p.colstats[((size_t)blockIdx.y * 2 + which) * p.N + nn] = a;
     }
 }
 
@@ -474,10 +510,8 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     const int m_fast = order_env >= 0 ? order_env : ((wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0);
     const int splits = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
-    if (splits > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
-    }
+    if (splits > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, stream, p, splits);
     return PV_CHECK_LAUNCH();
 }
 
@@ -485,7 +519,7 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
     if constexpr (!GEGLU) {
-        if (p.colstats) return launch<NF, CONV, false, true>(p, stream);
+        if (p.colstats && !(p.splitk > 1 && p.splitk_ws)) return launch<NF, CONV, false, true>(p, stream);   // split-K: the reduce launch makes them
     }
     return launch<NF, CONV, GEGLU>(p, stream);
 }
@@ -501,7 +535,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     if (p.M <= 0 || p.N <= 0 || cin <= 0 || (cin % 64) || (p.c0 % 64) || (p.taps != 1 && p.taps != 9) || p.act == PV_ACT_GELU || p.splitk < 0 || p.splitk > 16 ||
         !p.a0 || !p.w || !p.out || (p.c1 && !p.a1) || p.hout * p.wout <= 0)
         return (int)hipErrorInvalidValue;
-    if (p.colstats && (p.geglu || p.out_f32 || (p.splitk > 1 && p.splitk_ws))) return (int)hipErrorInvalidValue;
+    if (p.colstats && (p.geglu || p.out_f32)) return (int)hipErrorInvalidValue;
     if (p.taps == 9 && !(p.pad == 1 || (p.pad == 0 && p.stride == 2 && !p.upsample))) return (int)hipErrorInvalidValue;
     {
         const size_t a_rows = p.taps == 9 ? (size_t)p.batch * p.hin * p.win : (size_t)p.M;

@@ -119,7 +119,8 @@ class Recorder:
              colstats: bool = False) -> torch.Tensor:
         """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin].
         ``colstats``: the output feeds a GroupNorm - let the epilogue leave its per-column (sum, sum of squares) behind so that
-        ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: split-K, fp32, GEGLU)."""
+        ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: fp32, GEGLU; with split-K the
+        reduce launch produces them)."""
         lda0, c0 = _rows(a)
         lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
         taps = 9 if conv is not None else 1
@@ -149,7 +150,7 @@ class Recorder:
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)
-        if colstats and splitk == 1 and not geglu and not out_f32 and ldc == n_out and not _NO_COLSTATS:
+        if colstats and not geglu and not out_f32 and ldc == n_out and not _NO_COLSTATS:
             cs = self.colstats[key] = self.empty(((M + 63) // 64, 2, N), torch.float32)
         else:
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
@@ -159,7 +160,7 @@ class Recorder:
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS>
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
-                f"{'true' if cs is not None else 'false'}>")
+                f"{'true' if (cs is not None and splitk == 1) else 'false'}>")
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 
