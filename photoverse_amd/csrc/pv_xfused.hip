@@ -8,22 +8,28 @@
 // read of hs and one write of out.  Built for the C = 320 / d = 40 layers (64x64 and larger levels: 63 % of attn2's launches'
 // time at 512x512), where M = B*N is large and the GEMMs are too short-K to run well on their own.
 //
-// Structure: one workgroup = 128 query rows x ALL heads = 8 waves in a 4 (rows) x 2 (features) grid, one workgroup per CU with
-// all 160 KiB of LDS.  A wave owns 32 query rows (two 16-column MFMA operands) and half of the features (two groups of two
-// heads) for the whole chain; activations stay in registers except one exchange of the context fragments between the two wave
-// columns before to_out:
+// Structure: one workgroup = 128 query rows x ALL heads, 4 waves, 78 KiB of LDS -> two workgroups per CU.  A wave owns 32 query
+// rows (two 16-column MFMA operands) for the whole chain, so no activation ever leaves the register file:
 //
 //   phase 0  X^T (B operand of v_mfma_f32_16x16x32_f16: lane = query, 8 consecutive channels per k-group) is loaded straight
-//            into registers; LayerNorm statistics are 80 in-lane adds + a 4-lane swap reduction; normalised in place.
-//   phase 1  Q^T[n][q] = Wq[n][:] . X^T : Wq streams through a 4-stage LDS ring (one 80-row x 64-k tile per wave column and
-//            stage, LDS-DMA, counted vmcnt, one raw s_barrier per stage); the accumulator layout (lane = query, 4 consecutive features per k-group)
+//            into registers; LayerNorm statistics by v_dot2_f32_f16 + a 4-lane swap reduction; normalised in place (its affine
+//            part is folded into Wq / a query bias by the caller).
+//   phase 1  Q^T[n][q] = Wq[n][:] . X^T : Wq streams through a 3-stage LDS ring (80 rows x 64 k per stage, LDS-DMA, counted
+//            vmcnt, one raw s_barrier per stage); the accumulator layout (lane = query, 4 consecutive features per k-group)
 //            IS the next product's B operand once converted to fp16 - with a permuted contraction order, which the K image
-//            and the columns of Wo are pre-permuted to match on the host / in pv_xattn_pack_kv.
+//            and the columns of Wo are pre-permuted to match (pv_xattn_pack_kv / pv_xattn_fused_wo_slot).
 //   phase 2  per 80-feature group (= 2 heads of 40): S^T = K.Q^T (K image rows from LDS), two independent softmaxes in
-//            registers, O^T = V^T.P^T (V^T fragments by ds_read_b64_tr_b16); the K/V images of the sample are prefetched by
-//            LDS-DMA (first pair at kernel start, second pair into the idle Wq ring).  The 2.5-fragment head boundary needs no padding: fragment 2 of a group is computed for both
-//            heads and merged by lane group.
-//   phase 3  out^T[n][q] = Wo'[n][:] . ctx^T through the same ring; epilogue adds bias + residual and stores fp16.
+//            registers, O^T = V^T.P^T (V^T fragments by ds_read_b64_tr_b16); the K/V images of the (sample, group) are LDS-DMA
+//            double-buffered (group 0 is prefetched at kernel start).  The 2.5-fragment head boundary needs no padding:
+//            fragment 2 of a group is computed for both heads and merged by lane group.
+//   phase 3  out^T[n][q] = Wo'[n][:] . ctx^T through the same kind of ring (prefetched during the last group); the epilogue adds
+//            bias + residual (requested at the start of each 80-column chunk) and stores fp16.
+//
+// Measured (MI355X, B=16, N=4096): 78 us vs 118 us for the four launches; 430 TFLOP/s = 17 % of the dense fp16 MFMA peak.  Where the
+// rest goes (tools/diag/xfused_stamps.py): every workgroup of the single wave of 512 runs the same phases at the same time, so the
+// HBM phases (X load, output store) and the MFMA phases do not overlap chip-wide; phase 2 issues ~3300 VALU instructions per wave
+// (two softmaxes over 96 keys per head) against 336 MFMAs.  An 8-wave / one-workgroup-per-CU variant (features split over two wave
+// columns, context exchanged through LDS) measured 82 us: a workgroup barrier costs ~400 cycles when all waves of a CU run in lockstep.
 #include "pv_common.h"
 
 namespace {
@@ -128,30 +134,28 @@ struct pv_xfused_params_dev : pv_xattn_fused_params {
 };
 
 template <int C>
-__global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_params_dev p) {
-    static_assert(C == 4 * GF, "the 4 x 2 wave grid splits exactly four 80-feature groups over two wave columns");
+__global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_params_dev p) {
+    static_assert(C % GF == 0 && C % 64 == 0, "C must be a multiple of 80 and of 64");
     constexpr int D = 40;
     constexpr int NG = C / GF;        // feature groups (pairs of heads): 4
-    constexpr int LF = 10;            // 16-feature fragments one wave column owns (two groups)
-    constexpr int NFR = C / 16;       // fragments per row: 20
+    constexpr int NFR = C / 16;       // 16-feature fragments per row: 20
     constexpr int KK = C / 32;        // 32-deep contraction steps over C: 10
     constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk: 5
-    constexpr int NT = 2 * KT;        // ring stages per GEMM phase (two 80-row chunks per wave column): 10
-    constexpr int S = 4;              // ring depth
-    constexpr int TILE_BYTES = GF * 128;                   // 80 weight rows x 64 k
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;            // one tile per wave column
+    constexpr int NT = NG * KT;       // ring stages per GEMM phase: 20
+    constexpr int S = 3;              // ring depth
+    constexpr int TILE_BYTES = GF * 128;                   // one stage: 80 weight rows x 64 k = 10 KiB
     constexpr int KIMG_BYTES = XK * KROW;                  // one head
     constexpr int VIMG_BYTES = XK * GF * 2;
-    constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;   // 39 KiB
+    constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;   // K images of the group's two heads + V image: 39 KiB
     constexpr int GROUP_PIECES = GROUP_BYTES / 1024;
-    constexpr int REGION = S * STAGE_BYTES;                // 80 KiB; the kernel uses two such regions = all 160 KiB of the CU
-    static_assert(GROUP_BYTES % 1024 == 0 && 2 * GROUP_BYTES <= REGION && 4 * NFR * 2 * 64 * 8 <= REGION, "LDS plan");
+    static_assert(GROUP_BYTES % 1024 == 0 && S * TILE_BYTES <= GROUP_BYTES, "LDS plan: a weight ring fits inside one K/V buffer");
+    // LDS: two 39-KiB buffers.  Buffer 0 = Wq ring (phase 1), K/V of groups 1 and 3; buffer 1 = K/V of groups 0 and 2, Wo ring (phase 3).
+    // 78 KiB per workgroup -> TWO independent workgroups per CU (each other's barrier / DMA / HBM waits are covered, as in the GEMM).
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const regA = smem;             // phase 1: Wq ring | phase 2 step 1: K/V images | exchange of the context fragments
-    char* const regB = smem + REGION;    // phase 2 step 0: K/V images | phase 3: Wo ring
+    char* const buf0 = smem;
+    char* const buf1 = smem + GROUP_BYTES;
 
     const int lane = pv_lane_id(), wave = pv_wave_id();
-    const int wm = wave >> 1, wn = wave & 1;    // 4 x 2 wave grid: wm = 32-row block, wn = half of the features (two groups)
     const int fr = lane & 15, g = lane >> 4;
     const int m0 = (int)blockIdx.x * 128;
     const int b = m0 / p.nq;
@@ -165,70 +169,75 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_par
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vimg), 0, (int)p.vimg_bytes, 0x00020000);
 
     // ---- LDS-DMA issue helpers (one piece = one wave instruction = 1 KiB) -----------------------------------------------
-    // Ring stage t of a [C][C] weight: for wave column c in {0,1} the tile rows [80 (2c + t/KT), +80) x k [64 (t%KT), +64) at
-    // stage offset c * TILE_BYTES.  20 pieces of 8 rows x 128 B.  Swizzle on the source:
-    // LDS position (lane & 7) of row r holds chunk (lane & 7) ^ (r & 7).
+    // Ring stage t of a [C][C] weight: rows [80 (t/KT), +80) x k [64 (t%KT), +64); 10 pieces of 8 rows x 128 B: waves 0,1 issue 3,
+    // waves 2,3 issue 2.  Swizzle on the source: LDS position (lane & 7) of row r holds chunk (lane & 7) ^ (r & 7).
     const int lrow = lane >> 3;
     const unsigned w_lane_off = (unsigned)lrow * (unsigned)(C * 2) + (unsigned)(((lane & 7) ^ lrow) << 4);
-    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rw, char* region, int t) {
-        if (wave >= 4) return;                                // waves 0-3 are the DMA issuers (5 pieces each), see below
-        const int kt = t % KT, half = t / KT;
-        char* dst = region + (t % S) * STAGE_BYTES;
+    // per-lane part of the source offset of this wave's (up to) three pieces: stage-invariant VGPRs; the stage part goes into the
+    // instruction's scalar offset (otherwise the compiler keeps 60 per-stage offsets alive from phase 1 to phase 3 and spills them)
+    unsigned piece_off[3];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int j = wave + 4 * i;                       // piece 0..19
-            const int col = j / 10, pj = j - col * 10;        // wave column, 8-row piece inside its tile
-            const unsigned row = (unsigned)((2 * col + half) * GF + pj * 8);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + j * 1024), 16, (int)(row * (unsigned)(C * 2) + (unsigned)(kt * 128) + w_lane_off), 0, 0, 0);
-        }
-    };
-    // K/V images of step st: group st (wave column 0) at offset 0, group 2 + st (wave column 1) at GROUP_BYTES; linear copies
-    // (the images are stored in LDS order).  78 pieces: waves 0,1 issue 20, waves 2,3 issue 19.
-    // Only waves 0-3 issue LDS-DMA: each SIMD hosts waves w and w + 4, which run the same program between the same barriers; if both
-    // stopped to issue (an LDS-DMA piece costs the issuing wave ~70 cycles) the SIMD's matrix pipe would idle - this way wave w + 4
-    // keeps issuing MFMAs while wave w feeds the ring.
-    auto issue_kv = [&](char* region, int st) {
-        if (wave >= 4) return;
+    for (int i = 0; i < 3; ++i) piece_off[i] = w_lane_off + (unsigned)((wave + 4 * i) * 8) * (unsigned)(C * 2);
+    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rw, char* ring, int t) {
+        const int nc = t / KT, kt = t % KT;
+        char* dst = ring + (t % S) * TILE_BYTES;
+        const int soff = nc * GF * (C * 2) + kt * 128;
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
+        for (int i = 0; i < 3; ++i) {
             const int j = wave + 4 * i;
-            if (j < 2 * GROUP_PIECES) {
-                const int col = j / GROUP_PIECES, pj = j - col * GROUP_PIECES;
-                const int grp = 2 * col + st;
-                if (pj < 2 * KIMG_BYTES / 1024)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(region + j * 1024), 16,
-                                                             (int)((unsigned)((b * (NG * 2) + 2 * grp) * KIMG_BYTES) + (unsigned)pj * 1024u + (unsigned)lane * 16u), 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(region + j * 1024), 16,
-                                                             (int)((unsigned)((b * NG + grp) * VIMG_BYTES) + (unsigned)(pj - 2 * KIMG_BYTES / 1024) * 1024u + (unsigned)lane * 16u), 0, 0, 0);
-            }
+            if (i < 2 || wave < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + j * 1024), 16, (int)piece_off[i], soff, 0, 0);
         }
     };
-    // wait until this wave's pieces of everything but the `y` youngest ring stages have landed (issuing waves only)
-    auto wait_stages = [&](int y) {
-        if (wave < 4) { if (y >= 4) xf_wait_vmcnt<20>(); else if (y == 3) xf_wait_vmcnt<15>(); else if (y == 2) xf_wait_vmcnt<10>(); else if (y == 1) xf_wait_vmcnt<5>(); else xf_wait_vmcnt<0>(); }
+    // K/V images of (sample b, group grp): a linear 39-KiB copy (the images are stored in LDS order): waves 0-2 issue 10 pieces, wave 3: 9
+    auto issue_group = [&](int grp, char* dst) {
+        const unsigned kbase = (unsigned)((b * (NG * 2) + 2 * grp) * KIMG_BYTES) + (unsigned)lane * 16u;
+        const unsigned vbase = (unsigned)((b * NG + grp) * VIMG_BYTES) + (unsigned)lane * 16u;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int j = wave + 4 * i;
+            if (j < 2 * KIMG_BYTES / 1024)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(dst + j * 1024), 16, (int)(kbase + (unsigned)j * 1024u), 0, 0, 0);
+            else if (j < GROUP_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(dst + j * 1024), 16, (int)(vbase + (unsigned)(j - 2 * KIMG_BYTES / 1024) * 1024u), 0, 0, 0);
+        }
+    };
+    // vmcnt bookkeeping in units of "this wave's pieces": ring stage = 3 (waves 0,1) or 2; K/V group = 10 (waves 0-2) or 9
+    auto wait_except = [&](int stages, int groups) {       // wait for everything but the youngest `stages` ring stages + `groups` K/V groups
+        const int n = stages * (wave < 2 ? 3 : 2) + groups * (wave < 3 ? 10 : 9);
+        switch (n) {   // wave-uniform; the counts that occur
+            case 0: xf_wait_vmcnt<0>(); break;
+            case 2: xf_wait_vmcnt<2>(); break;
+            case 3: xf_wait_vmcnt<3>(); break;
+            case 4: xf_wait_vmcnt<4>(); break;
+            case 6: xf_wait_vmcnt<6>(); break;
+            case 9: xf_wait_vmcnt<9>(); break;
+            case 10: xf_wait_vmcnt<10>(); break;
+            case 13: xf_wait_vmcnt<13>(); break;   // 2 stages (waves 2,3: 4) + group (wave 3: 9)
+            case 14: xf_wait_vmcnt<14>(); break;   // waves 2: 4 + 10
+            case 15: xf_wait_vmcnt<15>(); break;   // 2 stages x 3 (waves 0,1) + ... not reached; kept for safety
+            case 16: xf_wait_vmcnt<16>(); break;   // waves 0,1: 6 + 10
+            default: xf_wait_vmcnt<0>(); break;
+        }
     };
     auto wg_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads / writes are retired
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads are retired
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-    // ---- phase 0: X^T into registers (+ LayerNorm); the first Wq stages and the first K/V images are already on their way ---
+    // ---- phase 0: X^T into registers (+ LayerNorm) -----------------------------------------------------------------------
     half8_t xf[KK][2];
     int mrow[2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        mrow[qi] = m0 + wm * 32 + qi * 16 + fr;
+        mrow[qi] = m0 + wave * 32 + qi * 16 + fr;
         const half_t* src = hs + (size_t)mrow[qi] * p.ld_hs + g * 8;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = *reinterpret_cast<const half8_t*>(src + kk * 32);
     }
-    issue_kv(regB, 0);
-    issue_stage(rq, regA, 0);
-    issue_stage(rq, regA, 1);
-    issue_stage(rq, regA, 2);
-    issue_stage(rq, regA, 3);
+    issue_group(0, buf1);                 // K/V of group 0 waits in buffer 1 while the Wq ring runs in buffer 0
+    issue_stage(rq, buf0, 0);
+    issue_stage(rq, buf0, 1);
     if (p.ln) {
         // LayerNorm WITHOUT its affine part (the caller folds gamma into the columns of wq and beta into q_bias):
         // x^ = x * rstd - mean * rstd, one mixed-precision FMA per element (fp16 in, fp32 math, fp16 out).  Statistics: the row sum
@@ -264,76 +273,57 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_par
                 for (int j = 0; j < 8; ++j) xf[kk][qi][j] = (half_t)fmaf((float)xf[kk][qi][j], rstd, nmr);
         }
     }
-    // The register loads above made the compiler wait; make the hand-counted DMA bookkeeping start from a known state too:
-    // everything issued so far (K/V step 0 included) has landed after this wait.
+    // The register loads above made the compiler wait; start the hand-counted DMA bookkeeping from a known state too:
+    // everything issued so far (K/V group 0 and the first two Wq stages) has landed after this wait.
     xf_wait_vmcnt<0>();
 
-    // ---- phase 1: Q^T = Wq . X^T for this wave column's 160 features -----------------------------------------------------
-    // qf[l][qi]: fp16 of local fragment l (features 160 wn + 16 l + 4g + r) for this lane's query, pre-scaled by log2(e)/sqrt(d)
-    half4_t qf[LF][2];
+    // Fragment reads of a ring: row 16 i + fr, chunk (4 ks + g) ^ (fr & 7): two per-lane bases (ks = 0 / 1) + compile-time offsets
+    const int ring_lane[2] = {fr * 128 + ((g ^ (fr & 7)) << 4), fr * 128 + (((4 + g) ^ (fr & 7)) << 4)};
+
+    // ---- phase 1: Q^T = Wq . X^T -----------------------------------------------------------------------------------------
+    // qf[f][qi]: fp16 of fragment f (features 16 f + 4g + r) for this lane's query, pre-scaled by log2(e)/sqrt(d)
+    half4_t qf[NFR][2];
     const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
-    // Ring schedule (phases 1 and 3), as in the GEMM kernel: a 64-deep stage is two 32-deep halves H0 / H1 and the workgroup
-    // barrier sits BETWEEN them, so the fragment reads of one half overlap the MFMAs of the other:
-    //     read H1(t) | MFMA H0(t)  ->  stage t+1 landed, lgkmcnt(0), s_barrier, refill buffer t with stage t+S  ->  read H0(t+1) | MFMA H1(t)
-    // Fragment reads of the ring: row 16 i + fr, chunk (4 ks + g) ^ (fr & 7) - every address is one of two per-lane bases (ks = 0 / 1)
-    // plus a compile-time offset (stage, fragment), so each read is ONE instruction (ds_read_b128 with an immediate offset < 64 KiB);
-    // left to itself the compiler rebuilt most addresses with VALU / SALU adds and the ring stages were instruction-issue bound.
-    const int ring_lane[2] = {wn * TILE_BYTES + fr * 128 + ((g ^ (fr & 7)) << 4), wn * TILE_BYTES + fr * 128 + (((4 + g) ^ (fr & 7)) << 4)};
-    auto read_half = [&](half8_t (&a)[5], const char* region, int t, int ks) {
-        const char* base = region + ring_lane[ks];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8_t*>(base + (t % S) * STAGE_BYTES + i * 2048);
-    };
     {
         float4_t acc[5][2];
-        half8_t a0[5], a1[5];
-        wg_barrier();                      // stage 0 (drained above) is visible to every wave
-        read_half(a0, regA, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int kt = t % KT;
+            const int nc = t / KT, kt = t % KT;
             if (kt == 0) {
                 // accumulators start from the query bias (beta of the folded LayerNorm pushed through to_q), rows 4g..4g+3 of each fragment
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    acc[i][0] = acc[i][1] = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + (2 * wn + t / KT) * GF + i * 16 + g * 4)
-                                                      : float4_t{0.f, 0.f, 0.f, 0.f};
+                    acc[i][0] = acc[i][1] = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + nc * GF + i * 16 + g * 4) : float4_t{0.f, 0.f, 0.f, 0.f};
             }
-            read_half(a1, regA, t, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (t >= 1) wait_except(t + 1 < NT ? 1 : 0, 0);       // stage t landed; stage t+1 (issued an iteration ago) may be in flight
+            wg_barrier();                                          // ... for every wave, and buffer (t-1) % S is read out
+            if (t + 2 < NT) issue_stage(rq, buf0, t + 2);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* base = buf0 + (t % S) * TILE_BYTES + ring_lane[ks];
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], xf[2 * kt][qi], acc[i][qi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < NT) {
-                wait_stages((t + S - 1 < NT ? t + S - 1 : NT - 1) - (t + 1));   // stage t+1 landed; the later issued ones may be in flight
-                wg_barrier();                                                     // ... for every wave, and buffer t % S is read out
-                if (t + S < NT) issue_stage(rq, regA, t + S);
-                __builtin_amdgcn_sched_barrier(0);
-                read_half(a0, regA, t + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 5; ++i) {
+                    const half8_t a = *reinterpret_cast<const half8_t*>(base + i * 2048);
+#pragma unroll
+                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[2 * kt + ks][qi], acc[i][qi], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], xf[2 * kt + 1][qi], acc[i][qi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
             if (kt == KT - 1) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) qf[(t / KT) * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
+                        for (int r = 0; r < 4; ++r) qf[nc * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
             }
         }
     }
 
-    // ---- phase 2: dual-branch attention; this wave column's two 80-feature groups (two heads each) ------------------------
-    wg_barrier();                          // every wave is done with the Wq ring (region A)
-    issue_kv(regA, 1);                     // K/V images of step 1 land while step 0 computes out of region B
-    half4_t cf[LF][2];                     // context fragments, same layout as qf
+    // ---- phase 2: dual-branch attention, one 80-feature group (two heads) at a time; K/V double-buffered ------------------
+    // group g lives in buffer (g + 1) & 1: group 0 was prefetched into buffer 1 at kernel start
+    wg_barrier();                          // every wave is done with the Wq ring (buffer 0)
+    issue_group(1, buf0);
+    half4_t cf[NFR][2];                    // context fragments, same layout as qf
     bool tmask[4], imask[4];               // validity of this lane's keys in fragment 4 (text tail) and fragment 5 (image tokens)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -341,23 +331,19 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_par
         imask[r] = g * 4 + r < p.nip;
     }
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        if (st == 1) {
-            wg_barrier();                  // every wave is done with region B: prefetch the first Wo stages into it
-            issue_stage(ro, regB, 0);
-            issue_stage(ro, regB, 1);
-            issue_stage(ro, regB, 2);
-            issue_stage(ro, regB, 3);
-            wait_stages(4);                // all but the four Wo stages: the K/V images of step 1 landed
-            wg_barrier();
-        }
-        const char* sbuf = (st == 0 ? regB : regA) + wn * GROUP_BYTES;
+    for (int grp = 0; grp < NG; ++grp) {
+        // group grp landed; in flight behind it: group grp+1 (grp < 3); at grp == 3 additionally the three Wo stages issued after group 2
+        if (grp == 0) wait_except(0, 1);
+        else if (grp < NG - 1) { wait_except(0, 1); }
+        else wait_except(2, 0);
+        wg_barrier();
+        const char* sbuf = ((grp + 1) & 1) ? buf1 : buf0;
         const half_t* sV = reinterpret_cast<const half_t*>(sbuf + 2 * KIMG_BYTES);
         float4_t o2_h0[2];                 // head 0's fragment 2 (its rows 0-7 are head 0's features 32..39)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const char* sK = sbuf + hh * KIMG_BYTES;
-            const int fa = st * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = st * 5 + 2;
+            const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
             float4_t s[6][2];
 #pragma unroll
             for (int kb = 0; kb < 6; ++kb) s[kb][0] = s[kb][1] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -432,55 +418,39 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_par
                 if (hh == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cf[st * 5 + 0][qi][r] = (half_t)o[0][qi][r];
-                        cf[st * 5 + 1][qi][r] = (half_t)o[1][qi][r];
+                        cf[grp * 5 + 0][qi][r] = (half_t)o[0][qi][r];
+                        cf[grp * 5 + 1][qi][r] = (half_t)o[1][qi][r];
                     }
                     o2_h0[qi] = o[2][qi];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cf[st * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
-                        cf[st * 5 + 3][qi][r] = (half_t)o[1][qi][r];
-                        cf[st * 5 + 4][qi][r] = (half_t)o[2][qi][r];
+                        cf[grp * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
+                        cf[grp * 5 + 3][qi][r] = (half_t)o[1][qi][r];
+                        cf[grp * 5 + 4][qi][r] = (half_t)o[2][qi][r];
                     }
                 }
             }
         }
+        if (grp + 2 < NG) {
+            wg_barrier();                  // every wave is done with this buffer: refill it with group grp + 2
+            issue_group(grp + 2, ((grp + 1) & 1) ? buf1 : buf0);
+        } else if (grp == NG - 2) {
+            wg_barrier();                  // buffer 1 (group 2) is free: the Wo ring starts there while group 3 computes out of buffer 0
+            issue_stage(ro, buf1, 0);
+            issue_stage(ro, buf1, 1);
+        }
     }
 
-    // ---- exchange: every wave needs the context fragments of BOTH wave columns for the to_out contraction -----------------
-    wg_barrier();                          // every wave is done with the K/V images in region A
-    {
-        half4_t* xch = reinterpret_cast<half4_t*>(regA) + (size_t)wm * (NFR * 2 * 64) + lane;   // [wm][fragment][qi][lane]
-#pragma unroll
-        for (int l = 0; l < LF; ++l)
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) xch[((wn * LF + l) * 2 + qi) * 64] = cf[l][qi];
-    }
-    wg_barrier();
-    half4_t ca[NFR][2];
-    {
-        const half4_t* xch = reinterpret_cast<const half4_t*>(regA) + (size_t)wm * (NFR * 2 * 64) + lane;
-#pragma unroll
-        for (int f = 0; f < NFR; ++f)
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) ca[f][qi] = xch[(f * 2 + qi) * 64];
-    }
-
-    // ---- phase 3: out^T = Wo' . ctx^T for this wave column's 160 output features, + bias + residual ----------------------
+    // ---- phase 3: out^T = Wo' . ctx^T, + bias + residual ----------------------------------------------------------------
     {
         half_t* outp = reinterpret_cast<half_t*>(p.out);
         float4_t acc[5][2];
         half4_t res[5][2];
-        half8_t a0[5], a1[5];
-        // stages 0..3 were issued during phase 2 (into region B)
-        wait_stages(3);
-        wg_barrier();
-        read_half(a0, regB, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int kt = t % KT;
-            const int nb = (2 * wn + t / KT) * GF + g * 4;
+            const int nc = t / KT, kt = t % KT;
+            const int nb = nc * GF + g * 4;
             if (kt == 0) {
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
 #pragma unroll
@@ -490,28 +460,22 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const pv_xfused_par
                     for (int qi = 0; qi < 2; ++qi) res[i][qi] = *reinterpret_cast<const half4_t*>(hs + (size_t)mrow[qi] * p.ld_hs + nb + i * 16);
                 }
             }
-            read_half(a1, regB, t, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            wait_except(t + 1 < NT ? 1 : 0, 0);
+            wg_barrier();
+            if (t + 2 < NT) issue_stage(ro, buf1, t + 2);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* base = buf1 + (t % S) * TILE_BYTES + ring_lane[ks];
+                half8_t bc[2];
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
-                    acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], cat4(ca[4 * kt][qi], ca[4 * kt + 1][qi]), acc[i][qi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < NT) {
-                wait_stages((t + S - 1 < NT ? t + S - 1 : NT - 1) - (t + 1));
-                wg_barrier();
-                if (t + S < NT) issue_stage(ro, regB, t + S);
-                __builtin_amdgcn_sched_barrier(0);
-                read_half(a0, regB, t + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int qi = 0; qi < 2; ++qi) bc[qi] = cat4(cf[2 * (2 * kt + ks)][qi], cf[2 * (2 * kt + ks) + 1][qi]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const half8_t a = *reinterpret_cast<const half8_t*>(base + i * 2048);
+#pragma unroll
+                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bc[qi], acc[i][qi], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
-                    acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], cat4(ca[4 * kt + 2][qi], ca[4 * kt + 3][qi]), acc[i][qi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
             if (kt == KT - 1) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
@@ -560,7 +524,7 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     if (kb >= (1ull << 31) || vb >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
-    constexpr int SMEM = 2 * 4 * 2 * GF * 128;   // two 80-KiB regions (xattn_fused_kernel): all of the CU's LDS, one workgroup per CU
+    constexpr int SMEM = 2 * (2 * XK * KROW + XK * GF * 2);   // two 39-KiB K/V buffers (the weight rings alias them): two workgroups per CU
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -571,6 +535,6 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)p.batch * p.nq / 128)), dim3(512), SMEM, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)p.batch * p.nq / 128)), dim3(256), SMEM, (hipStream_t)stream, p);
     return PV_CHECK_LAUNCH();
 }
