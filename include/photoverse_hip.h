@@ -247,6 +247,17 @@ int pv_pointwise_nchw(const float* x, const float* w, const float* bias, float* 
                       int32_t hw, void* stream);
 /* in place clamp of fp32 values (images.clamp(-1, 1), infer.py:122) */
 int pv_clamp_f32(float* x, float lo, float hi, int64_t n, void* stream);
+/* out[b][i] = ca[b]*x[b][i] (+ cb[b]*y[b][i]): scheduler.add_noise (infer.py:65, train.py:484: ca = sqrt(acp[t_b]),
+ * cb = sqrt(1 - acp[t_b])) and the 1/scaling_factor latent scaling (infer.py:121) */
+int pv_affine_rows_f32(const float* x, const float* y, const float* ca, const float* cb, float* out, int64_t per_sample,
+                       int32_t batch, void* stream);
+/* vae.encode(x).latent_dist.sample() (infer.py:63, train.py:473): moments fp32 [B][2c][hw] (mean | logvar, NCHW),
+ * out = mean + exp(0.5*clamp(logvar,-30,20)) * eps */
+int pv_posterior_sample(const float* moments, const float* eps, float* out, int32_t batch, int64_t chw, void* stream);
+/* deterministic mean reductions of the training losses (train.py:509-516): mode 0 mean(a), 1 mean|a| (concept_text_loss),
+ * 2 mean((a-b)^2) (F.mse_loss); a / b fp32 or fp16 (is_f16); partial: workspace of n_partial floats; out[0] = result */
+int pv_reduce_mean(const void* a, const void* b, int32_t mode, int32_t is_f16, int64_t n, float* partial, int32_t n_partial,
+                   float* out, void* stream);
 
 /* im2col of a 3x3 / pad-1 conv over NCHW fp32 with few channels (UNet conv_in): fp16 rows [B*H*W][kpad], column
  * k = ci*9 + ky*3 + kx, zero padded (kpad % 64 == 0), so conv_in runs on pv_gemm_conv with w.reshape(cout, cin*9). */

@@ -80,6 +80,9 @@ SIGNATURES = {
     "pv_rows_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "pv_pointwise_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_affine_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "pv_posterior_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "pv_reduce_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "pv_clamp_f32": (c_int, [c_void_p, c_float, c_float, c_int64, c_void_p]),
     "pv_im2col3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -387,6 +387,73 @@ extern "C" int pv_pointwise_nchw(const float* x, const float* w, const float* bi
     return PV_CHECK_LAUNCH();
 }
 
+namespace {
+// out[b][i] = ca[b] * x[b][i] + cb[b] * y[b][i]   (per-sample coefficients; y / cb may be NULL: out = ca[b] * x)
+__global__ void affine_rows_kernel(const float* x, const float* y, const float* ca, const float* cb, float* out, long per, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long b = i / per;
+    float v = ca[b] * x[i];
+    if (y) v += cb[b] * y[i];
+    out[i] = v;
+}
+// posterior sample of the VAE encoder: out = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps; moments = [B][2c][hw] (mean | logvar)
+__global__ void posterior_sample_kernel(const float* moments, const float* eps, float* out, long chw, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long b = i / chw, r = i - b * chw;
+    const float mean = moments[b * 2 * chw + r];
+    const float logvar = fminf(fmaxf(moments[b * 2 * chw + chw + r], -30.f), 20.f);
+    out[i] = mean + __expf(0.5f * logvar) * eps[i];
+}
+// stage 1 of a deterministic mean: block partial sums of f(a, b); mode 0: a, 1: |a|, 2: (a - b)^2.  a / b: fp32, or fp16 when f16 != 0
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const void* a_, const void* b_, int mode, int f16, long n, float* partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float a = f16 ? (float)reinterpret_cast<const half_t*>(a_)[i] : reinterpret_cast<const float*>(a_)[i];
+        if (mode == 0) acc += a;
+        else if (mode == 1) acc += fabsf(a);
+        else {
+            const float b = f16 ? (float)reinterpret_cast<const half_t*>(b_)[i] : reinterpret_cast<const float*>(b_)[i];
+            acc += (a - b) * (a - b);
+        }
+    }
+    acc = pv_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void reduce_final_kernel(const float* partial, int nb, float scale, float* out) {
+    float acc = 0.f;
+    for (int i = 0; i < nb; ++i) acc += partial[i];     // fixed order
+    out[0] = acc * scale;
+}
+}  // namespace
+
+extern "C" int pv_affine_rows_f32(const float* x, const float* y, const float* ca, const float* cb, float* out, int64_t per_sample, int32_t batch,
+                                  void* stream) {
+    if (!x || !ca || !out || per_sample <= 0 || batch <= 0 || (y && !cb)) return (int)hipErrorInvalidValue;
+    const long n = (long)per_sample * batch;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, ca, cb, out, (long)per_sample, n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_posterior_sample(const float* moments, const float* eps, float* out, int32_t batch, int64_t chw, void* stream) {
+    if (!moments || !eps || !out || batch <= 0 || chw <= 0) return (int)hipErrorInvalidValue;
+    const long n = (long)batch * chw;
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, moments, eps, out, (long)chw, n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_reduce_mean(const void* a, const void* b, int32_t mode, int32_t is_f16, int64_t n, float* partial, int32_t n_partial, float* out,
+                              void* stream) {
+    if (!a || !partial || !out || n <= 0 || n_partial <= 0 || n_partial > 4096 || mode < 0 || mode > 2 || (mode == 2 && !b)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, a, b, mode, is_f16, (long)n, partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, n_partial, 1.0f / (float)n, out);
+    return PV_CHECK_LAUNCH();
+}
+
 extern "C" int pv_clamp_f32(float* x, float lo, float hi, int64_t n, void* stream) {
     if (n <= 0 || !x) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(clamp_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, lo, hi, (long)n);

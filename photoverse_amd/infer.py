@@ -101,10 +101,13 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
 
     if vae is None:
         return latents
-    _latents = 1 / vae.config.scaling_factor * latents.clone()                            # :121-123
-    images = vae.decode(_latents).sample
+    from .ops import Recorder
+    rec = Recorder(latents.device)                                                        # :121: 1 / scaling_factor * latents
+    inv = torch.full((latents.shape[0],), 1.0 / vae.config.scaling_factor, dtype=torch.float32, device=latents.device)
+    _latents = rec.affine_rows(latents.contiguous(), inv)
+    rec.run()
+    images = vae.decode(_latents).sample                                                  # :122-123
     if images.is_cuda and images.dtype == torch.float32 and images.is_contiguous():
-        from .ops import Recorder
         rec = Recorder(images.device)
         rec.clamp_(images, -1.0, 1.0)
         rec.run()

@@ -284,6 +284,36 @@ class Recorder:
         self._add(self.lib.pv_pointwise_nchw, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), batch, cin, cout, hw)
         return out
 
+    def affine_rows(self, x, ca, y=None, cb=None, out=None):
+        """out[b] = ca[b] * x[b] (+ cb[b] * y[b]); x / y / out fp32 [B, ...] contiguous, ca / cb fp32 [B]."""
+        if out is None:
+            out = self.empty(tuple(x.shape), torch.float32)
+        B = x.shape[0]
+        self.keep.extend(t for t in (x, y, ca, cb, out) if t is not None)
+        self._add(self.lib.pv_affine_rows_f32, _ptr(x), _ptr(y), _ptr(ca), _ptr(cb), _ptr(out), x.numel() // B, B)
+        return out
+
+    def posterior_sample(self, moments, eps, out=None):
+        """moments fp32 [B, 2c, h, w] (mean | logvar), eps fp32 [B, c, h, w] -> mean + exp(0.5 clamp(logvar)) eps."""
+        B, c2 = moments.shape[0], moments.shape[1]
+        if out is None:
+            out = self.empty(tuple(eps.shape), torch.float32)
+        self.keep.extend((moments, eps, out))
+        self._add(self.lib.pv_posterior_sample, _ptr(moments), _ptr(eps), _ptr(out), B, eps.numel() // B)
+        return out
+
+    def reduce_mean(self, a, b=None, *, mode="mean", out=None):
+        """Deterministic mean(a) / mean|a| / mean((a-b)^2) -> fp32 scalar tensor on the device."""
+        m = {"mean": 0, "abs": 1, "mse": 2}[mode]
+        nb = max(1, min(1024, (a.numel() + 4095) // 4096))
+        partial = self.empty((nb,), torch.float32)
+        if out is None:
+            out = self.empty((1,), torch.float32)
+        assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.dtype == a.dtype and b.numel() == a.numel()))
+        self.keep.extend(t for t in (a, b, out) if t is not None)
+        self._add(self.lib.pv_reduce_mean, _ptr(a), _ptr(b), m, int(a.dtype == torch.float16), a.numel(), _ptr(partial), nb, _ptr(out))
+        return out
+
     def clamp_(self, x, lo, hi):
         self.keep.append(x)
         self._add(self.lib.pv_clamp_f32, _ptr(x), float(lo), float(hi), x.numel())

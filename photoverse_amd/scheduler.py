@@ -49,9 +49,17 @@ class DPMSolverMultistepScheduler:
 
     def add_noise(self, original_samples, noise, timesteps):
         """sqrt(acp[t]) x0 + sqrt(1 - acp[t]) noise  (infer.py:65, train.py:484); ``timesteps``: int64 [B]."""
-        acp = torch.from_numpy(self.alphas_cumprod).to(original_samples.device)[timesteps.to(original_samples.device).long()]
-        acp = acp.to(original_samples.dtype).view(-1, *([1] * (original_samples.dim() - 1)))
-        return acp.sqrt() * original_samples + (1 - acp).sqrt() * noise
+        acp = torch.from_numpy(self.alphas_cumprod)[timesteps.cpu().long()].to(torch.float64)          # host table lookup (per-sample scalars)
+        ca, cb = acp.sqrt().float(), (1 - acp).sqrt().float()
+        if original_samples.is_cuda and original_samples.dtype == torch.float32:
+            from .ops import Recorder
+            rec = Recorder(original_samples.device)
+            out = rec.affine_rows(original_samples.contiguous(), ca.to(original_samples.device), noise.contiguous().to(original_samples.device),
+                                  cb.to(original_samples.device))
+            rec.run()
+            return out
+        shape = (-1, *([1] * (original_samples.dim() - 1)))
+        return ca.view(shape).to(original_samples) * original_samples + cb.view(shape).to(original_samples) * noise
 
     def coefficient_table(self) -> torch.Tensor:
         """float32 [n, 8] rows {ca, cb, cx, c0, c1, 0, 0, 0} with, per step i (s = current, t = next sigma):

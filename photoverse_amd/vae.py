@@ -113,7 +113,13 @@ class DiagonalGaussianDistribution:
         self.var = torch.exp(self.logvar)
 
     def sample(self, generator=None):
-        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)   # the draw (input), not arithmetic
+        if self.parameters.is_cuda and self.parameters.dtype == torch.float32:
+            from .ops import Recorder
+            rec = Recorder(self.parameters.device)
+            out = rec.posterior_sample(self.parameters.contiguous(), eps.contiguous())
+            rec.run()
+            return out
         return self.mean + self.std * eps
 
     def mode(self):

@@ -209,3 +209,73 @@ def test_reference_layout_checkpoint_loads_into_hip_path(need_gpu, tmp_path):
     with torch.no_grad():
         assert rel_l2(ia_b([e.cuda() for e in embs]), r_ia(embs)) < 3e-3
         assert rel_l2(ta_b([e.cuda() for e in embs], token_index=0), r_ta(embs, token_index=0)) < 3e-3
+
+
+def test_training_step_forward_losses_match_oracle(need_gpu):
+    """Forward half of a training step (train.py:466-516): VAE encode + posterior sample, add_noise at per-sample timesteps, CLIP ->
+    adapters in FULL mode (3 tokens), injected text encoder, UNet in grad mode (forced per-layer fusion draws), and the three loss
+    terms - against the same composition of the oracle pieces with the same draws."""
+    import torch.nn.functional as F
+    from oracle.adapters_ref import PhotoVerseAdapterRef
+    from oracle.clip_ref import CLIPTextModelRef, CLIPVisionModelRef
+    from oracle.scheduler_ref import DPMSolverMultistepRef
+    from oracle.unet_ref import TINY_CONFIG, UNet2DConditionModelRef, get_visual_cross_attention_values_norm_ref, set_visual_cross_attention_adapter_ref
+    from oracle.vae_ref import AutoencoderKLDecoderRef
+    from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.train import training_step_forward
+    VAE = dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1)
+    ENT = 2                                                    # extra_num_tokens -> P = 3
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, ENT, unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT, vae_config=VAE, seed=21)
+    r_unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
+    set_visual_cross_attention_adapter_ref(r_unet, (ENT + 1,))
+    r_unet.load_state_dict(unet.state_dict())
+    r_vis = CLIPVisionModelRef(**VIS).eval(); r_vis.load_state_dict(image_encoder.state_dict())
+    r_txt = CLIPTextModelRef(**TXT).eval(); r_txt.load_state_dict(text_encoder.state_dict())
+    r_ia = PhotoVerseAdapterRef(256, 768, ENT + 1).eval(); r_ia.load_state_dict(image_adapter.state_dict())
+    r_ta = PhotoVerseAdapterRef(256, 768, ENT + 1).eval(); r_ta.load_state_dict(text_adapter.state_dict())
+    r_vae = AutoencoderKLDecoderRef(with_encoder=True, **VAE).eval(); r_vae.load_state_dict(vae.state_dict())
+    for m in (unet, vae, text_encoder, image_encoder, image_adapter, text_adapter):
+        m.to("cuda")
+    g = torch.Generator().manual_seed(22)
+    B = 2
+    batch = {"pixel_values": torch.rand(B, 3, 128, 128, generator=g) * 2 - 1, "pixel_values_clip": torch.randn(B, 3, 56, 56, generator=g),
+             "text_input_ids": torch.randint(0, 1000, (B, 77), generator=g), "concept_placeholder_idx": torch.tensor([[5], [3]])}
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    eps = torch.randn(B, 4, 16, 16, generator=g)
+    timesteps = torch.tensor([731, 42])
+    layers = [1, 2]
+    forced = [0.1, 0.5, 0.9, 0.4]
+    out = training_step_forward(batch, tok, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, scheduler, "cuda", layers, ENT,
+                                fusion_seed=3, forced_fusion=forced, noise=noise, timesteps=timesteps, posterior_eps=eps)
+    assert out["fusion_table"].cpu().tolist() == [[2.0, 0.0], [1.0, 1.0], [0.0, 2.0], [1.0, 1.0]]
+    # ---- oracle composition (train.py:466-516) ----
+    with torch.no_grad():
+        lat = r_vae.encode(batch["pixel_values"]).latent_dist.sample(eps=eps) * 0.18215
+        sch = DPMSolverMultistepRef()
+        acp = sch.alphas_cumprod[timesteps].view(-1, 1, 1, 1)
+        noisy = acp.sqrt() * lat + (1 - acp).sqrt() * noise
+        feats = r_vis(batch["pixel_values_clip"])
+        embs = [feats[0]] + [feats[2][i] for i in layers]
+        concept = r_ta(embs)
+        ehs = r_txt({"text_input_ids": batch["text_input_ids"], "concept_text_embeddings": concept,
+                     "concept_placeholder_idx": batch["concept_placeholder_idx"]})[0]
+        ehs_img = r_ia(embs)
+    mods = dict(r_unet.named_modules())
+    for name, u in zip(out["fusion_names"], forced):
+        mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = u
+    with torch.enable_grad():
+        pred = r_unet(noisy, timesteps, encoder_hidden_states=(ehs, ehs_img)).sample.detach()
+        vn = get_visual_cross_attention_values_norm_ref(r_unet).detach()
+    exp_diff = F.mse_loss(pred, noise).item()
+    exp_concept = concept.abs().mean().item()
+    exp_visual = vn.mean().item()
+    assert rel_l2(out["latents"], lat) < 5e-3 and rel_l2(out["noise_pred"], pred) < 1e-2
+    assert out["diffusion_loss"].item() == pytest.approx(exp_diff, rel=5e-3)
+    assert out["concept_text_loss"].item() == pytest.approx(exp_concept, rel=3e-3)
+    assert out["cross_attn_visual_loss"].item() == pytest.approx(exp_visual, rel=3e-3)
+    assert out["loss"].item() == pytest.approx(exp_diff + 0.01 * exp_concept + 0.001 * exp_visual, rel=5e-3)
+    # free draws: runs, finite, timesteps in range
+    out2 = training_step_forward(batch, tok, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, scheduler, "cuda", layers, ENT,
+                                 generator=torch.Generator().manual_seed(5), fusion_seed=3)
+    assert torch.isfinite(out2["loss"]).all() and 0 <= int(out2["timesteps"].min()) and int(out2["timesteps"].max()) < 1000
