@@ -253,7 +253,7 @@ def test_training_step_forward_losses_match_oracle(need_gpu):
     with torch.no_grad():
         lat = r_vae.encode(batch["pixel_values"]).latent_dist.sample(eps=eps) * 0.18215
         sch = DPMSolverMultistepRef()
-        acp = sch.alphas_cumprod[timesteps].view(-1, 1, 1, 1)
+        acp = torch.as_tensor(sch.alphas_cumprod)[timesteps].float().view(-1, 1, 1, 1)
         noisy = acp.sqrt() * lat + (1 - acp).sqrt() * noise
         feats = r_vis(batch["pixel_values_clip"])
         embs = [feats[0]] + [feats[2][i] for i in layers]
