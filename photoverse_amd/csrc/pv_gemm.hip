@@ -79,9 +79,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // CS: instantiation whose epilogue also produces the GroupNorm column statistics (pv_gemm_params.colstats).  Separate from the
 // plain kernel because the extra 40 accumulators cost the launches that do not want them 2-3 %.
-template <int NF, bool CONV, bool GEGLU, bool CS = false>
+template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
-                                                                              const int nblk, const int order) {
+                                                                              const int nblk, const int order, const int tpw_arg) {
+    const int tpw = MULTI ? tpw_arg : 1;        // MULTI = false: the straight one-tile kernel (the tile loop folds away)
     using Cfg = TileCfg<NF>;
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NWAVES;
@@ -91,13 +92,16 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
 
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
+    // tpw (tiles per workgroup): a workgroup walks `tpw` consecutive N-tiles of one M-tile with ONE continuous K pipeline - the
+    // LDS-DMA of the next tile's first stages is issued during the last K-steps of the current one and overlaps its epilogue, so
+    // short-K layers (K = 320: five K-steps per tile) do not pay a cold prologue per 128 x BN outputs.  tiles_n / nblk count GROUPS.
     const int bid = (order & 2) ? (int)blockIdx.x : pv_xcd_remap((int)blockIdx.x, nblk);
     const int m_fast = order & 1;
     const int tiles_m = nblk / tiles_n;
     const int tile_m = m_fast ? bid % tiles_m : bid / tiles_n;
-    const int tile_n = m_fast ? bid / tiles_m : bid % tiles_n;
+    const int tile_n = (m_fast ? bid / tiles_m : bid % tiles_n) * tpw;      // first N-tile of the group
     const int m0 = tile_m * BM;
-    const int n0 = tile_n * Cfg::BN;
+    int n0 = tile_n * Cfg::BN;                                               // advances by BN per tile
 
     const int cin = p.c0 + p.c1;
     const int K = p.taps * cin;
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
     // number of LDS-DMA instructions this wave issues per stage (for the counted vmcnt)
     const bool b_full = (Cfg::B_PIECES % NW == 0) || (wave + (Cfg::B_PER_WAVE - 1) * NW < Cfg::B_PIECES);
 
-    auto stage = [&](int kt_local, int buf) {
-        const int kt = k_begin + kt_local;
+    auto stage = [&](int g_local, int buf) {      // g_local: flat step index over (tile of the group, K-step)
+        const int tn = g_local / nk;
+        const int kt = k_begin + (g_local - tn * nk);
         char* sa = smem + buf * Cfg::STAGE_BYTES;
         char* sb = sa + Cfg::A_BYTES;
         // K order: channel-chunk major, filter-tap minor.  The 9 taps of one 64-channel slab re-read (shifted) the same
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + i * NW) * 8 * ROW_BYTES), 16, (int)off, 0, 0, 0);
         }
-        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u + (unsigned)tn * (unsigned)(Cfg::BN * K * 2);
 #pragma unroll
         for (int i = 0; i < Cfg::B_PER_WAVE; ++i) {
             if (i < Cfg::B_PER_WAVE - 1 || b_full)
@@ -237,13 +242,14 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
     };
 
+    const int T = nk * tpw;                     // steps of the whole group
 #pragma unroll
     for (int s = 0; s < S; ++s)
-        if (s < nk) stage(s, s);
+        if (s < T) stage(s, s);
     // stage 0 landed <=> at most the pieces of the younger issued stages are outstanding; drain fully when short
-    if (nk >= S && S == 3) {
+    if (T >= S && S == 3) {
         if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE) * 2>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1) * 2>();
-    } else if (nk >= S && S == 2) {
+    } else if (T >= S && S == 2) {
         if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1)>();
     } else {
         wait_vmcnt<0>();
@@ -252,26 +258,30 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
     asm volatile("" ::: "memory");
 
     half8_t xa0[MI], wb0[NF], xa1[MI], wb1[NF];
-    if (nk > 0) read_half(xa0, wb0, 0, 0);
+    if (T > 0) read_half(xa0, wb0, 0, 0);
+    for (int tn = 0; tn < tpw; ++tn) {
     for (int kt = 0; kt < nk; ++kt) {
-        read_half(xa1, wb1, kt, 1);
+        const int g = tn * nk + kt;             // flat step: LDS buffer g % S
+        read_half(xa1, wb1, g, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_half(xa0, wb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            // stage kt+1 landed: all younger issued stages (kt+2 .. kt+S-1) may stay in flight, if they were all issued
-            if (S == 3 && kt + S - 1 < nk) {
+        if (g + 1 < T) {
+            // stage g+1 landed: all younger issued stages (g+2 .. g+S-1) may stay in flight, if they were all issued
+            if (S == 3 && g + S - 1 < T) {
                 if (b_full) wait_vmcnt<(AP + Cfg::B_PER_WAVE)>(); else wait_vmcnt<(AP + Cfg::B_PER_WAVE - 1)>();
             } else {
                 wait_vmcnt<0>();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer kt % S are retired
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer g % S are retired
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + S < nk) stage(kt + S, kt % S);
+            if (g + S < T) stage(g + S, g % S);
             __builtin_amdgcn_sched_barrier(0);
-            read_half(xa0, wb0, kt + 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {                                   // at a tile boundary the first half of the next tile is read after the epilogue
+                read_half(xa0, wb0, g + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         mma_half(xa1, wb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -331,8 +341,11 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni)
             bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        // MULTI (tile loop): the K pipeline's registers stay live across the epilogue, so the residual is fetched in two batches of
+        // two row-fragments instead of all four at once (40 -> 20 registers)
+        constexpr int RB = MULTI ? 2 : MI;          // row-fragments per residual batch
         half4_t res[NF][MI];
-        if (p.residual) {
+        if (p.residual && !MULTI) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = min(m0 + wm * (MI * 16) + mi * 16 + fr, p.M - 1);
@@ -348,6 +361,15 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
         for (int ni = 0; ni < NF; ++ni) cs[ni] = cq[ni] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            if (MULTI && p.residual && mi % RB == 0) {
+#pragma unroll
+                for (int m2 = mi; m2 < mi + RB; ++m2) {
+                    const int mm = min(m0 + wm * (MI * 16) + m2 * 16 + fr, p.M - 1);
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        res[ni][m2] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + ni * 16);
+                }
+            }
             const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
             if (m >= p.M) continue;
             const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
@@ -420,6 +442,17 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_
             }
         }
     }
+    // ---- next tile of the group ------------------------------------------------------------------------------------
+    if (tn + 1 < tpw) {
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+        n0 += Cfg::BN;
+        read_half(xa0, wb0, (tn + 1) * nk, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }   // tiles of this workgroup
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the GEMM epilogue.  One workgroup = 64 rows x 64 columns
@@ -487,14 +520,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const pv_gemm_params
     }
 }
 
-template <int NF, bool CONV, bool GEGLU, bool CS = false>
-int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
+template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false>
+int launch(const pv_gemm_params_dev& p, hipStream_t stream, int tpw = 1) {
     using Cfg = TileCfg<NF>;
     static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = gemm_conv_kernel<NF, CONV, GEGLU, CS>;
+    auto kern = gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::SMEM_BYTES);
@@ -509,15 +542,35 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     static const int order_env = getenv("PV_TILE_ORDER") ? atoi(getenv("PV_TILE_ORDER")) : -1;   // experiments: bit0 M-fastest, bit1 no XCD remap
     const int m_fast = order_env >= 0 ? order_env : ((wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0);
     const int splits = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
-    hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n, nblk, m_fast);
+    hipLaunchKernelGGL(kern, dim3(nblk / tpw, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n / tpw, nblk / tpw, m_fast, tpw);
     if (splits > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, stream, p, splits);
     return PV_CHECK_LAUNCH();
 }
 
 // One tile shape (128 x BN x 64, two workgroups per CU) for every layer: larger tiles lost on every UNet shape (see the header).
+// tiles per workgroup: the shortest-K GEGLU layers (K = 320: five K-steps per tile, 10240 tiles at bs = 16) let one workgroup walk
+// several N-tiles with a continuous K pipeline, as long as the launch keeps >= 1024 workgroups.  Measured (kbench, MI355X): -4 % at
+// K = 320 (181.5 -> 174.6 us), nothing at K = 640, +6 % at K = 1280 - so only nk <= 5 uses it.
+template <int NF>
+int choose_tpw(const pv_gemm_params_dev& p) {
+    static const int tpw_env = getenv("PV_GEMM_TPW") ? atoi(getenv("PV_GEMM_TPW")) : 0;      // experiments: force (1 = off)
+    if (p.taps != 1 || (p.splitk > 1 && p.splitk_ws)) return 1;
+    const int tiles_n = p.N / (NF * 32), nk = (p.c0 + p.c1) / BK;
+    const long nblk = (long)((p.M + 127) / 128) * tiles_n;
+    if (tpw_env > 0) return tiles_n % tpw_env == 0 ? tpw_env : 1;
+    for (int c = 8; c >= 2; --c)
+        if (tiles_n % c == 0 && nk <= 5 && nblk / c >= 1024) return c;
+    return 1;
+}
+
+// One tile shape (128 x BN x 64, two workgroups per CU) for every layer: larger tiles lost on every UNet shape (see the header).
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
+    if constexpr (!CONV && GEGLU) {       // the plain-epilogue instantiations spill with the tile loop (NF = 5: 300+ B of scratch): GEGLU only
+        const int tpw = choose_tpw<NF>(p);
+        if (tpw > 1) return launch<NF, false, true, false, true>(p, stream, tpw);
+    }
     if constexpr (!GEGLU) {
         if (p.colstats && !(p.splitk > 1 && p.splitk_ws)) return launch<NF, CONV, false, true>(p, stream);   // split-K: the reduce launch makes them
     }

@@ -15,7 +15,7 @@ OUT = os.path.join(ROOT, "gpurun_out", "prof_bench")
 steps = sys.argv[1] if len(sys.argv) > 1 else "5"
 DOM = "gemm_conv_kernel<5, true, false, true>"
 env = dict(os.environ, TMPDIR="/tmp")
-base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "2", "--no-cpu-baseline"]
+base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "2", "--no-cpu-baseline", "--no-train-forward"]
 
 
 def run(args, tag):
