@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Diagnostic: in-kernel s_memtime stamps of one wave of the d=40 self-attention kernel (stamped COPY of pv_attn.hip, private lib).
+Per 64-key tile: barrier + LDS write + barrier | global prefetch issue | QK^T MFMAs | softmax | P.V MFMAs.  XA_ABLATE=nobar drops the
+two workgroup barriers per tile (wrong results, timing only)."""
+import ctypes, os, subprocess, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import photoverse_amd.build as b  # noqa: E402
+ABL = os.environ.get("XA_ABLATE", "")
+s = open(os.path.join(b.CSRC, "pv_attn.hip")).read()
+s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long at_stamps[16];\n'
+              '#define STAMP(i) do { if (D == 40 && blockIdx.x == 2000 && threadIdx.x == 0 && t == 20) at_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
+              % os.path.join(b.CSRC, "pv_common.h"))
+rep = [("        if (!DBUF) {\n            __syncthreads();  // previous tile fully consumed\n            swrite(0);\n            __syncthreads();\n        }",
+        "        STAMP(0);\n        if (!DBUF) {\n            %s\n            swrite(0);\n            %s\n        }\n        STAMP(1);" % (("", "") if "nobar" in ABL else ("__syncthreads();", "__syncthreads();"))),
+       ("        if (t + 1 < ntiles) gload(t + 1);\n", "        if (t + 1 < ntiles) gload(t + 1);\n        STAMP(2);\n"),
+       ("        half8_t pb[2][2];\n#pragma unroll\n        for (int qi = 0; qi < 2; ++qi) {\n            if (MASKED) {", "        STAMP(3);\n        half8_t pb[2][2];\n#pragma unroll\n        for (int qi = 0; qi < 2; ++qi) {\n            if (MASKED) {"),
+       ("#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);",
+        "        STAMP(4);\n#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);"),
+       ("        tile(t, st, need_mask, t == 0);\n", "        tile(t, st, need_mask, t == 0);\n        STAMP(5);\n")]
+for a, c in rep:
+    assert a in s, a[:60]
+    s = s.replace(a, c, 1)
+s += '\nextern "C" int pv_at_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(at_stamps), 16 * 8); }\n'
+src, lib = "/tmp/pv_attn_stamps.hip", "/tmp/libpv_diag_attn.so"
+open(src, "w").write(s)
+objs = []
+for f in b.SOURCES:
+    path = src if f == "pv_attn.hip" else os.path.join(b.CSRC, f)
+    o = f"/tmp/diaga_{f}.o"
+    subprocess.check_call([b._hipcc(), *b.FLAGS, *b.EXTRA_FLAGS.get(f, []), "-I", b.CSRC, "-c", path, "-o", o])
+    objs.append(o)
+subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+from photoverse_amd import _lib  # noqa: E402
+_lib.LIB = lib
+from photoverse_amd.ops import Recorder  # noqa: E402
+dev = torch.device("cuda")
+B, n, d = 16, 4096, 40
+C = 8 * d
+qkv = (torch.randn(B * n, 3 * C, device=dev) * 0.5).half()
+rec = Recorder(dev)
+rec.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=B, heads=8, nq=n, nk=n, d=d)
+for _ in range(3):
+    rec.run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    rec.run()
+e1.record()
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+fn = rec.lib.pv_at_stamps
+fn.restype = ctypes.c_int
+assert fn(out) == 0
+t = list(out)[:6]
+names = ["barrier + LDS write + barrier", "prefetch issue (next tile)", "QK^T (16 MFMA + reads)", "softmax (VALU)", "P.V (12 MFMA + tr reads)"]
+print(f"ablate={ABL or '-'}  launch {e0.elapsed_time(e1) / 5 * 1e3:.1f} us;  tile 20 of workgroup 2000, wave 0:")
+for i in range(5):
+    print(f"  {names[i]:34s} {t[i + 1] - t[i]:6d} cycles")
+print(f"  {'tile total':34s} {t[5] - t[0]:6d} cycles")
