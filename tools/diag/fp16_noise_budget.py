@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import unet_ref as U
 
 R = lambda t: t.half().float()
-MODE = {"carrier": False, "interior": False}
+MODE = {"carrier": False, "interior": False, "tf32carrier": False}   # tf32carrier: transformer-internal residual adds kept in fp32
 rc = lambda t: R(t) if MODE["carrier"] else t
 ri = lambda t: R(t) if MODE["interior"] else t
 
@@ -25,10 +25,11 @@ def block_forward(self, hidden_states, encoder_hidden_states=None):
     q, k, v = ri(a1.to_q(n)), ri(a1.to_k(n)), ri(a1.to_v(n))
     sp = lambda t: t.view(B, -1, h, C // h).transpose(1, 2)
     o = ri(F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, C))
-    hidden_states = rc(a1.to_out[0](o) + hidden_states)
+    rt = (lambda t: t) if MODE["tf32carrier"] else rc
+    hidden_states = rt(a1.to_out[0](o) + hidden_states)
     n2 = ri(self.norm2(hidden_states))
     x = self.attn2(n2, encoder_hidden_states=encoder_hidden_states)       # interior roundings of attn2 are tiny (0.45 % of flops): skipped
-    hidden_states = rc(x + hidden_states)
+    hidden_states = rt(x + hidden_states)
     n3 = ri(self.norm3(hidden_states))
     g = ri(self.ff.net[0](n3))
     hidden_states = rc(self.ff.net[2](g) + hidden_states)
@@ -38,7 +39,7 @@ def block_forward(self, hidden_states, encoder_hidden_states=None):
 def t2d_forward(self, hidden_states, encoder_hidden_states=None):
     b, _, h, w = hidden_states.shape
     residual = hidden_states
-    hidden_states = rc(self.proj_in(ri(self.norm(hidden_states))))
+    hidden_states = (lambda t: t if MODE["tf32carrier"] else rc(t))(self.proj_in(ri(self.norm(hidden_states))))
     inner = hidden_states.shape[1]
     hidden_states = hidden_states.permute(0, 2, 3, 1).reshape(b, h * w, inner)
     for blk in self.transformer_blocks:
@@ -75,8 +76,9 @@ g = torch.Generator().manual_seed(3)
 S = 16 if tiny else 64
 x, text, ip = torch.randn(1, 4, S, S, generator=g), R(torch.randn(1, 77, 768, generator=g)), R(torch.randn(1, 1, 768, generator=g))
 outs = {}
-for name, (c, i) in {"fp32": (False, False), "carrier only": (True, False), "interior only": (False, True), "both (= HIP plan)": (True, True)}.items():
-    MODE["carrier"], MODE["interior"] = c, i
+for name, (c, i, tf) in {"fp32": (False, False, False), "carrier only": (True, False, False), "interior only": (False, True, False),
+                         "both (= HIP plan)": (True, True, False), "both, fp32 hs0..hs2 inside transformer blocks": (True, True, True)}.items():
+    MODE["carrier"], MODE["interior"], MODE["tf32carrier"] = c, i, tf
     t0 = time.time()
     with torch.no_grad():
         outs[name] = ref(x, torch.tensor(481), encoder_hidden_states=(text, ip)).sample.double()
