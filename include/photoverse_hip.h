@@ -189,6 +189,53 @@ int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt,
                      int32_t heads, int32_t d, int32_t nt, int32_t nip, void* stream);
 int pv_xattn_fused_wo_slot(int32_t slot);
 
+/* ------------------------------------------------------------------------------------------
+ * BACKWARD of PhotoVerse's own trainable modules (first correct versions; the stock SD-v1.5 / CLIP
+ * backward is not built).
+ *
+ * pv_cross_attention_backward: gradient of the dual-branch SDPA (attention_processor.py:317-322,
+ * :392-420) given dout = dL/d(attention output before to_out):
+ *   dq   fp16 [B*nq][C]         dkt, dvt  fp32 [B*nt][C]        dkip, dvip  fp32 [B*nip][C]
+ * every output is multiplied by out_scale (un-scaling of a loss-scaled dout); dvip additionally gets
+ * (vnorm_coef + vnorm_grad[b][h][p]) * v / ||v||_head (gradient through to_v_ip_norm, :397 / train.py:512-513)
+ * before that scaling.  partial: fp32 workspace batch*heads*ceil(nq/64)*2*96*d.  Deterministic.
+ */
+typedef struct pv_xattn_bwd_params {
+    const void* q; int32_t ldq;
+    const void* kt; const void* vt; int32_t ldkt, ldvt;
+    const void* kip; const void* vip; int32_t ldkip, ldvip;
+    const void* dout; int32_t lddo;
+    void* dq; int32_t lddq;
+    float* partial;
+    float* dkt; float* dvt; float* dkip; float* dvip;
+    int32_t ld_dt, ld_di;              /* row strides (floats) of dkt / dvt and of dkip / dvip (e.g. 2C for a [dK | dV] buffer) */
+    int32_t batch, heads, nq, nt, nip, d;
+    float w_text, w_ip;
+    const float* fusion;               /* optional device pair overriding (w_text, w_ip) */
+    float out_scale, vnorm_coef;
+    const float* vnorm_grad;           /* optional dL/d(to_v_ip_norm) fp32 [B][heads][nip], added to vnorm_coef per (b, h, p) */
+} pv_xattn_bwd_params;
+int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream);
+/* out[c][r] = x[r][c] (fp16), rows zero-padded to rows_pad: operand layout of dW = dY^T . X on pv_gemm_conv */
+int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, void* out, int32_t ldo, int32_t rows_pad, void* stream);
+/* LayerNorm (+ LeakyReLU) backward (adapters.py:15-19): dx fp16; dgb_partial (optional) fp32 [ceil(rows/4)][2][cols] =
+ * per-4-row-block (dgamma, dbeta) terms, to be summed with pv_reduce_blocks */
+typedef struct pv_layernorm_bwd_params {
+    const void* x; int32_t ldx;
+    const void* dy; int32_t lddy;
+    void* dx; int32_t lddx;
+    const float* gamma; const float* beta;
+    float* dgb_partial;
+    int32_t rows, cols;
+    float eps;
+    int32_t act;
+} pv_layernorm_bwd_params;
+int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
+/* out[i] = scale * sum_b x[b][i], b in order (deterministic) */
+int pv_reduce_blocks(const float* x, int32_t nblk, int64_t inner, float scale, float* out, void* stream);
+/* out[c] = sum_r x[r][c] over fp16 rows (bias gradients); partial: nblk*cols floats */
+int pv_colsum_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, float* partial, int32_t nblk, float* out, void* stream);
+
 /* GEGLU gate (diffusers GEGLU, exact-erf GELU): out[m][j] = x[m][j] * gelu(x[m][n+j]) */
 int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, int32_t n, void* stream);
 

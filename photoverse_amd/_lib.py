@@ -54,6 +54,20 @@ class XAttnFusedParams(C.Structure):
                 ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
 
 
+class XAttnBwdParams(C.Structure):
+    _fields_ = [("q", c_void_p), ("ldq", c_int), ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int),
+                ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int), ("dout", c_void_p), ("lddo", c_int),
+                ("dq", c_void_p), ("lddq", c_int), ("partial", c_void_p), ("dkt", c_void_p), ("dvt", c_void_p), ("dkip", c_void_p),
+                ("dvip", c_void_p), ("ld_dt", c_int), ("ld_di", c_int), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nt", c_int), ("nip", c_int), ("d", c_int),
+                ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p), ("out_scale", c_float), ("vnorm_coef", c_float), ("vnorm_grad", c_void_p)]
+
+
+class LayerNormBwdParams(C.Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int), ("dy", c_void_p), ("lddy", c_int), ("dx", c_void_p), ("lddx", c_int),
+                ("gamma", c_void_p), ("beta", c_void_p), ("dgb_partial", c_void_p), ("rows", c_int), ("cols", c_int), ("eps", c_float),
+                ("act", c_int)]
+
+
 #: every symbol ``include/photoverse_hip.h`` declares: name -> (restype, argtypes)
 SIGNATURES = {
     "pv_abi_version": (c_int, []),
@@ -69,6 +83,11 @@ SIGNATURES = {
     "pv_xattn_pack_kv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_xattn_fused_wo_slot": (c_int, [c_int]),
+    "pv_cross_attention_backward": (c_int, [C.POINTER(XAttnBwdParams), c_void_p]),
+    "pv_transpose_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "pv_layernorm_backward": (c_int, [C.POINTER(LayerNormBwdParams), c_void_p]),
+    "pv_reduce_blocks": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]),
+    "pv_colsum_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

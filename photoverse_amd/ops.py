@@ -16,7 +16,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AttnParams, GemmParams, GroupNormParams, LayerNormParams, XAttnFusedParams, XAttnParams
+from ._lib import (AttnParams, GemmParams, GroupNormParams, LayerNormBwdParams, LayerNormParams, XAttnBwdParams, XAttnFusedParams,
+                   XAttnParams)
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
@@ -256,6 +257,67 @@ class Recorder:
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
         self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320>", flops, 2.0 * (3 * M * C + 2 * C * C)))
         return out, p
+
+    # ---- backward of PhotoVerse's own trainable modules (pv_backward.hip) ----
+    def cross_attention_backward(self, q, kt, vt, kip, vip, dout, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, fusion=None,
+                                 out_scale=1.0, vnorm_coef=0.0, vnorm_grad=None):
+        """Gradients of the dual-branch SDPA: dq fp16 [B*nq, C]; [dK_t | dV_t] fp32 [B*nt, 2C]; [dK_ip | dV_ip] fp32 [B*nip, 2C]
+        (returned as dq, dkv_text, dkv_ip)."""
+        C_ = heads * d
+        dq = self.empty((batch * nq, C_), torch.float16)
+        dkv_t = self.empty((batch * nt, 2 * C_), torch.float32)
+        dkv_i = self.empty((batch * nip, 2 * C_), torch.float32)
+        dkt, dvt, dkip, dvip = dkv_t[:, :C_], dkv_t[:, C_:], dkv_i[:, :C_], dkv_i[:, C_:]
+        ntile = (nq + 63) // 64
+        partial = self.empty((batch * heads * ntile * 2 * 96 * d,), torch.float32)
+        p = XAttnBwdParams(_ptr(q), _rows(q)[0], _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0], _rows(vip)[0],
+                           _ptr(dout), _rows(dout)[0], _ptr(dq), C_, _ptr(partial), _ptr(dkt), _ptr(dvt), _ptr(dkip), _ptr(dvip), 2 * C_, 2 * C_, batch, heads, nq, nt,
+                           nip, d, float(w_text), float(w_ip), _ptr(fusion), float(out_scale), float(vnorm_coef), _ptr(vnorm_grad))
+        self.keep.extend(t for t in (q, kt, vt, kip, vip, dout, fusion, vnorm_grad) if t is not None)
+        self._add(self.lib.pv_cross_attention_backward, p)
+        return dq, dkv_t, dkv_i
+
+    def transpose(self, x, rows_pad=None):
+        """fp16 [R, C] -> [C, rows_pad] (zero padded rows): the operand layout of the weight-gradient GEMMs."""
+        ldx, cols = _rows(x)
+        rows = x.shape[0]
+        rp = rows_pad or (rows + 63) // 64 * 64
+        out = self.empty((cols, rp), torch.float16)
+        self.keep.append(x)
+        self._add(self.lib.pv_transpose_f16, _ptr(x), ldx, rows, cols, _ptr(out), rp, rp)
+        return out
+
+    def wgrad(self, dy16, x16, scale=None):
+        """dW [N, K] fp32 = dy16[M, N]^T . x16[M, K] on the MFMA GEMM (both operands transposed, M zero-padded to 64).
+        K must be a multiple of 128 (or 160)."""
+        a = self.transpose(dy16)          # [N, Mp]
+        w = self.transpose(x16)           # [K, Mp]
+        return self.gemm(a, w, out_f32=True, splitk=0)
+
+    def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True):
+        rows, cols = x.shape
+        dx = self.empty((rows, cols), torch.float16)
+        nblk = (rows + 3) // 4
+        part = self.empty((nblk, 2, cols), torch.float32) if want_affine else None
+        p = LayerNormBwdParams(_ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, _ptr(gamma), _ptr(beta), _ptr(part), rows, cols,
+                               float(eps), act)
+        self.keep.extend((x, dy, gamma, beta))
+        self._add(self.lib.pv_layernorm_backward, p)
+        dgb = None
+        if want_affine:
+            dgb = self.empty((2, cols), torch.float32)
+            self._add(self.lib.pv_reduce_blocks, _ptr(part), nblk, 2 * cols, 1.0, _ptr(dgb))
+        return dx, dgb
+
+    def colsum(self, x16):
+        """fp32 [C] column sums of fp16 rows (bias gradients), deterministic."""
+        rows, cols = x16.shape
+        nblk = max(1, min(256, rows // 64))
+        part = self.empty((nblk, cols), torch.float32)
+        out = self.empty((cols,), torch.float32)
+        self.keep.append(x16)
+        self._add(self.lib.pv_colsum_f16, _ptr(x16), _rows(x16)[0], rows, cols, _ptr(part), nblk, _ptr(out))
+        return out
 
     def geglu(self, x, out=None):
         ldx, n2 = _rows(x)

@@ -169,6 +169,48 @@ def test_training_mode_loop_fuses_on_the_last_step_only(tiny_pair):
             assert not torch.equal(plain.latents, train.latents) and torch.isfinite(train.latents).all()
 
 
+@pytest.mark.parametrize("name,N", [("mid_block.attentions.0.transformer_blocks.0.attn2", 64), ("down_blocks.0.attentions.0.transformer_blocks.0.attn2", 200)])
+def test_processor_backward_matches_oracle_autograd(tiny_pair, name, N):
+    """BACKWARD of the reference's own processor on HIP: gradients of PhotoVerseAttnProcessor2_0 (grad mode, forced fusion draws)
+    with respect to hidden_states, the text / image-token embeddings, to_k_ip / to_v_ip, to_q / to_k / to_v / to_out, and through
+    to_v_ip_norm (the regulariser of train.py:512-513) - against torch autograd over the oracle processor."""
+    ref, hip = tiny_pair
+    ra, ha = dict(ref.named_modules())[name], dict(hip.named_modules())[name]
+    C = ra.to_q.in_features
+    g = torch.Generator().manual_seed(61)
+    B, P = 2, 5
+    h0, t0, i0 = torch.randn(B, N, C, generator=g), torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g)
+    G = torch.randn(B, N, C, generator=g)
+    plist = [("to_q.weight", lambda m: m.to_q.weight), ("to_k.weight", lambda m: m.to_k.weight), ("to_v.weight", lambda m: m.to_v.weight),
+             ("to_out.0.weight", lambda m: m.to_out[0].weight), ("to_out.0.bias", lambda m: m.to_out[0].bias),
+             ("to_k_ip", lambda m: m.processor.to_k_ip[0].weight), ("to_v_ip", lambda m: m.processor.to_v_ip[0].weight)]
+    for seed in (0.5, 0.1, 0.9):
+        ra.processor.forced_fusion_seed = ha.processor.forced_fusion_seed = seed
+        res = []
+        for mod, dev in ((ra, "cpu"), (ha, "cuda")):
+            for _, get in plist:
+                get(mod).requires_grad_(True)
+                get(mod).grad = None
+            h, t, i = (x.clone().to(dev).requires_grad_(True) for x in (h0, t0, i0))
+            with torch.enable_grad():
+                out = mod(h, encoder_hidden_states=(t, i))
+                vn = mod.processor.to_v_ip_norm
+                loss = (out.float() * G.to(dev)).sum() + 0.3 * vn.sum()
+            loss.backward()
+            res.append({"h": h.grad, "t": t.grad, "i": i.grad, **{n: get(mod).grad for n, get in plist}})
+        for k in res[0]:
+            a, b = res[1][k], res[0][k]
+            if seed < 1 / 3 and k in ("to_k_ip",):            # text-only fusion: the image-token keys get no gradient ...
+                assert b.abs().max() == 0 and a.abs().max() < 1e-6
+                continue
+            assert a is not None and a.shape == b.shape, k
+            assert rel_l2(a, b) < 1e-2, (k, seed, rel_l2(a, b))
+    ra.processor.forced_fusion_seed = ha.processor.forced_fusion_seed = None
+    for _, get in plist:
+        get(ha).grad = None
+        get(ra).grad = None
+
+
 def test_cpu_tensor_is_refused(tiny_pair):
     _, hip = tiny_pair
     with pytest.raises(RuntimeError, match="no CPU path"):
