@@ -229,6 +229,8 @@ typedef struct pv_layernorm_bwd_params {
     int32_t rows, cols;
     float eps;
     int32_t act;
+    int32_t dy_group, dy_skip;         /* dy_group > 1: row r reads dy row r / dy_group; the first dy_skip rows of a group get 0 */
+    float dy_scale;                    /* multiplies dy (1 / count of a mean; 1.0 otherwise) */
 } pv_layernorm_bwd_params;
 int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
 /* out[i] = scale * sum_b x[b][i], b in order (deterministic) */

@@ -213,7 +213,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
     __syncthreads();
     if (row < p.rows) {
         const half_t* x = reinterpret_cast<const half_t*>(p.x) + (size_t)row * p.ldx;
-        const half_t* dy = reinterpret_cast<const half_t*>(p.dy) + (size_t)row * p.lddy;
+        // dy may be shared by groups of rows (the patch-token mean of adapters.py:36: every patch row of a sample receives
+        // dy[sample] / count, the leading `dy_skip` rows of a group - the CLS row - receive nothing)
+        const int grp = p.dy_group > 1 ? p.dy_group : 1;
+        const int drow = row / grp;
+        const float dys = (p.dy_group > 1 && (row - drow * grp) < p.dy_skip) ? 0.f : p.dy_scale;
+        const half_t* dy = reinterpret_cast<const half_t*>(p.dy) + (size_t)drow * p.lddy;
         float sum = 0.f;
         for (int c = lane; c < p.cols; c += 64) sum += (float)x[c];
         const float mean = pv_wave_sum(sum) / (float)p.cols;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
         for (int c = lane; c < p.cols; c += 64) {
             const float xh = ((float)x[c] - mean) * rstd;
             const float z = p.gamma[c] * xh + p.beta[c];
-            float g = (float)dy[c];
+            float g = (float)dy[c] * dys;
             if (p.act == PV_ACT_LEAKY_RELU && z < 0.f) g *= 0.01f;
             const float dxh = g * p.gamma[c];
             s1 += dxh;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
         for (int c = lane; c < p.cols; c += 64) {
             const float xh = ((float)x[c] - mean) * rstd;
             const float z = p.gamma[c] * xh + p.beta[c];
-            float g = (float)dy[c];
+            float g = (float)dy[c] * dys;
             if (p.act == PV_ACT_LEAKY_RELU && z < 0.f) g *= 0.01f;
             dx[c] = (half_t)(rstd * (g * p.gamma[c] - s1 - xh * s2));
         }

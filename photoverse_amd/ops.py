@@ -294,13 +294,15 @@ class Recorder:
         w = self.transpose(x16)           # [K, Mp]
         return self.gemm(a, w, out_f32=True, splitk=0)
 
-    def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True):
+    def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0):
+        """dx fp16 [rows, cols] and (dgamma, dbeta) fp32 [2, cols].  ``dy_group`` > 1: dy has rows / dy_group rows, row r uses
+        dy[r // dy_group] * dy_scale, except the first ``dy_skip`` rows of each group (zero)."""
         rows, cols = x.shape
         dx = self.empty((rows, cols), torch.float16)
         nblk = (rows + 3) // 4
         part = self.empty((nblk, 2, cols), torch.float32) if want_affine else None
         p = LayerNormBwdParams(_ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, _ptr(gamma), _ptr(beta), _ptr(part), rows, cols,
-                               float(eps), act)
+                               float(eps), act, int(dy_group), int(dy_skip), float(dy_scale))
         self.keep.extend((x, dy, gamma, beta))
         self._add(self.lib.pv_layernorm_backward, p)
         dgb = None

@@ -279,3 +279,38 @@ def test_training_step_forward_losses_match_oracle(need_gpu):
     out2 = training_step_forward(batch, tok, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, scheduler, "cuda", layers, ENT,
                                  generator=torch.Generator().manual_seed(5), fusion_seed=3)
     assert torch.isfinite(out2["loss"]).all() and 0 <= int(out2["timesteps"].min()) and int(out2["timesteps"].max()) < 1000
+
+
+def test_adapter_backward_matches_oracle_autograd(need_gpu):
+    """BACKWARD of the reference's own adapters on HIP (what train.py:372-377 optimises): every parameter gradient of
+    PhotoVerseAdapter - both mapping MLPs of every token, through LayerNorm + LeakyReLU and the patch-token mean - against torch
+    autograd over the oracle adapter, in full mode and for a single token."""
+    from oracle.adapters_ref import PhotoVerseAdapterRef
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    torch.manual_seed(5)
+    ref = PhotoVerseAdapterRef(256, 768, 2)
+    hip = PhotoVerseAdapter(256, 768, 2)
+    hip.load_state_dict(ref.state_dict())
+    hip.to("cuda")
+    g = torch.Generator().manual_seed(6)
+    B, T = 3, 17
+    embs = [torch.randn(B, T, 256, generator=g) for _ in range(2)]
+    for token_index, G in ((None, torch.randn(B, 2, 768, generator=g)), (1, torch.randn(B, 1, 768, generator=g))):
+        for m in (ref, hip):
+            m.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            out_r = ref(embs, token_index=token_index)
+            (out_r * G).sum().backward()
+            out_h = hip([e.cuda() for e in embs], token_index=token_index)
+            assert out_h.requires_grad and rel_l2(out_h, out_r) < 3e-3
+            (out_h * G.cuda()).sum().backward()
+        gr = dict(ref.named_parameters())
+        checked = 0
+        for n, p in hip.named_parameters():
+            if gr[n].grad is None:
+                assert p.grad is None or p.grad.abs().max() == 0, n          # tokens the call did not use
+                continue
+            assert p.grad is not None and p.grad.shape == gr[n].grad.shape, n
+            assert rel_l2(p.grad, gr[n].grad) < 1e-2, (n, rel_l2(p.grad, gr[n].grad))
+            checked += 1
+        assert checked == (28 if token_index is None else 14)                 # 2 MLPs x (3 Linear + 2 LayerNorm) x (weight, bias) per token

@@ -200,8 +200,8 @@ def test_processor_backward_matches_oracle_autograd(tiny_pair, name, N):
             res.append({"h": h.grad, "t": t.grad, "i": i.grad, **{n: get(mod).grad for n, get in plist}})
         for k in res[0]:
             a, b = res[1][k], res[0][k]
-            if seed < 1 / 3 and k in ("to_k_ip",):            # text-only fusion: the image-token keys get no gradient ...
-                assert b.abs().max() == 0 and a.abs().max() < 1e-6
+            if b is None or b.abs().max() == 0:              # a branch the fusion draw dropped (e.g. to_k_ip under text-only fusion)
+                assert a is None or a.abs().max() < 1e-6, k
                 continue
             assert a is not None and a.shape == b.shape, k
             assert rel_l2(a, b) < 1e-2, (k, seed, rel_l2(a, b))
