@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 4
+#define PV_ABI_VERSION 5
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -132,8 +132,62 @@ typedef struct pv_attn_params {
     void* out; int32_t ldo;
     int32_t batch, heads, nq, nk, d;
     int32_t causal;
+    float* lse;                      /* optional fp32 [B][heads][nq]: log-sum-exp of the scaled scores in log2 units, kept for
+                                        pv_attention_backward; NULL = not written */
 } pv_attn_params;
 int pv_attention(const pv_attn_params* p, void* stream);
+
+/* Backward of pv_attention (the [EXT] AttnProcessor2_0 SDPA of attn1, models/unet.py:20-24, and the CLIP text layers the gradient
+ * of text_adapter crosses, train.py:498-500).  Probabilities are recomputed from lse; delta: fp32 workspace [B][heads][nq].
+ * dq / dk / dv: fp16 rows (may be column slices of one [dq | dk | dv] buffer).  d in {40, 64, 80, 160}.  Deterministic. */
+typedef struct pv_attn_bwd_params {
+    const void* q; const void* k; const void* v;
+    int32_t ldq, ldk, ldv;
+    const void* out; int32_t ldo;    /* the forward output O */
+    const void* dout; int32_t lddo;
+    const float* lse;
+    float* delta;
+    void* dq; void* dk; void* dv;
+    int32_t lddq, lddk, lddv;
+    int32_t batch, heads, nq, nk, d;
+    int32_t causal;
+} pv_attn_bwd_params;
+int pv_attention_backward(const pv_attn_bwd_params* p, void* stream);
+
+/* GroupNorm (+ SiLU) backward over NHWC fp16 ([EXT] ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out): data gradient
+ * only (the affine parameters are frozen in train.py).  stats: the forward's pv_groupnorm_params.partial after the statistics launch
+ * ((mean, rstd) at stats[b * stats_stride + g * 2]); partial: fp32 [B][splits][2][C]; sums: fp32 [B][groups][2].
+ * dx0 / dx1 receive the gradient of x0 / x1 (+ add0 / add1 when given - gradient accumulation of a tensor with several consumers);
+ * a NULL dx is skipped. */
+typedef struct pv_groupnorm_bwd_params {
+    const void* x0; const void* x1;
+    int32_t c0, c1, ld0, ld1;
+    int32_t batch, hw, groups, splits;
+    const float* stats; int32_t stats_stride;
+    const float* gamma; const float* beta;
+    int32_t act;
+    const void* dy; int32_t ld_dy;
+    float* partial; float* sums;
+    void* dx0; int32_t ld_dx0; const void* add0; int32_t ld_add0;
+    void* dx1; int32_t ld_dx1; const void* add1; int32_t ld_add1;
+} pv_groupnorm_bwd_params;
+int pv_groupnorm_backward(const pv_groupnorm_bwd_params* p, void* stream);
+/* GEGLU backward: h = [value | gate] fp16 [rows][2n] (pre-activation of GEGLU.proj), dy [rows][n] -> dh [rows][2n] */
+int pv_geglu_backward(const void* h, int32_t ldh, const void* dy, int32_t lddy, void* dh, int32_t lddh, int32_t rows, int32_t n, void* stream);
+/* dx = dy * act'(x) for a saved pre-activation x (quick-GELU of the CLIP MLP, SiLU, LeakyReLU, GELU) */
+int pv_act_backward(const void* x, int32_t ldx, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t rows, int32_t cols, int32_t act,
+                    void* stream);
+/* out = a + b over fp16 rows (gradient accumulation) */
+int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream);
+/* z (B,2h,2w,c) = x (B,h,w,c) at the even positions, 0 elsewhere: input of the data gradient of a stride-2 3x3 conv (Downsample2D) */
+int pv_dilate2x(const void* x, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* out (B,h,w,c) = 2x2 block sums of g (B,2h,2w,c) (+ add): gradient of the x2 nearest upsample (Upsample2D) */
+int pv_pool2x_sum(const void* g, const void* add, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* out = coef * sign(x): gradient of |x|.mean() (train.py:509, coef = weight / n) */
+int pv_sign_f32(const float* x, float coef, float* out, int64_t n, void* stream);
+/* out[b][e][:] = scale * x[b*seq + idx[b] + e][:] (fp16 rows -> fp32): gradient of the rows _inject_concept_embeddings wrote (clip.py:17-24) */
+int pv_gather_rows_f32(const void* x, int32_t ldx, const int32_t* idx, float* out, int32_t batch, int32_t seq, int32_t n_e, int32_t dim, float scale,
+                       void* stream);
 
 /* Fused dual-branch cross attention = the SDPA part of PhotoVerseAttnProcessor2_0.__call__
  * (attention_processor.py:307-322 text branch, :392-420 image-token branch and fusion):
@@ -235,6 +289,14 @@ typedef struct pv_layernorm_bwd_params {
 int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
 /* out[i] = scale * sum_b x[b][i], b in order (deterministic) */
 int pv_reduce_blocks(const float* x, int32_t nblk, int64_t inner, float scale, float* out, void* stream);
+/* out[0] = scale * sum(a^2), deterministic (gradient norms of clip_grad_norm_) */
+int pv_reduce_sumsq(const float* a, int64_t n, float scale, float* partial, int32_t n_partial, float* out, void* stream);
+/* torch.optim.AdamW step on one fp32 tensor (train.py:372-377, :545); gscale (device scalar or NULL) multiplies the gradient
+ * first - it carries 1/loss_scale and the clip_grad_norm_ coefficient without a host sync */
+int pv_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, const float* gscale, void* stream);
+/* clip_grad_norm_ (train.py:538-541): out[0] = base * min(1, max_norm / (sqrt(sum_i sumsq[i]) + 1e-6)), out[1] = the norm */
+int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream);
 /* out[c] = sum_r x[r][c] over fp16 rows (bias gradients); partial: nblk*cols floats */
 int pv_colsum_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, float* partial, int32_t nblk, float* out, void* stream);
 

@@ -37,7 +37,23 @@ class LayerNormParams(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("ldq", c_int), ("ldk", c_int), ("ldv", c_int),
                 ("out", c_void_p), ("ldo", c_int), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nk", c_int),
-                ("d", c_int), ("causal", c_int)]
+                ("d", c_int), ("causal", c_int), ("lse", c_void_p)]
+
+
+class AttnBwdParams(C.Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("ldq", c_int), ("ldk", c_int), ("ldv", c_int),
+                ("out", c_void_p), ("ldo", c_int), ("dout", c_void_p), ("lddo", c_int), ("lse", c_void_p), ("delta", c_void_p),
+                ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p), ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
+                ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nk", c_int), ("d", c_int), ("causal", c_int)]
+
+
+class GroupNormBwdParams(C.Structure):
+    _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("c0", c_int), ("c1", c_int), ("ld0", c_int), ("ld1", c_int),
+                ("batch", c_int), ("hw", c_int), ("groups", c_int), ("splits", c_int), ("stats", c_void_p), ("stats_stride", c_int),
+                ("gamma", c_void_p), ("beta", c_void_p), ("act", c_int), ("dy", c_void_p), ("ld_dy", c_int),
+                ("partial", c_void_p), ("sums", c_void_p),
+                ("dx0", c_void_p), ("ld_dx0", c_int), ("add0", c_void_p), ("ld_add0", c_int),
+                ("dx1", c_void_p), ("ld_dx1", c_int), ("add1", c_void_p), ("ld_add1", c_int)]
 
 
 class XAttnParams(C.Structure):
@@ -88,6 +104,19 @@ SIGNATURES = {
     "pv_layernorm_backward": (c_int, [C.POINTER(LayerNormBwdParams), c_void_p]),
     "pv_reduce_blocks": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]),
     "pv_colsum_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "pv_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
+                              c_void_p]),
+    "pv_attention_backward": (c_int, [C.POINTER(AttnBwdParams), c_void_p]),
+    "pv_groupnorm_backward": (c_int, [C.POINTER(GroupNormBwdParams), c_void_p]),
+    "pv_geglu_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_act_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_add_rows_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_dilate2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_pool2x_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_sign_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    "pv_gather_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "pv_reduce_sumsq": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "pv_clip_coef": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -109,7 +138,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

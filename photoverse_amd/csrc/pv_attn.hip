@@ -289,6 +289,8 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
             l = pv_quad_sum(l_run[qi]);
         }
         const float inv = 1.0f / l;
+        // log-sum-exp of the scaled scores in log2 units (P = exp2(S' - lse)): what pv_attention_backward recomputes P from
+        if (p.lse != nullptr && fq == 0 && qrow[qi] < p.nq) p.lse[((size_t)b * p.heads + h) * p.nq + qrow[qi]] = m_run[qi] + __log2f(l);
         if (qrow[qi] < p.nq) {
 #pragma unroll
             for (int f = 0; f < C::DVF; ++f) {

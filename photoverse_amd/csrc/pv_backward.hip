@@ -278,7 +278,47 @@ __global__ __launch_bounds__(256) void colsum_f16_kernel(const half_t* x, int ld
     partial[(size_t)blockIdx.y * cols + c] = a;
 }
 
+// torch.optim.AdamW step (train.py:372-377), one launch per parameter tensor, fp32 state:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),   g = grad * gscale
+// gscale folds the loss-scale removal and the clip_grad_norm_ coefficient; it is read from DEVICE memory (no host sync).
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, const float* gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// clip coefficient of torch.nn.utils.clip_grad_norm_: out[0] = min(1, max_norm / (sqrt(sum_sq) + 1e-6)) * base, sum_sq = sum of sq[i]
+__global__ void clip_coef_kernel(const float* sq, int n, float max_norm, float base, float* out) {
+    float a = 0.f;
+    for (int i = 0; i < n; ++i) a += sq[i];
+    const float norm = sqrtf(a);
+    out[0] = fminf(1.f, max_norm / (norm + 1e-6f)) * base;
+    out[1] = norm;
+}
+
 }  // namespace
+
+extern "C" int pv_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int32_t step, const float* gscale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return (int)hipErrorInvalidValue;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2s, gscale);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream) {
+    if (!sumsq || !out || n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, n, max_norm, base, out);
+    return PV_CHECK_LAUNCH();
+}
 
 extern "C" int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream) {
     if (!p->q || !p->kt || !p->vt || !p->kip || !p->vip || !p->dout || !p->dq || !p->partial || !p->dkt || !p->dvt || !p->dkip || !p->dvip ||

@@ -406,7 +406,7 @@ __global__ void posterior_sample_kernel(const float* moments, const float* eps, 
     const float logvar = fminf(fmaxf(moments[b * 2 * chw + chw + r], -30.f), 20.f);
     out[i] = mean + __expf(0.5f * logvar) * eps[i];
 }
-// stage 1 of a deterministic mean: block partial sums of f(a, b); mode 0: a, 1: |a|, 2: (a - b)^2.  a / b: fp32, or fp16 when f16 != 0
+// stage 1 of a deterministic mean: block partial sums of f(a, b); mode 0: a, 1: |a|, 2: (a - b)^2, 3: a^2.  a / b: fp32, or fp16 when f16 != 0
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const void* a_, const void* b_, int mode, int f16, long n, float* partial) {
     __shared__ float red[4];
     float acc = 0.f;
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const void* a_, con
         const float a = f16 ? (float)reinterpret_cast<const half_t*>(a_)[i] : reinterpret_cast<const float*>(a_)[i];
         if (mode == 0) acc += a;
         else if (mode == 1) acc += fabsf(a);
+        else if (mode == 3) acc += a * a;
         else {
             const float b = f16 ? (float)reinterpret_cast<const half_t*>(b_)[i] : reinterpret_cast<const float*>(b_)[i];
             acc += (a - b) * (a - b);
@@ -451,6 +452,13 @@ extern "C" int pv_reduce_mean(const void* a, const void* b, int32_t mode, int32_
     if (!a || !partial || !out || n <= 0 || n_partial <= 0 || n_partial > 4096 || mode < 0 || mode > 2 || (mode == 2 && !b)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(reduce_partial_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, a, b, mode, is_f16, (long)n, partial);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, n_partial, 1.0f / (float)n, out);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_reduce_sumsq(const float* a, int64_t n, float scale, float* partial, int32_t n_partial, float* out, void* stream) {
+    if (!a || !partial || !out || n <= 0 || n_partial <= 0 || n_partial > 4096) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, a, nullptr, 3, 0, (long)n, partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, n_partial, scale, out);
     return PV_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,676 @@
+// Backward kernels of the stock SD-v1.5 / CLIP blocks the training step back-propagates THROUGH (train.py:505-506, :536: the
+// UNet and the text encoder are frozen apart from LoRA, but the gradient has to cross them to reach the adapters, to_k_ip / to_v_ip and
+// the LoRA factors):
+//
+//   pv_attention_backward     flash-style backward of softmax(Q K^T / sqrt(d)) V (attn1 of every transformer block, CLIP text layers
+//                             with the causal mask): MFMA v_mfma_f32_16x16x32_f16, probabilities recomputed from the forward's
+//                             log-sum-exp, no atomics - one kernel owns 64 keys and walks the queries (dK, dV), one owns 64 queries
+//                             and walks the keys (dQ); fixed summation order
+//   pv_groupnorm_backward     GroupNorm (+ SiLU) backward over NHWC fp16, two-source channel concat like the forward
+//   pv_geglu_backward, pv_act_backward, pv_add_rows_f16, pv_dilate2x, pv_pool2x_sum, pv_sign_f32, pv_gather_rows_f32
+//                             elementwise / layout pieces (GEGLU gate, quick-GELU, gradient accumulation, the data-gradient of the
+//                             stride-2 and the nearest-upsample convolutions, |x|.mean() gradient, concept-row gather)
+//
+// Data gradients of every Linear / 3x3 convolution are the forward MFMA GEMM (pv_gemm_conv) on transposed / tap-flipped weights.
+#include "pv_common.h"
+
+namespace {
+
+__device__ __forceinline__ half8_t tz8() { return half8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+template <int D>
+struct BCfg {
+    static constexpr int DK = (D + 31) / 32 * 32;   // contraction length over the head dimension (zero padded)
+    static constexpr int KSTEPS = DK / 32;
+    static constexpr int DT = (D + 15) / 16;        // 16-row fragments of the d-major outputs
+    static constexpr int RS = DK + 8;               // row stride (halfs) of the row-major tiles
+    static constexpr int TS = 64 + 8;               // row stride of the transposed tiles [d][64]
+    static constexpr int CH = D / 8;                // 16-byte chunks per row
+    static constexpr int TILE = 64 * RS;            // halfs of one row-major tile
+    static constexpr int TTILE = DT * 16 * TS;      // halfs of one transposed tile
+};
+
+// stage 64 rows of a [rows][ld] fp16 matrix (columns [0, D) of head h already applied to the base pointer) into LDS as a row-major
+// tile (zero beyond D / beyond the last row) and, when sT != nullptr, as its transpose [d][row]
+template <int D>
+__device__ __forceinline__ void stage_tile(const half_t* g, int ld, int row0, int nrows, half_t* sR, half_t* sT, float mul) {
+    using C = BCfg<D>;
+    constexpr int CHP = C::DK / 8;
+    for (int i = threadIdx.x; i < 64 * CHP; i += 256) {
+        const int r = i / CHP, c = i - r * CHP;
+        half8_t v = tz8();
+        if (c < C::CH && row0 + r < nrows) v = *reinterpret_cast<const half8_t*>(g + (size_t)(row0 + r) * ld + c * 8);
+        if (mul != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * mul);
+        }
+        *reinterpret_cast<half8_t*>(sR + r * C::RS + c * 8) = v;
+        if (sT != nullptr && c * 8 < C::DT * 16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c * 8 + j < C::DT * 16) sT[(c * 8 + j) * C::TS + r] = v[j];
+        }
+    }
+}
+
+// MFMA-A fragment from a transposed tile: rows d = f*16 + fr, the 8 contraction slots {s2*32 + fq*4 + 0..3, s2*32 + 16 + fq*4 + 0..3}
+template <int D>
+__device__ __forceinline__ half8_t tfrag(const half_t* sT, int f, int s2, int fr, int fq) {
+    using C = BCfg<D>;
+    const half_t* a = sT + (f * 16 + fr) * C::TS + s2 * 32 + fq * 4;
+    const half4_t lo = *reinterpret_cast<const half4_t*>(a);
+    const half4_t hi = *reinterpret_cast<const half4_t*>(a + 16);
+    return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// delta[b][h][q] = sum_c dO[q][c] * O[q][c]
+__global__ void attn_bwd_delta_kernel(const pv_attn_bwd_params p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.batch * p.heads * p.nq;
+    if (idx >= total) return;
+    const int q = (int)(idx % p.nq), h = (int)((idx / p.nq) % p.heads), b = (int)(idx / ((long)p.nq * p.heads));
+    const half_t* o = reinterpret_cast<const half_t*>(p.out) + ((size_t)b * p.nq + q) * p.ldo + h * p.d;
+    const half_t* g = reinterpret_cast<const half_t*>(p.dout) + ((size_t)b * p.nq + q) * p.lddo + h * p.d;
+    float a = 0.f;
+    for (int c = 0; c < p.d; c += 8) {
+        const half8_t x = *reinterpret_cast<const half8_t*>(o + c), y = *reinterpret_cast<const half8_t*>(g + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
+    }
+    p.delta[idx] = a;
+}
+
+// dQ: one workgroup = 64 queries of one (sample, head) (wave w: queries 16w..16w+15 as the MFMA column), keys walked in tiles of 64.
+//   S'^T = K (q qscale)^T - lse  (log2 units)     P^T = exp2(S'^T)        dP^T = V dO^T        dS^T = P^T (dP^T - delta)
+//   dQ^T += K^T dS^T   (contraction over the 64 keys, order permuted identically on both operands)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_params p) {
+    using C = BCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sK = reinterpret_cast<half_t*>(smem);
+    half_t* sV = sK + C::TILE;
+    half_t* sKT = sV + C::TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nqt = (p.nq + 63) / 64;
+    const int qt = blockIdx.x % nqt, h = (blockIdx.x / nqt) % p.heads, b = blockIdx.x / (nqt * p.heads);
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
+    const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
+    const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
+    const float scale = rsqrtf((float)D), qscale = scale * 1.4426950408889634f;
+
+    const int qrow = qt * 64 + wave * 16 + fr;
+    const bool qok = qrow < p.nq;
+    const int qc = qok ? qrow : p.nq - 1;
+    half8_t qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const int c = ks * 4 + fq;
+        qf[ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)qc * p.ldq + c * 8) : tz8();
+        dof[ks] = (c < C::CH && qok) ? *reinterpret_cast<const half8_t*>(DO + (size_t)qc * p.lddo + c * 8) : tz8();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * qscale);    // same fp16 rounding as the forward kernel
+    }
+    const size_t bh = ((size_t)b * p.heads + h) * p.nq;
+    const float nlse = qok ? -p.lse[bh + qc] : -INFINITY;
+    const float delta = qok ? p.delta[bh + qc] : 0.f;
+
+    float4_t acc[C::DT];
+#pragma unroll
+    for (int f = 0; f < C::DT; ++f) acc[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    int ntiles = (p.nk + 63) / 64;
+    if (p.causal) ntiles = min(ntiles, min(qt * 64 + 63, p.nq - 1) / 64 + 1);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        stage_tile<D>(Kg, p.ldk, t * 64, p.nk, sK, sKT, 1.0f);
+        stage_tile<D>(Vg, p.ldv, t * 64, p.nk, sV, nullptr, 1.0f);
+        __syncthreads();
+        const bool masked = p.causal || (t + 1) * 64 > p.nk;
+        float4_t ds[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4_t s = float4_t{nlse, nlse, nlse, nlse}, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const half8_t ka = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                const half8_t va = *reinterpret_cast<const half8_t*>(sV + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = PV_EXP2(s[r]);
+                if (masked) {
+                    const int key = t * 64 + kb * 16 + fq * 4 + r;
+                    if (key >= p.nk || (p.causal && key > qrow)) pr = 0.f;
+                }
+                ds[kb][r] = pr * (dp[r] - delta);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8_t bsl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bsl[r] = (half_t)ds[2 * s2][r];
+                bsl[r + 4] = (half_t)ds[2 * s2 + 1][r];
+            }
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sKT, f, s2, fr, fq), bsl, acc[f], 0, 0, 0);
+        }
+    }
+    if (qok) {
+        half_t* dQ = reinterpret_cast<half_t*>(p.dq) + ((size_t)b * p.nq + qrow) * p.lddq + h * D;
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) {
+            const int dv = f * 16 + fq * 4;
+            if (dv < D) {
+                half4_t o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[f][r] * scale);
+                *reinterpret_cast<half4_t*>(dQ + dv) = o;
+            }
+        }
+    }
+}
+
+// dK, dV: one workgroup = 64 keys of one (sample, head) (wave w: keys 16w..16w+15 as the MFMA column), queries walked in tiles of 64.
+//   S' = (q qscale) K^T - lse      P = exp2(S')      dP = dO V^T      dS = P (dP - delta)
+//   dV^T += dO^T P      dK^T += (q qscale)^T dS / log2(e)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_params p) {
+    using C = BCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sQ = reinterpret_cast<half_t*>(smem);
+    half_t* sDO = sQ + C::TILE;
+    half_t* sQT = sDO + C::TILE;
+    half_t* sDOT = sQT + C::TTILE;
+    float* sL = reinterpret_cast<float*>(sDOT + C::TTILE);     // -lse of the 64 staged queries (-inf beyond nq)
+    float* sDl = sL + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nkt = (p.nk + 63) / 64;
+    const int kt = blockIdx.x % nkt, h = (blockIdx.x / nkt) % p.heads, b = blockIdx.x / (nkt * p.heads);
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
+    const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
+    const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
+    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
+    const size_t bh = ((size_t)b * p.heads + h) * p.nq;
+
+    const int key = kt * 64 + wave * 16 + fr;
+    const bool kok = key < p.nk;
+    const int kc = kok ? key : p.nk - 1;
+    half8_t kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const int c = ks * 4 + fq;
+        kf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Kg + (size_t)kc * p.ldk + c * 8) : tz8();
+        vf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Vg + (size_t)kc * p.ldv + c * 8) : tz8();
+    }
+    float4_t accK[C::DT], accV[C::DT];
+#pragma unroll
+    for (int f = 0; f < C::DT; ++f) accK[f] = accV[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nqt = (p.nq + 63) / 64;
+    const int t0 = p.causal ? (kt * 64) / 64 : 0;          // causal: queries before this key tile never see it
+    for (int t = t0; t < nqt; ++t) {
+        __syncthreads();
+        stage_tile<D>(Q, p.ldq, t * 64, p.nq, sQ, sQT, qscale);
+        stage_tile<D>(DO, p.lddo, t * 64, p.nq, sDO, sDOT, 1.0f);
+        if (tid < 64) {
+            const int qr = t * 64 + tid;
+            sL[tid] = qr < p.nq ? -p.lse[bh + qr] : -INFINITY;
+            sDl[tid] = qr < p.nq ? p.delta[bh + qr] : 0.f;
+        }
+        __syncthreads();
+        float4_t pw[4], ds[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            float4_t s = *reinterpret_cast<const float4_t*>(sL + qb * 16 + fq * 4);
+            const float4_t dl = *reinterpret_cast<const float4_t*>(sDl + qb * 16 + fq * 4);
+            float4_t dp = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const half8_t qa = *reinterpret_cast<const half8_t*>(sQ + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                const half8_t da = *reinterpret_cast<const half8_t*>(sDO + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(da, vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = PV_EXP2(s[r]);
+                const int qr = t * 64 + qb * 16 + fq * 4 + r;
+                if (!kok || (p.causal && key > qr)) pr = 0.f;
+                pw[qb][r] = pr;
+                ds[qb][r] = pr * (dp[r] - dl[r]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8_t bp, bs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bp[r] = (half_t)pw[2 * s2][r];
+                bp[r + 4] = (half_t)pw[2 * s2 + 1][r];
+                bs[r] = (half_t)ds[2 * s2][r];
+                bs[r + 4] = (half_t)ds[2 * s2 + 1][r];
+            }
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) {
+                accV[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sDOT, f, s2, fr, fq), bp, accV[f], 0, 0, 0);
+                accK[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sQT, f, s2, fr, fq), bs, accK[f], 0, 0, 0);
+            }
+        }
+    }
+    if (kok) {
+        half_t* dK = reinterpret_cast<half_t*>(p.dk) + ((size_t)b * p.nk + key) * p.lddk + h * D;
+        half_t* dV = reinterpret_cast<half_t*>(p.dv) + ((size_t)b * p.nk + key) * p.lddv + h * D;
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) {
+            const int dv = f * 16 + fq * 4;
+            if (dv < D) {
+                half4_t ok_, ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ok_[r] = (half_t)(accK[f][r] * 0.6931471805599453f);
+                    ov[r] = (half_t)accV[f][r];
+                }
+                *reinterpret_cast<half4_t*>(dK + dv) = ok_;
+                *reinterpret_cast<half4_t*>(dV + dv) = ov;
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
+    using C = BCfg<D>;
+    constexpr int smem_dq = (2 * C::TILE + C::TTILE) * 2;
+    constexpr int smem_dkv = (2 * C::TILE + 2 * C::TTILE) * 2 + 128 * 4;
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long rows = (long)p.batch * p.heads * p.nq;
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3((unsigned)(((p.nk + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dkv, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)(((p.nq + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dq, s, p);
+    return PV_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GroupNorm (+ SiLU) backward.  y = act(z), z = gamma xhat + beta, xhat = (x - mean) rstd, statistics per (image, group):
+//   dxhat = dy act'(z) gamma;  dx = rstd (dxhat - mean_g(dxhat) - xhat mean_g(dxhat xhat))
+// Thread = one 8-channel chunk x one pixel lane; grid (pixel splits, images, 64-chunk blocks).
+constexpr int GB_CPB = 64;    // channel chunks per workgroup
+constexpr int GB_ROWS = 4;    // pixel lanes per workgroup
+
+struct GnbCoef {
+    float a[8], bsh[8], g[8], rstd[8], m1[8], m2[8];
+};
+
+__device__ __forceinline__ half8_t gnb_load(const pv_groupnorm_bwd_params& p, size_t row, int chunk) {
+    const int c = chunk * 8;
+    if (c < p.c0) return *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.x0) + row * p.ld0 + c);
+    return *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.x1) + row * p.ld1 + (c - p.c0));
+}
+
+__device__ __forceinline__ void gnb_coef(const pv_groupnorm_bwd_params& p, int b, int chunk, bool with_sums, GnbCoef& k) {
+    const int C = p.c0 + p.c1, cpg = C / p.groups;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j, g = c / cpg;
+        const float* st = p.stats + (size_t)b * p.stats_stride + g * 2;
+        const float mean = st[0], rstd = st[1];
+        k.rstd[j] = rstd;
+        k.g[j] = p.gamma[c];
+        k.a[j] = rstd;                    // xhat = x * a + bsh
+        k.bsh[j] = -mean * rstd;
+        if (with_sums) {
+            k.m1[j] = p.sums[((size_t)b * p.groups + g) * 2];
+            k.m2[j] = p.sums[((size_t)b * p.groups + g) * 2 + 1];
+        }
+    }
+}
+
+// dxhat for one element
+__device__ __forceinline__ float gnb_dxhat(float xhat, float dy, float gamma, float beta, int act) {
+    float dz = dy;
+    if (act == PV_ACT_SILU) {
+        const float z = xhat * gamma + beta;
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+        dz = dy * sg * (1.0f + z * (1.0f - sg));
+    }
+    return dz * gamma;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const pv_groupnorm_bwd_params p) {
+    __shared__ float red[GB_ROWS][GB_CPB][16];
+    const int C = p.c0 + p.c1, nchunk = C / 8;
+    const int tid = threadIdx.x, cl = tid % GB_CPB, r = tid / GB_CPB;
+    const int chunk = blockIdx.z * GB_CPB + cl, b = blockIdx.y, split = blockIdx.x;
+    const bool ok = chunk < nchunk;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (ok) {
+        GnbCoef k;
+        gnb_coef(p, b, chunk, false, k);
+        float beta[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) beta[j] = p.beta[chunk * 8 + j];
+        const int per = (p.hw + p.splits - 1) / p.splits;
+        const int px0 = split * per, px1 = min(px0 + per, p.hw);
+        for (int px = px0 + r; px < px1; px += GB_ROWS) {
+            const size_t row = (size_t)b * p.hw + px;
+            const half8_t xv = gnb_load(p, row, chunk);
+            const half8_t dv = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.dy) + row * p.ld_dy + chunk * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (float)xv[j] * k.a[j] + k.bsh[j];
+                const float dxh = gnb_dxhat(xh, (float)dv[j], k.g[j], beta[j], p.act);
+                s1[j] += dxh;
+                s2[j] += dxh * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[r][cl][j] = s1[j];
+        red[r][cl][8 + j] = s2[j];
+    }
+    __syncthreads();
+    if (r == 0 && ok) {
+        float* out = p.partial + (((size_t)b * p.splits + split) * 2) * C + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < GB_ROWS; ++rr) {
+                a += red[rr][cl][j];
+                q += red[rr][cl][8 + j];
+            }
+            out[j] = a;
+            out[C + j] = q;
+        }
+    }
+}
+
+// one wave per (image, group): fixed-order sum over splits x channels of the group -> sums[b][g] = (mean dxhat, mean dxhat*xhat)
+__global__ void gn_bwd_finalize_kernel(const pv_groupnorm_bwd_params p) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= p.batch * p.groups) return;
+    const int b = idx / p.groups, g = idx - b * p.groups;
+    const int C = p.c0 + p.c1, cpg = C / p.groups;
+    float a = 0.f, q = 0.f;
+    for (int i = lane; i < p.splits * cpg; i += 64) {
+        const int s = i / cpg, c = g * cpg + (i - s * cpg);
+        const float* src = p.partial + (((size_t)b * p.splits + s) * 2) * C + c;
+        a += src[0];
+        q += src[C];
+    }
+    a = pv_wave_sum(a);
+    q = pv_wave_sum(q);
+    if (lane == 0) {
+        const float n = (float)cpg * (float)p.hw;
+        p.sums[((size_t)b * p.groups + g) * 2] = a / n;
+        p.sums[((size_t)b * p.groups + g) * 2 + 1] = q / n;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pv_groupnorm_bwd_params p, const int px_per_block) {
+    const int C = p.c0 + p.c1, nchunk = C / 8;
+    const int tid = threadIdx.x, cl = tid % GB_CPB, r = tid / GB_CPB;
+    const int chunk = blockIdx.z * GB_CPB + cl, b = blockIdx.y;
+    if (chunk >= nchunk) return;
+    GnbCoef k;
+    gnb_coef(p, b, chunk, true, k);
+    float beta[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) beta[j] = p.beta[chunk * 8 + j];
+    const int c = chunk * 8;
+    const bool first = c < p.c0;
+    half_t* dx = first ? reinterpret_cast<half_t*>(p.dx0) : reinterpret_cast<half_t*>(p.dx1);
+    const half_t* add = first ? reinterpret_cast<const half_t*>(p.add0) : reinterpret_cast<const half_t*>(p.add1);
+    const int ldx = first ? p.ld_dx0 : p.ld_dx1, lda = first ? p.ld_add0 : p.ld_add1, cc = first ? c : c - p.c0;
+    if (dx == nullptr) return;
+    const int px0 = blockIdx.x * px_per_block, px1 = min(px0 + px_per_block, p.hw);
+    for (int px = px0 + r; px < px1; px += GB_ROWS) {
+        const size_t row = (size_t)b * p.hw + px;
+        const half8_t xv = gnb_load(p, row, chunk);
+        const half8_t dv = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.dy) + row * p.ld_dy + chunk * 8);
+        half8_t av = tz8();
+        if (add) av = *reinterpret_cast<const half8_t*>(add + row * lda + cc);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (float)xv[j] * k.a[j] + k.bsh[j];
+            const float dxh = gnb_dxhat(xh, (float)dv[j], k.g[j], beta[j], p.act);
+            o[j] = (half_t)(k.rstd[j] * (dxh - k.m1[j] - xh * k.m2[j]) + (float)av[j]);
+        }
+        *reinterpret_cast<half8_t*>(dx + row * ldx + cc) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// elementwise / layout pieces
+
+// GEGLU: y = a * gelu(g), h = [a | g] (each n wide).  dh = [dy gelu(g) | dy a gelu'(g)], gelu'(g) = Phi(g) + g phi(g)
+__global__ void geglu_bwd_kernel(const half_t* h, int ldh, const half_t* dy, int lddy, half_t* dh, int lddh, int rows, int n) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = n / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const half8_t a = *reinterpret_cast<const half8_t*>(h + (size_t)r * ldh + c);
+    const half8_t g = *reinterpret_cast<const half8_t*>(h + (size_t)r * ldh + n + c);
+    const half8_t d = *reinterpret_cast<const half8_t*>(dy + (size_t)r * lddy + c);
+    half8_t da, dg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gv = (float)g[j], dv = (float)d[j];
+        const float cdf = 0.5f * (1.0f + pv_erf_fast(gv * 0.70710678118654752440f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * gv * gv);
+        da[j] = (half_t)(dv * gv * cdf);
+        dg[j] = (half_t)(dv * (float)a[j] * (cdf + gv * pdf));
+    }
+    *reinterpret_cast<half8_t*>(dh + (size_t)r * lddh + c) = da;
+    *reinterpret_cast<half8_t*>(dh + (size_t)r * lddh + n + c) = dg;
+}
+
+// dx = dy * act'(x) for the pointwise activations applied to a saved pre-activation x
+__global__ void act_bwd_kernel(const half_t* x, int ldx, const half_t* dy, int lddy, half_t* dx, int lddx, int rows, int cols, int act) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const half8_t xv = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + c);
+    const half8_t dv = *reinterpret_cast<const half8_t*>(dy + (size_t)r * lddy + c);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (float)xv[j];
+        float g = 1.0f;
+        if (act == PV_ACT_QUICK_GELU) {
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * v));
+            g = sg * (1.0f + 1.702f * v * (1.0f - sg));
+        } else if (act == PV_ACT_SILU) {
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            g = sg * (1.0f + v * (1.0f - sg));
+        } else if (act == PV_ACT_LEAKY_RELU) {
+            g = v > 0.f ? 1.0f : 0.01f;
+        } else if (act == PV_ACT_GELU) {
+            g = 0.5f * (1.0f + pv_erf_fast(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+        }
+        o[j] = (half_t)((float)dv[j] * g);
+    }
+    *reinterpret_cast<half8_t*>(dx + (size_t)r * lddx + c) = o;
+}
+
+__global__ void add_rows_kernel(const half_t* a, int lda, const half_t* b, int ldb, half_t* out, int ldo, int rows, int cols) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const half8_t x = *reinterpret_cast<const half8_t*>(a + (size_t)r * lda + c);
+    const half8_t y = *reinterpret_cast<const half8_t*>(b + (size_t)r * ldb + c);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)x[j] + (float)y[j]);
+    *reinterpret_cast<half8_t*>(out + (size_t)r * ldo + c) = o;
+}
+
+// z[b][2i][2j][:] = x[b][i][j][:], zeros elsewhere (input of the data-gradient convolution of a stride-2 3x3 conv)
+__global__ void dilate2x_kernel(const half_t* x, half_t* z, int batch, int h, int w, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = c / 8;
+    const long total = (long)batch * 4 * h * w * nch;
+    if (idx >= total) return;
+    const int ch = (int)(idx % nch);
+    const long px = idx / nch;
+    const int j2 = (int)(px % (2 * w)), i2 = (int)((px / (2 * w)) % (2 * h)), b = (int)(px / ((long)4 * h * w));
+    half8_t v = tz8();
+    if (!(i2 & 1) && !(j2 & 1)) v = *reinterpret_cast<const half8_t*>(x + (((size_t)b * h + i2 / 2) * w + j2 / 2) * c + ch * 8);
+    *reinterpret_cast<half8_t*>(z + (size_t)px * c + ch * 8) = v;
+}
+
+// out[b][i][j][:] = sum of the 2x2 block of g (+ add): gradient of the x2 nearest upsample
+__global__ void pool2x_kernel(const half_t* g, const half_t* add, half_t* out, int batch, int h, int w, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = c / 8;
+    const long total = (long)batch * h * w * nch;
+    if (idx >= total) return;
+    const int ch = (int)(idx % nch);
+    const long px = idx / nch;
+    const int j = (int)(px % w), i = (int)((px / w) % h), b = (int)(px / ((long)h * w));
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (add) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(add + (size_t)px * c + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (float)v[e];
+    }
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const half8_t v = *reinterpret_cast<const half8_t*>(g + (((size_t)b * 2 * h + 2 * i + di) * 2 * w + 2 * j + dj) * c + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+        }
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
+    *reinterpret_cast<half8_t*>(out + (size_t)px * c + ch * 8) = o;
+}
+
+__global__ void sign_kernel(const float* x, float coef, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] > 0.f ? coef : (x[i] < 0.f ? -coef : 0.f);
+}
+
+// out[b][e][:] = scale * x[b * seq + idx[b] + e][:]  (fp16 rows -> fp32): gradient of the concept rows written by
+// _inject_concept_embeddings (clip.py:17-24)
+__global__ void gather_rows_kernel(const half_t* x, int ldx, const int32_t* idx, float* out, int batch, int seq, int n_e, int dim, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * n_e * dim) return;
+    const int c = (int)(i % dim), e = (int)((i / dim) % n_e), b = (int)(i / ((long)dim * n_e));
+    const int row = idx[b] + e;
+    out[i] = (row >= 0 && row < seq) ? scale * (float)x[((size_t)b * seq + row) * ldx + c] : 0.f;
+}
+
+}  // namespace
+
+extern "C" int pv_attention_backward(const pv_attn_bwd_params* p, void* stream) {
+    if (!p || !p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->delta || !p->dq || !p->dk || !p->dv) return (int)hipErrorInvalidValue;
+    if (p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nk <= 0) return (int)hipErrorInvalidValue;
+    if ((p->ldq | p->ldk | p->ldv | p->ldo | p->lddo | p->lddq | p->lddk | p->lddv) % 8) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->d) {
+        case 40: return launch_attn_bwd<40>(*p, s);
+        case 64: return launch_attn_bwd<64>(*p, s);
+        case 80: return launch_attn_bwd<80>(*p, s);
+        case 160: return launch_attn_bwd<160>(*p, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+extern "C" int pv_groupnorm_backward(const pv_groupnorm_bwd_params* p, void* stream) {
+    if (!p || !p->x0 || !p->dy || !p->stats || !p->gamma || !p->beta || !p->partial || !p->sums) return (int)hipErrorInvalidValue;
+    const int C = p->c0 + p->c1;
+    if (C % 8 || p->c0 % 8 || C % p->groups || p->groups > 64 || p->splits < 1 || p->splits > 64 || (p->c1 > 0 && !p->x1)) return (int)hipErrorInvalidValue;
+    if ((p->ld0 | p->ld1 | p->ld_dy | p->ld_dx0 | p->ld_dx1 | p->ld_add0 | p->ld_add1) % 8) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const int zb = (C / 8 + GB_CPB - 1) / GB_CPB;
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)p->splits, (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)((p->batch * p->groups + 3) / 4)), dim3(256), 0, s, *p);
+    const int ppb = 64;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((p->hw + ppb - 1) / ppb), (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p, ppb);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_geglu_backward(const void* h, int32_t ldh, const void* dy, int32_t lddy, void* dh, int32_t lddh, int32_t rows, int32_t n, void* stream) {
+    if (!h || !dy || !dh || rows <= 0 || n <= 0 || n % 8 || (ldh | lddy | lddh) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (n / 8);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)h, ldh, (const half_t*)dy, lddy,
+                       (half_t*)dh, lddh, rows, n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_act_backward(const void* x, int32_t ldx, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t rows, int32_t cols, int32_t act,
+                               void* stream) {
+    if (!x || !dy || !dx || rows <= 0 || cols <= 0 || cols % 8 || (ldx | lddy | lddx) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (const half_t*)dy, lddy,
+                       (half_t*)dx, lddx, rows, cols, act);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream) {
+    if (!a || !b || !out || rows <= 0 || cols <= 0 || cols % 8 || (lda | ldb | ldo) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, lda, (const half_t*)b, ldb,
+                       (half_t*)out, ldo, rows, cols);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_dilate2x(const void* x, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!x || !z || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(dilate2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)z, batch, h, w, c);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_pool2x_sum(const void* g, const void* add, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!g || !out || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * h * w * (c / 8);
+    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)g, (const half_t*)add, (half_t*)out,
+                       batch, h, w, c);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_sign_f32(const float* x, float coef, float* out, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, coef, out, (long)n);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_gather_rows_f32(const void* x, int32_t ldx, const int32_t* idx, float* out, int32_t batch, int32_t seq, int32_t n_e, int32_t dim, float scale,
+                                  void* stream) {
+    if (!x || !idx || !out || batch <= 0 || seq <= 0 || n_e <= 0 || dim <= 0) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * n_e * dim;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, idx, out, batch, seq, n_e,
+                       dim, scale);
+    return PV_CHECK_LAUNCH();
+}

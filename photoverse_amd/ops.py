@@ -16,8 +16,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (AttnParams, GemmParams, GroupNormParams, LayerNormBwdParams, LayerNormParams, XAttnBwdParams, XAttnFusedParams,
-                   XAttnParams)
+from ._lib import (AttnBwdParams, AttnParams, GemmParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
+                   XAttnBwdParams, XAttnFusedParams, XAttnParams)
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
@@ -166,7 +166,9 @@ class Recorder:
         return out
 
     def groupnorm(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5,
-                  act=ACT_NONE, groups=32) -> torch.Tensor:
+                  act=ACT_NONE, groups=32, return_stats=False) -> torch.Tensor:
+        """``return_stats``: also return the statistics buffer ((mean, rstd) per (image, group) at ``stats[b, g*2 : g*2+2]``) for
+        ``groupnorm_backward``."""
         ld0, c0 = _rows(x)
         ld1, c1 = _rows(x1) if x1 is not None else (0, 0)
         splits = 64
@@ -182,7 +184,7 @@ class Recorder:
         self.keep.extend(t for t in (x, x1, gamma, beta) if t is not None)
         self._add(self.lib.pv_groupnorm_stats_from_colstats if from_cs else self.lib.pv_groupnorm_stats, p)
         self._add(self.lib.pv_groupnorm_apply, p)
-        return y
+        return (y, partial.view(batch, -1)) if return_stats else y
 
     def layernorm(self, x: torch.Tensor, gamma, beta, *, eps=1e-5, act=ACT_NONE, out=None) -> torch.Tensor:
         ldx, cols = _rows(x)
@@ -194,16 +196,102 @@ class Recorder:
         self._add(self.lib.pv_layernorm, p)
         return out
 
-    def attention(self, q, k, v, *, batch, heads, nq, nk, d, causal=False, out=None) -> torch.Tensor:
+    def attention(self, q, k, v, *, batch, heads, nq, nk, d, causal=False, out=None, lse=None) -> torch.Tensor:
+        """``lse``: optional fp32 [batch, heads, nq] buffer that receives the log-sum-exp ``attention_backward`` needs."""
         ldq, _ = _rows(q)
         ldk, _ = _rows(k)
         ldv, _ = _rows(v)
         if out is None:
             out = self.empty((batch * nq, heads * d), torch.float16)
         ldo, _ = _rows(out)
-        p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal))
-        self.keep.extend((q, k, v, out))
+        p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal), _ptr(lse))
+        self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
         self._add(self.lib.pv_attention, p)
+        return out
+
+    # ---- backward of the stock blocks the training gradient crosses (pv_train.hip) ----
+    def attention_backward(self, q, k, v, out, dout, lse, *, batch, heads, nq, nk, d, causal=False, dq=None, dk=None, dv=None):
+        """(dq, dk, dv) fp16 rows of softmax(q k^T / sqrt(d)) v; pass column slices of one buffer to get [dq | dk | dv]."""
+        C_ = heads * d
+        dq = self.empty((batch * nq, C_)) if dq is None else dq
+        dk = self.empty((batch * nk, C_)) if dk is None else dk
+        dv = self.empty((batch * nk, C_)) if dv is None else dv
+        delta = self.empty((batch, heads, nq), torch.float32)
+        p = AttnBwdParams(_ptr(q), _ptr(k), _ptr(v), _rows(q)[0], _rows(k)[0], _rows(v)[0], _ptr(out), _rows(out)[0], _ptr(dout), _rows(dout)[0],
+                          _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
+                          int(causal))
+        self.keep.extend((q, k, v, out, dout, lse, dq, dk, dv))
+        self._add(self.lib.pv_attention_backward, p)
+        return dq, dk, dv
+
+    def groupnorm_backward(self, x, dy, stats, gamma, beta, *, batch, hw, x1=None, act=ACT_NONE, groups=32, add0=None, add1=None,
+                           want0=True, want1=True):
+        """Data gradient of ``groupnorm`` (``stats`` = the ``stats`` it returned): (dx0, dx1) fp16, each + its ``add`` when given."""
+        ld0, c0 = _rows(x)
+        ld1, c1 = _rows(x1) if x1 is not None else (0, 0)
+        Cc = c0 + c1
+        splits = 64
+        while splits > 1 and (hw % splits or hw // splits < 16):
+            splits //= 2
+        partial = self.empty((batch, splits, 2, Cc), torch.float32)
+        sums = self.empty((batch, groups, 2), torch.float32)
+        dx0 = self.empty((batch * hw, c0)) if want0 else None
+        dx1 = self.empty((batch * hw, c1)) if (want1 and x1 is not None) else None
+        p = GroupNormBwdParams(_ptr(x), _ptr(x1), c0, c1, ld0, ld1, batch, hw, groups, splits, _ptr(stats), stats.stride(0), _ptr(gamma), _ptr(beta),
+                               act, _ptr(dy), _rows(dy)[0], _ptr(partial), _ptr(sums),
+                               _ptr(dx0), c0, _ptr(add0), _rows(add0)[0] if add0 is not None else 0,
+                               _ptr(dx1), c1, _ptr(add1), _rows(add1)[0] if add1 is not None else 0)
+        self.keep.extend(t for t in (x, x1, dy, stats, gamma, beta, add0, add1) if t is not None)
+        self._add(self.lib.pv_groupnorm_backward, p)
+        return dx0, dx1
+
+    def geglu_backward(self, h, dy):
+        rows, n2 = h.shape
+        dh = self.empty((rows, n2))
+        self.keep.extend((h, dy))
+        self._add(self.lib.pv_geglu_backward, _ptr(h), _rows(h)[0], _ptr(dy), _rows(dy)[0], _ptr(dh), n2, rows, n2 // 2)
+        return dh
+
+    def act_backward(self, x, dy, act):
+        rows, cols = x.shape
+        dx = self.empty((rows, cols))
+        self.keep.extend((x, dy))
+        self._add(self.lib.pv_act_backward, _ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, rows, cols, act)
+        return dx
+
+    def add_rows(self, a, b, out=None):
+        rows, cols = a.shape
+        if out is None:
+            out = self.empty((rows, cols))
+        self.keep.extend((a, b, out))
+        self._add(self.lib.pv_add_rows_f16, _ptr(a), _rows(a)[0], _ptr(b), _rows(b)[0], _ptr(out), _rows(out)[0], rows, cols)
+        return out
+
+    def dilate2x(self, x, *, batch, h, w):
+        c = x.shape[1]
+        z = self.empty((batch * 4 * h * w, c))
+        self.keep.append(x)
+        self._add(self.lib.pv_dilate2x, _ptr(x), _ptr(z), batch, h, w, c)
+        return z
+
+    def pool2x_sum(self, g, *, batch, h, w, add=None):
+        c = g.shape[1]
+        out = self.empty((batch * h * w, c))
+        self.keep.extend(t for t in (g, add) if t is not None)
+        self._add(self.lib.pv_pool2x_sum, _ptr(g), _ptr(add), _ptr(out), batch, h, w, c)
+        return out
+
+    def sign(self, x, coef):
+        out = self.empty(tuple(x.shape), torch.float32)
+        self.keep.append(x)
+        self._add(self.lib.pv_sign_f32, _ptr(x), float(coef), _ptr(out), x.numel())
+        return out
+
+    def gather_rows(self, x, idx, *, batch, seq, n_e, scale=1.0):
+        dim = x.shape[1]
+        out = self.empty((batch, n_e, dim), torch.float32)
+        self.keep.extend((x, idx))
+        self._add(self.lib.pv_gather_rows_f32, _ptr(x), _rows(x)[0], _ptr(idx), _ptr(out), batch, seq, n_e, dim, float(scale))
         return out
 
     def cross_attention(self, q, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, vnorm=None, out=None, fusion=None):
@@ -376,6 +464,14 @@ class Recorder:
         assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.dtype == a.dtype and b.numel() == a.numel()))
         self.keep.extend(t for t in (a, b, out) if t is not None)
         self._add(self.lib.pv_reduce_mean, _ptr(a), _ptr(b), m, int(a.dtype == torch.float16), a.numel(), _ptr(partial), nb, _ptr(out))
+        return out
+
+    def reduce_sumsq(self, a, *, out, scale=1.0):
+        """out[0] = scale * sum(a^2) for an fp32 tensor, deterministic."""
+        nb = max(1, min(1024, (a.numel() + 4095) // 4096))
+        partial = self.empty((nb,), torch.float32)
+        self.keep.extend((a, out))
+        self._add(self.lib.pv_reduce_sumsq, _ptr(a), a.numel(), float(scale), _ptr(partial), nb, _ptr(out))
         return out
 
     def clamp_(self, x, lo, hi):

@@ -316,3 +316,30 @@ def test_adapter_backward_matches_oracle_autograd(need_gpu):
             assert rel_l2(p.grad, gr[n].grad) < 4e-2, (n, rel_l2(p.grad, gr[n].grad))
             checked += 1
         assert checked == (40 if token_index is None else 20)                 # per token: 2 MLPs x (3 Linear + 2 LayerNorm) x (weight, bias)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grad_scale", [1.0, 256.0])
+def test_adamw_and_clip_match_torch(grad_scale):
+    """optim.AdamW (HIP kernels, device-side clip coefficient) against torch.optim.AdamW + clip_grad_norm_ on CPU fp32
+    (train.py:372-377, :538-545): three steps, two clip groups + one unclipped parameter."""
+    from photoverse_amd.optim import AdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1024, 768), (1024,), (320, 768), (7,), (33, 5)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    o_hip = AdamW(mine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    groups = ([0, 1], [2, 3])
+    for step in range(3):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g) * (0.05 if step == 1 else 2.0)     # step 1: norm < 1 -> coefficient clamps at 1
+            p.grad = gr.clone()
+            q.grad = (gr * grad_scale).cuda()
+        want_norms = [float(torch.nn.utils.clip_grad_norm_([ref[i] for i in grp], 1.0)) for grp in groups]
+        o_ref.step()
+        norms = o_hip.step(clip_groups=[[mine[i] for i in grp] for grp in groups], max_norm=1.0, grad_scale=grad_scale)
+        for n, w in zip(norms, want_norms):
+            assert abs(float(n) - w) < 1e-4 * w
+        for p, q in zip(ref, mine):
+            assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step

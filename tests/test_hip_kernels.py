@@ -428,3 +428,120 @@ def test_bad_arguments_fail_loudly(rec_cls):
     rec.gemm(a, w)
     with pytest.raises(HipLaunchError):
         rec.run()
+
+
+# ------------------------------------------------------------------ backward kernels of the stock blocks (pv_train.hip)
+@pytest.mark.parametrize("B,H,N,d,causal", [(2, 2, 200, 40, False), (1, 2, 130, 80, False), (2, 3, 77, 64, True), (1, 2, 64, 160, False),
+                                             (1, 1, 333, 40, True)])
+def test_self_attention_backward(rec_cls, B, H, N, d, causal):
+    """pv_attention (lse output) + pv_attention_backward against autograd through fp32 SDPA."""
+    g = torch.Generator().manual_seed(N + d)
+    C = H * d
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    dout = torch.randn(B * N, C, generator=g)
+    q32, k32, v32 = (qkv[:, i * C:(i + 1) * C].half().float().view(B, N, H, d).transpose(1, 2).clone().requires_grad_() for i in range(3))
+    ref = F.scaled_dot_product_attention(q32, k32, v32, is_causal=causal)
+    ref.backward(dout.half().float().view(B, N, H, d).transpose(1, 2))
+    want = [t.grad.transpose(1, 2).reshape(B * N, C) for t in (q32, k32, v32)]
+
+    rec = rec_cls("cuda")
+    x = qkv.half().cuda()
+    lse = rec.empty((B, H, N), torch.float32)
+    o = rec.attention(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], batch=B, heads=H, nq=N, nk=N, d=d, causal=causal, lse=lse)
+    dqkv = rec.empty((B * N, 3 * C))
+    rec.attention_backward(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], o, dout.half().cuda(), lse, batch=B, heads=H, nq=N, nk=N, d=d, causal=causal,
+                           dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+    rec.run()
+    torch.cuda.synchronize()
+    assert rel_l2(o.float().cpu(), ref.detach().transpose(1, 2).reshape(B * N, C)) < 2e-3
+    # lse: natural-log logsumexp of the scaled scores, in log2 units
+    s = (q32.detach() @ k32.detach().transpose(-1, -2)) / d ** 0.5
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+    assert (lse.cpu() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max() < 2e-2
+    for i, name in enumerate("qkv"):
+        assert rel_l2(dqkv[:, i * C:(i + 1) * C].float().cpu(), want[i]) < 4e-3, name
+
+
+@pytest.mark.parametrize("B,hw,c0,c1,act,with_add", [(2, 256, 320, 0, "silu", False), (1, 64, 640, 320, "silu", True), (2, 144, 320, 0, "none", True),
+                                                      (1, 16, 1280, 1280, "silu", False)])
+def test_groupnorm_backward(rec_cls, B, hw, c0, c1, act, with_add):
+    from photoverse_amd import ops
+    g = torch.Generator().manual_seed(hw + c0)
+    C = c0 + c1
+    x = (torch.randn(B, hw, C, generator=g) * 1.5 + 0.3).half()
+    gamma, beta = torch.randn(C, generator=g) * 0.5 + 1, torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(B, hw, C, generator=g).half()
+    add = torch.randn(B, hw, C, generator=g).half()
+    xr = x.float().requires_grad_()
+    y = F.group_norm(xr.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    if act == "silu":
+        y = F.silu(y)
+    y.backward(dy.float())
+    want = xr.grad + (add.float() if with_add else 0)
+
+    rec = rec_cls("cuda")
+    xc = x.cuda().view(B * hw, C)
+    x0 = xc[:, :c0].contiguous()
+    x1 = xc[:, c0:].contiguous() if c1 else None
+    a = ops.ACT_SILU if act == "silu" else ops.ACT_NONE
+    yk, stats = rec.groupnorm(x0, gamma.cuda(), beta.cuda(), batch=B, hw=hw, x1=x1, eps=1e-5, act=a, return_stats=True)
+    addc = add.cuda().view(B * hw, C)
+    dx0, dx1 = rec.groupnorm_backward(x0, dy.cuda().view(B * hw, C), stats, gamma.cuda(), beta.cuda(), batch=B, hw=hw, x1=x1, act=a,
+                                      add0=addc[:, :c0] if with_add else None, add1=(addc[:, c0:] if (with_add and c1) else None))
+    rec.run()
+    torch.cuda.synchronize()
+    assert rel_l2(yk.float().cpu().view(B, hw, C), y.detach()) < 2e-3
+    got = torch.cat([dx0] + ([dx1] if c1 else []), 1).float().cpu().view(B, hw, C)
+    assert rel_l2(got, want) < 3e-3
+
+
+def test_elementwise_backward_pieces(rec_cls):
+    from photoverse_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rec = rec_cls("cuda")
+    # GEGLU
+    h = torch.randn(100, 2 * 640, generator=g).half()
+    dy = torch.randn(100, 640, generator=g).half()
+    hr = h.float().requires_grad_()
+    (hr[:, :640] * F.gelu(hr[:, 640:])).backward(dy.float())
+    dh = rec.geglu_backward(h.cuda(), dy.cuda())
+    # quick-GELU / SiLU
+    x = torch.randn(77, 3072, generator=g).half()
+    d2 = torch.randn(77, 3072, generator=g).half()
+    xr = x.float().requires_grad_()
+    (xr * torch.sigmoid(1.702 * xr)).backward(d2.float())
+    want_q = xr.grad.clone()
+    xr.grad = None
+    F.silu(xr).backward(d2.float())
+    dq_ = rec.act_backward(x.cuda(), d2.cuda(), ops.ACT_QUICK_GELU)
+    ds_ = rec.act_backward(x.cuda(), d2.cuda(), ops.ACT_SILU)
+    # add, dilate, pool
+    a, b = torch.randn(50, 320, generator=g).half(), torch.randn(50, 320, generator=g).half()
+    s_ = rec.add_rows(a.cuda(), b.cuda())
+    t = torch.randn(2, 3, 5, 64, generator=g).half()
+    z = rec.dilate2x(t.cuda().view(-1, 64), batch=2, h=3, w=5)
+    big = torch.randn(2, 6, 10, 64, generator=g).half()
+    addp = torch.randn(2, 3, 5, 64, generator=g).half()
+    pl = rec.pool2x_sum(big.cuda().view(-1, 64), batch=2, h=3, w=5, add=addp.cuda().view(-1, 64))
+    # sign, gather
+    v = torch.randn(4, 1, 768, generator=g)
+    v[0, 0, :5] = 0
+    sg = rec.sign(v.cuda(), 0.25)
+    rows = torch.randn(4 * 77, 768, generator=g).half()
+    idx = torch.tensor([5, 1, 71, 76], dtype=torch.int32)
+    gr = rec.gather_rows(rows.cuda(), idx.cuda(), batch=4, seq=77, n_e=1, scale=0.5)
+    rec.run()
+    torch.cuda.synchronize()
+    assert rel_l2(dh.float().cpu(), hr.grad) < 2e-3
+    assert rel_l2(dq_.float().cpu(), want_q) < 2e-3
+    assert rel_l2(ds_.float().cpu(), xr.grad) < 2e-3
+    assert torch.equal(s_.cpu(), (a.float() + b.float()).half())
+    zr = torch.zeros(2, 6, 10, 64, dtype=torch.float16)
+    zr[:, ::2, ::2] = t
+    assert torch.equal(z.cpu().view(2, 6, 10, 64), zr)
+    pr = big.float().view(2, 3, 2, 5, 2, 64).sum((2, 4)) + addp.float()
+    assert rel_l2(pl.float().cpu().view(2, 3, 5, 64), pr) < 1e-3
+    assert torch.equal(sg.cpu(), 0.25 * torch.sign(v))
+    want_g = torch.stack([0.5 * rows.float().view(4, 77, 768)[b, idx[b]] for b in range(4)]).view(4, 1, 768)
+    assert torch.equal(gr.cpu(), want_g)
