@@ -177,12 +177,14 @@ int pv_geglu_backward(const void* h, int32_t ldh, const void* dy, int32_t lddy, 
 /* dx = dy * act'(x) for a saved pre-activation x (quick-GELU of the CLIP MLP, SiLU, LeakyReLU, GELU) */
 int pv_act_backward(const void* x, int32_t ldx, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t rows, int32_t cols, int32_t act,
                     void* stream);
+/* y = act(x) as its own pass (the training forward keeps the pre-activation) */
+int pv_act_forward(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t rows, int32_t cols, int32_t act, void* stream);
 /* out = a + b over fp16 rows (gradient accumulation) */
 int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream);
 /* z (B,2h,2w,c) = x (B,h,w,c) at the even positions, 0 elsewhere: input of the data gradient of a stride-2 3x3 conv (Downsample2D) */
-int pv_dilate2x(const void* x, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+int pv_dilate2x(const void* x, int32_t ldx, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* out (B,h,w,c) = 2x2 block sums of g (B,2h,2w,c) (+ add): gradient of the x2 nearest upsample (Upsample2D) */
-int pv_pool2x_sum(const void* g, const void* add, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+int pv_pool2x_sum(const void* g, const void* add, int32_t ldadd, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* out = coef * sign(x): gradient of |x|.mean() (train.py:509, coef = weight / n) */
 int pv_sign_f32(const float* x, float coef, float* out, int64_t n, void* stream);
 /* out[b][e][:] = scale * x[b*seq + idx[b] + e][:] (fp16 rows -> fp32): gradient of the rows _inject_concept_embeddings wrote (clip.py:17-24) */

@@ -517,6 +517,19 @@ __global__ void act_bwd_kernel(const half_t* x, int ldx, const half_t* dy, int l
     *reinterpret_cast<half8_t*>(dx + (size_t)r * lddx + c) = o;
 }
 
+// y = act(x) as its own pass (training keeps the pre-activation; inference fuses the activation into the GEMM epilogue)
+__global__ void act_fwd_kernel(const half_t* x, int ldx, half_t* y, int ldy, int rows, int cols, int act) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const half8_t xv = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + c);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)pv_apply_act((float)xv[j], act);
+    *reinterpret_cast<half8_t*>(y + (size_t)r * ldy + c) = o;
+}
+
 __global__ void add_rows_kernel(const half_t* a, int lda, const half_t* b, int ldb, half_t* out, int ldo, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = cols / 8;
@@ -531,7 +544,7 @@ __global__ void add_rows_kernel(const half_t* a, int lda, const half_t* b, int l
 }
 
 // z[b][2i][2j][:] = x[b][i][j][:], zeros elsewhere (input of the data-gradient convolution of a stride-2 3x3 conv)
-__global__ void dilate2x_kernel(const half_t* x, half_t* z, int batch, int h, int w, int c) {
+__global__ void dilate2x_kernel(const half_t* x, int ldx, half_t* z, int batch, int h, int w, int c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = c / 8;
     const long total = (long)batch * 4 * h * w * nch;
@@ -540,12 +553,12 @@ __global__ void dilate2x_kernel(const half_t* x, half_t* z, int batch, int h, in
     const long px = idx / nch;
     const int j2 = (int)(px % (2 * w)), i2 = (int)((px / (2 * w)) % (2 * h)), b = (int)(px / ((long)4 * h * w));
     half8_t v = tz8();
-    if (!(i2 & 1) && !(j2 & 1)) v = *reinterpret_cast<const half8_t*>(x + (((size_t)b * h + i2 / 2) * w + j2 / 2) * c + ch * 8);
+    if (!(i2 & 1) && !(j2 & 1)) v = *reinterpret_cast<const half8_t*>(x + (((size_t)b * h + i2 / 2) * w + j2 / 2) * ldx + ch * 8);
     *reinterpret_cast<half8_t*>(z + (size_t)px * c + ch * 8) = v;
 }
 
 // out[b][i][j][:] = sum of the 2x2 block of g (+ add): gradient of the x2 nearest upsample
-__global__ void pool2x_kernel(const half_t* g, const half_t* add, half_t* out, int batch, int h, int w, int c) {
+__global__ void pool2x_kernel(const half_t* g, const half_t* add, int ldadd, half_t* out, int batch, int h, int w, int c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = c / 8;
     const long total = (long)batch * h * w * nch;
@@ -557,7 +570,7 @@ __global__ void pool2x_kernel(const half_t* g, const half_t* add, half_t* out, i
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
     if (add) {
-        const half8_t v = *reinterpret_cast<const half8_t*>(add + (size_t)px * c + ch * 8);
+        const half8_t v = *reinterpret_cast<const half8_t*>(add + (size_t)px * ldadd + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = (float)v[e];
     }
@@ -637,6 +650,14 @@ extern "C" int pv_act_backward(const void* x, int32_t ldx, const void* dy, int32
     return PV_CHECK_LAUNCH();
 }
 
+extern "C" int pv_act_forward(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t rows, int32_t cols, int32_t act, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || cols % 8 || (ldx | ldy) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (half_t*)y, ldy, rows, cols,
+                       act);
+    return PV_CHECK_LAUNCH();
+}
+
 extern "C" int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream) {
     if (!a || !b || !out || rows <= 0 || cols <= 0 || cols % 8 || (lda | ldb | ldo) % 8) return (int)hipErrorInvalidValue;
     const long total = (long)rows * (cols / 8);
@@ -645,17 +666,17 @@ extern "C" int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_
     return PV_CHECK_LAUNCH();
 }
 
-extern "C" int pv_dilate2x(const void* x, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
-    if (!x || !z || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) return (int)hipErrorInvalidValue;
+extern "C" int pv_dilate2x(const void* x, int32_t ldx, void* z, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!x || !z || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 || ldx % 8 || ldx < c) return (int)hipErrorInvalidValue;
     const long total = (long)batch * 4 * h * w * (c / 8);
-    hipLaunchKernelGGL(dilate2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)z, batch, h, w, c);
+    hipLaunchKernelGGL(dilate2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (half_t*)z, batch, h, w, c);
     return PV_CHECK_LAUNCH();
 }
 
-extern "C" int pv_pool2x_sum(const void* g, const void* add, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
-    if (!g || !out || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) return (int)hipErrorInvalidValue;
+extern "C" int pv_pool2x_sum(const void* g, const void* add, int32_t ldadd, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!g || !out || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 || (add && (ldadd % 8 || ldadd < c))) return (int)hipErrorInvalidValue;
     const long total = (long)batch * h * w * (c / 8);
-    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)g, (const half_t*)add, (half_t*)out,
+    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)g, (const half_t*)add, ldadd, (half_t*)out,
                        batch, h, w, c);
     return PV_CHECK_LAUNCH();
 }

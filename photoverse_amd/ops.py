@@ -259,6 +259,13 @@ class Recorder:
         self._add(self.lib.pv_act_backward, _ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, rows, cols, act)
         return dx
 
+    def act_forward(self, x, act):
+        rows, cols = x.shape
+        y = self.empty((rows, cols))
+        self.keep.append(x)
+        self._add(self.lib.pv_act_forward, _ptr(x), _rows(x)[0], _ptr(y), cols, rows, cols, act)
+        return y
+
     def add_rows(self, a, b, out=None):
         rows, cols = a.shape
         if out is None:
@@ -271,14 +278,14 @@ class Recorder:
         c = x.shape[1]
         z = self.empty((batch * 4 * h * w, c))
         self.keep.append(x)
-        self._add(self.lib.pv_dilate2x, _ptr(x), _ptr(z), batch, h, w, c)
+        self._add(self.lib.pv_dilate2x, _ptr(x), _rows(x)[0], _ptr(z), batch, h, w, c)
         return z
 
     def pool2x_sum(self, g, *, batch, h, w, add=None):
         c = g.shape[1]
         out = self.empty((batch * h * w, c))
         self.keep.extend(t for t in (g, add) if t is not None)
-        self._add(self.lib.pv_pool2x_sum, _ptr(g), _ptr(add), _ptr(out), batch, h, w, c)
+        self._add(self.lib.pv_pool2x_sum, _ptr(g), _ptr(add), _rows(add)[0] if add is not None else 0, _ptr(out), batch, h, w, c)
         return out
 
     def sign(self, x, coef):

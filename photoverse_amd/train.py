@@ -109,3 +109,360 @@ def training_step_forward(batch, tokenizer, image_encoder, text_encoder, unet, t
     return {"loss": loss, "diffusion_loss": diffusion_loss, "concept_text_loss": concept_text_loss,
             "cross_attn_visual_loss": cross_attn_visual_loss, "noise_pred": noise_pred, "noise": noise, "timesteps": timesteps,
             "latents": latents, "fusion_table": eng.fusion_tab.clone(), "fusion_names": list(eng.fusion_names)}
+
+
+# ======================================================================================================================
+# The full step: forward + backward as two static launch plans (tape.py), AdamW on the device (optim.py)
+# ======================================================================================================================
+from typing import Dict, List  # noqa: E402
+
+from . import ops as _ops  # noqa: E402
+from .lora import LoRALinear  # noqa: E402
+from .tape import Tape, Var, conv3_dgrad_weight  # noqa: E402
+from .unet import ResnetBlock2D, Transformer2DModel, _conv1_w, _conv3_w, _f16, _f32  # noqa: E402
+
+
+class TrainStep:
+    """One PhotoVerse training iteration (``/root/reference/train.py:466-545`` without the optional ArcFace term) for a fixed
+    shape, as a forward and a backward launch plan over the HIP kernels.
+
+    Trainable (train.py:366-377): both adapters, ``to_k_ip`` / ``to_v_ip`` of the 16 cross-attention processors and - with
+    ``--use_lora`` - the LoRA factors behind ``attn2.to_q / to_k / to_v``.  Everything else is frozen, but the gradient crosses it:
+    the whole UNet (dX of every conv / Linear / GroupNorm / LayerNorm / attention / GEGLU, skip connections, down / up sampling) and
+    the 12 CLIP text layers between the injected concept rows and the text K / V projections.
+
+    ``step(batch)`` fills the static inputs, replays the two plans and leaves ``.grad`` (times ``grad_scale``, fp32) on every
+    trainable parameter; ``optim.AdamW.step(clip_groups=..., grad_scale=...)`` finishes the iteration without a host sync.
+    The LoRA factor gradients dA = s B^T dW, dB = s dW A^T are rank-r products of the merged-weight gradient (library GEMM).
+    """
+
+    def __init__(self, unet, text_encoder, text_adapter, image_adapter, *, batch: int, h: int, w: int, n_tokens: int, seq: int = 77,
+                 clip_tokens: int = 257, clip_dim: int = 1024, grad_scale: float = 4096.0, fusion_seed: int = 0,
+                 loss_weights=(1.0, 0.01, 0.001)):
+        dev = unet.device
+        self.unet, self.text_encoder, self.text_adapter, self.image_adapter = unet, text_encoder, text_adapter, image_adapter
+        self.B, self.H, self.W, self.E, self.S_len = batch, h, w, n_tokens, seq
+        self.grad_scale = float(grad_scale)
+        self.loss_weights = tuple(float(x) for x in loss_weights)
+        tp = self.tape = Tape(dev, grad_scale)
+        rf = tp.rf
+        cfg = unet.config
+        self.pgrads: List[tuple] = []
+        # static inputs
+        self.noisy = rf.hold(torch.zeros((batch, cfg.in_channels, h, w), dtype=torch.float32, device=dev))
+        self.noise = rf.hold(torch.zeros_like(self.noisy))
+        self.timesteps = rf.hold(torch.zeros((batch,), dtype=torch.float32, device=dev))
+        self.ids = rf.hold(torch.zeros((batch, seq), dtype=torch.int64, device=dev))
+        self.pidx = rf.hold(torch.zeros((batch,), dtype=torch.int64, device=dev))
+        self.pidx32 = rf.hold(torch.zeros((batch,), dtype=torch.int32, device=dev))
+        self.embs = [rf.hold(torch.zeros((batch, clip_tokens, clip_dim), dtype=torch.float16, device=dev)) for _ in range(n_tokens)]
+        self._build(fusion_seed)
+
+    # ------------------------------------------------------------------ parameter-gradient sinks
+    def _to(self, param):
+        def sink(buf):
+            self.pgrads.append((param, buf))
+        return sink
+
+    def _affine_to(self, ln):
+        def sink(dgb):
+            self.pgrads.append((ln.weight, dgb[0]))
+            self.pgrads.append((ln.bias, dgb[1]))
+        return sink
+
+    # ------------------------------------------------------------------ adapters (adapters.py:30-44, full mode)
+    def _mlp(self, seq, x: Var, group: int) -> Var:
+        tp = self.tape
+
+        def lin(i, xin):
+            L = seq[i]
+            w16, wT = tp.trainable(lambda L=L: L.weight)
+            return tp.linear(xin, w16, wT, bias=L.bias.data, on_wgrad=self._to(L.weight), on_bgrad=self._to(L.bias))
+        h0 = lin(0, x)
+        a1 = tp.layernorm(h0, seq[1].weight.data, seq[1].bias.data, eps=seq[1].eps, act=_ops.ACT_LEAKY_RELU, on_affine=self._affine_to(seq[1]))
+        h3 = lin(3, a1)
+        a4 = tp.layernorm(h3, seq[4].weight.data, seq[4].bias.data, eps=seq[4].eps, act=_ops.ACT_LEAKY_RELU, on_affine=self._affine_to(seq[4]),
+                          mean_group=group)
+        return lin(6, a4)
+
+    def _adapter(self, adapter) -> Var:
+        tp, B = self.tape, self.B
+        cout = getattr(adapter, "mapping_0")[6].out_features
+        whole = tp.rf.empty((B, self.E * cout))
+        parts = []
+        for i, emb in enumerate(self.embs):
+            T, D = emb.shape[1], emb.shape[2]
+            cls = self._mlp(getattr(adapter, f"mapping_{i}"), Var(emb.view(B, T * D)[:, :D]), 1)
+            pat = self._mlp(getattr(adapter, f"mapping_patch_{i}"), Var(emb.view(B * T, D)), T)
+            parts.append(tp.add_into(cls, pat, whole[:, i * cout:(i + 1) * cout]))
+        return tp.columns(parts, whole)
+
+    # ------------------------------------------------------------------ text encoder (clip.py:29-102 with the injected concept rows)
+    def _text(self, concept: Var) -> Var:
+        tp, B, S, E = self.tape, self.B, self.S_len, self.E
+        te = self.text_encoder
+        cfg, tm = te.config, te.text_model
+        dim, heads = cfg.hidden_size, cfg.num_attention_heads
+        x0 = tp.rf.clip_text_embed(self.ids, _f32(tm.embeddings.token_embedding.weight), _f32(tm.embeddings.position_embedding.weight),
+                                   concept.t.view(B * E, dim), self.pidx, n_concept=E, batch=B, seq=S, dim=dim)
+        x = Var(x0, True)
+
+        def embed_bwd(x=x):
+            if x.g is None:
+                return
+            g32 = tp.rb.gather_rows(x.g, self.pidx32, batch=B, seq=S, n_e=E)
+            tp._accum(concept, tp.rb.cast_to_f16(g32.view(B, E * dim)))
+        tp.back.append(embed_bwd)
+        for lyr in tm.encoder.layers:
+            sa = lyr.self_attn
+            hcur = tp.layernorm(x, _f32(lyr.layer_norm1.weight), _f32(lyr.layer_norm1.bias), eps=lyr.layer_norm1.eps)
+            wqkv = torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0)
+            bqkv = torch.cat([_f32(sa.q_proj.bias), _f32(sa.k_proj.bias), _f32(sa.v_proj.bias)], 0).contiguous()
+            qkv = tp.linear(hcur, *tp.frozen(wqkv), bias=bqkv, rows_per_image=S)
+            a = tp.self_attention(qkv, batch=B, heads=heads, n=S, d=dim // heads, causal=True)
+            x = tp.linear(a, *tp.frozen(sa.out_proj.weight), bias=_f32(sa.out_proj.bias), residual=x, rows_per_image=S)
+            hcur = tp.layernorm(x, _f32(lyr.layer_norm2.weight), _f32(lyr.layer_norm2.bias), eps=lyr.layer_norm2.eps)
+            f = tp.linear(hcur, *tp.frozen(lyr.mlp.fc1.weight), bias=_f32(lyr.mlp.fc1.bias), rows_per_image=S)
+            f = tp.activation(f, _ops.ACT_QUICK_GELU)
+            x = tp.linear(f, *tp.frozen(lyr.mlp.fc2.weight), bias=_f32(lyr.mlp.fc2.bias), residual=x, rows_per_image=S)
+        return tp.layernorm(x, _f32(tm.final_layer_norm.weight), _f32(tm.final_layer_norm.bias), eps=tm.final_layer_norm.eps)
+
+    # ------------------------------------------------------------------ UNet blocks ([EXT] diffusers; launch plan as unet.UNetEngine)
+    def _resnet(self, m: ResnetBlock2D, x: Var, x1: Optional[Var], h, w, temb_all, toff) -> Var:
+        tp, B = self.tape, self.B
+        cout = m.conv1.out_channels
+        hn = tp.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=B, hw=h * w, x1=x1, eps=m.norm1.eps, act=_ops.ACT_SILU)
+        h1 = tp.conv3(hn, _conv3_w(m.conv1.weight), conv3_dgrad_weight(m.conv1.weight), bias=_f32(m.conv1.bias), batch=B, h=h, w=w,
+                      rowadd=temb_all[:, toff:toff + cout], rowadd_ld=temb_all.stride(0))
+        h2 = tp.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=B, hw=h * w, eps=m.norm2.eps, act=_ops.ACT_SILU)
+        if m.conv_shortcut is not None:
+            sc = tp.linear(x, *tp.frozen(_conv1_w(m.conv_shortcut.weight)), bias=_f32(m.conv_shortcut.bias), x1=x1, rows_per_image=h * w)
+        else:
+            assert x1 is None
+            sc = x
+        return tp.conv3(h2, _conv3_w(m.conv2.weight), conv3_dgrad_weight(m.conv2.weight), bias=_f32(m.conv2.bias), batch=B, h=h, w=w, residual=sc)
+
+    def _maybe_lora(self, lin_mod):
+        """(w16, wT16, sink) of an attn2 projection: trainable through its LoRA factors, else frozen."""
+        tp = self.tape
+        if isinstance(lin_mod, LoRALinear):
+            return tp.trainable(lambda m=lin_mod: m.weight), lin_mod
+        return tp.frozen(lin_mod.weight), None
+
+    def _lora_sink(self, mods_rows):
+        """mods_rows: [(LoRALinear or None, row0, row1)] - slices of a stacked merged-weight gradient."""
+        def sink(dW):
+            for mod, r0, r1 in mods_rows:
+                if mod is not None:
+                    self.lora_pending.append((mod, dW[r0:r1]))
+        return sink
+
+    def _transformer(self, name: str, m: Transformer2DModel, x: Var, h, w, text: Var, ip: Var) -> Var:
+        tp, B = self.tape, self.B
+        n = h * w
+        blk = m.transformer_blocks[0]
+        C = m.proj_in.out_channels
+        heads = blk.attn1.heads
+        d = C // heads
+        g = tp.groupnorm(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=B, hw=n, eps=m.norm.eps, act=_ops.ACT_NONE)
+        hs = tp.linear(g, *tp.frozen(_conv1_w(m.proj_in.weight)), bias=_f32(m.proj_in.bias), rows_per_image=n)
+        # attn1 ([EXT] AttnProcessor2_0, models/unet.py:20-24)
+        a1 = blk.attn1
+        n1 = tp.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
+        qkv = tp.linear(n1, *tp.frozen(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)), rows_per_image=n)
+        sa = tp.self_attention(qkv, batch=B, heads=heads, n=n, d=d)
+        hs = tp.linear(sa, *tp.frozen(a1.to_out[0].weight), bias=_f32(a1.to_out[0].bias), residual=hs, rows_per_image=n)
+        # attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435), grad mode: fusion drawn on the device
+        a2, proc = blk.attn2, blk.attn2.processor
+        n2 = tp.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
+        (wq, wqT), lq = self._maybe_lora(a2.to_q)
+        q = tp.linear(n2, wq, wqT, rows_per_image=n, on_wgrad=self._lora_sink([(lq, 0, C)]) if lq is not None else None)
+        lk = a2.to_k if isinstance(a2.to_k, LoRALinear) else None
+        lv = a2.to_v if isinstance(a2.to_v, LoRALinear) else None
+        kv_fn = lambda a2=a2: torch.cat([a2.to_k.weight, a2.to_v.weight], 0)
+        wkv, wkvT = tp.trainable(kv_fn) if (lk is not None or lv is not None) else tp.frozen(kv_fn())
+        kvt = tp.linear(text, wkv, wkvT, rows_per_image=self.S_len,
+                        on_wgrad=self._lora_sink([(lk, 0, C), (lv, C, 2 * C)]) if (lk is not None or lv is not None) else None)
+        kip, vip = proc.to_k_ip[0], proc.to_v_ip[0]
+        wkvip, wkvipT = tp.trainable(lambda kip=kip, vip=vip: torch.cat([kip.weight, vip.weight], 0))
+
+        def ip_sink(dW, kip=kip, vip=vip, C=C):
+            self.pgrads.append((kip.weight, dW[:C]))
+            self.pgrads.append((vip.weight, dW[C:]))
+        kvip = tp.linear(ip, wkvip, wkvipT, rows_per_image=self.E, on_wgrad=ip_sink)
+        vnorm = tp.rf.empty((B, heads, self.E), torch.float32)
+        self.vnorms[name] = vnorm
+        fus = self.fusion_tab[len(self.fusion_names)]
+        self.fusion_names.append(name)
+        xa = tp.cross_attention(q, kvt, kvip, batch=B, heads=heads, n=n, nt=self.S_len, nip=self.E, d=d, fusion=fus, vnorm=vnorm,
+                                vnorm_coef=self.loss_weights[2] * self.grad_scale / (self.n_xattn * B * heads * self.E))
+        hs = tp.linear(xa, *tp.frozen(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
+        # GEGLU feed-forward (pre-activation kept for the backward)
+        n3 = tp.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
+        hg = tp.linear(n3, *tp.frozen(blk.ff.net[0].proj.weight), bias=_f32(blk.ff.net[0].proj.bias), rows_per_image=n)
+        gg = tp.geglu(hg)
+        hs = tp.linear(gg, *tp.frozen(blk.ff.net[2].weight), bias=_f32(blk.ff.net[2].bias), residual=hs, rows_per_image=n)
+        return tp.linear(hs, *tp.frozen(_conv1_w(m.proj_out.weight)), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n, colstats=True)
+
+    # ------------------------------------------------------------------ the plan
+    def _build(self, fusion_seed: int):
+        import numpy as np
+        from .attention_processor import PhotoVerseAttnProcessor2_0
+        from .unet import Attention
+        tp, u, B = self.tape, self.unet, self.B
+        rf, rb = tp.rf, tp.rb
+        dev = tp.device
+        cfg = u.config
+        h, w = self.H, self.W
+        c0 = cfg.block_out_channels[0]
+        self.vnorms: Dict[str, torch.Tensor] = {}
+        self.fusion_names: List[str] = []
+        self.lora_pending: List[tuple] = []
+        procs = [m.processor for _, m in u.named_modules() if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0)]
+        self.n_xattn = len(procs)
+        # grad-mode branch fusion, one device-side draw per forward (attention_processor.py:413-420; pv_fusion_draw)
+        self.fusion_tab = rf.hold(torch.ones((self.n_xattn, 2), dtype=torch.float32, device=dev))
+        key = np.array([fusion_seed & 0xFFFFFFFF, (fusion_seed >> 32) & 0xFFFFFFFF, 0, 0], dtype=np.uint32).view(np.int32)
+        self.fusion_rng = rf.hold(torch.from_numpy(key.copy()).to(dev))
+        self.fusion_forced = rf.hold(torch.full((self.n_xattn,), -1.0, dtype=torch.float32, device=dev))
+        p0 = procs[0]
+        rf.fusion_draw(None, self.fusion_rng, self.fusion_forced, self.fusion_tab, n_layers=self.n_xattn, rule1=p0.fusion_rule1, rule2=p0.fusion_rule2,
+                       scale=float(p0.scale[0]), only_last_step=False)
+
+        # --- conditioning: adapters (trainable) and the text encoder (frozen, crossed by the gradient) - train.py:495-502
+        concept = self._adapter(self.text_adapter)                      # [B, E * 768]
+        self.concept = concept
+        # concept-text regulariser (train.py:509): forward value + its gradient seed, in tape order right after the adapter
+        self.terms = rf.hold(torch.zeros(3, dtype=torch.float32, device=dev))
+        rf.reduce_mean(concept.t, mode="abs", out=self.terms[1:2])
+
+        def concept_loss_bwd():
+            c32 = rb.cast_to_f32(concept.t)
+            g = rb.sign(c32, self.loss_weights[1] * self.grad_scale / concept.t.numel())
+            tp._accum(concept, rb.cast_to_f16(g))
+        tp.back.append(concept_loss_bwd)
+        text = self._text(concept)                                      # [B * S, 768]
+        ip = self._adapter(self.image_adapter)                          # [B, E * 768]  == rows [B * E, 768]
+        ip_rows = Var(ip.t.view(B * self.E, -1), True)
+
+        def ip_rows_bwd():
+            if ip_rows.g is not None:
+                g = ip_rows.g if ip_rows.g.is_contiguous() else rb.add_rows(ip_rows.g, torch.zeros_like(ip_rows.t))
+                tp._accum(ip, g.view(B, -1))
+        tp.back.append(ip_rows_bwd)
+        self.text_states, self.ip_states = text, ip_rows
+
+        # --- UNet forward (no gradient needed upstream of the first cross-attention layer)
+        te = rf.timestep_embedding(self.timesteps, None, B, c0)
+        e1 = rf.gemm(te, _f16(u.time_embedding.linear_1.weight), bias=_f32(u.time_embedding.linear_1.bias), act=_ops.ACT_SILU)
+        e2 = rf.gemm(e1, _f16(u.time_embedding.linear_2.weight), bias=_f32(u.time_embedding.linear_2.bias), act=_ops.ACT_SILU)
+        resnets = [m for m in u.modules() if isinstance(m, ResnetBlock2D)]
+        toffs, off = {}, 0
+        for m in resnets:
+            toffs[id(m)] = off
+            off += m.conv1.out_channels
+        pad = (-off) % 160
+        wt = torch.cat([_f16(m.time_emb_proj.weight) for m in resnets] +
+                       ([torch.zeros(pad, resnets[0].time_emb_proj.in_features, dtype=torch.float16, device=dev)] if pad else []), 0)
+        bt = torch.cat([_f32(m.time_emb_proj.bias) for m in resnets] + ([torch.zeros(pad, device=dev)] if pad else []), 0)
+        temb_all = rf.gemm(e2, wt.contiguous(), bias=bt.contiguous(), out_f32=True)
+        kin = cfg.in_channels * 9
+        kpad = (kin + 63) // 64 * 64
+        cols = rf.im2col3x3(self.noisy, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
+        w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=dev)
+        w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
+        x = Var(rf.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True), False)
+        skips = [(x, h, w)]
+        for bi, blk in enumerate(u.down_blocks):
+            for i, res in enumerate(blk.resnets):
+                x = self._resnet(res, x, None, h, w, temb_all, toffs[id(res)])
+                if blk.has_attn:
+                    x = self._transformer(f"down_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
+                skips.append((x, h, w))
+            if blk.downsamplers is not None:
+                conv = blk.downsamplers[0].conv
+                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, stride=2)
+                h, w = h // 2, w // 2
+                skips.append((x, h, w))
+        mb = u.mid_block
+        x = self._resnet(mb.resnets[0], x, None, h, w, temb_all, toffs[id(mb.resnets[0])])
+        x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, h, w, text, ip_rows)
+        x = self._resnet(mb.resnets[1], x, None, h, w, temb_all, toffs[id(mb.resnets[1])])
+        for bi, blk in enumerate(u.up_blocks):
+            for i, res in enumerate(blk.resnets):
+                sk, sh, sw = skips.pop()
+                assert (sh, sw) == (h, w)
+                x = self._resnet(res, x, sk, h, w, temb_all, toffs[id(res)])
+                if blk.has_attn:
+                    x = self._transformer(f"up_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
+            if blk.upsamplers is not None:
+                conv = blk.upsamplers[0].conv
+                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, upsample=1)
+                h, w = h * 2, w * 2
+        xn = tp.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w, eps=u.conv_norm_out.eps, act=_ops.ACT_SILU)
+        wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
+        self.noise_pred = rf.conv_out(xn.t, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels)
+
+        # --- losses (train.py:509-516, :536): values in the forward plan, gradient seeds at the head of the backward plan
+        rf.reduce_mean(self.noise_pred, self.noise, mode="mse", out=self.terms[0:1])
+        per_layer = rf.empty((len(self.vnorms),), torch.float32)
+        for i, name in enumerate(self.vnorms):
+            rf.reduce_mean(self.vnorms[name], mode="mean", out=per_layer[i:i + 1])
+        rf.reduce_mean(per_layer, mode="mean", out=self.terms[2:3])
+        lw = torch.tensor([3.0 * x_ for x_ in self.loss_weights], dtype=torch.float32, device=dev)
+        weighted = rf.affine_rows(self.terms.view(3, 1), rf.hold(lw))
+        self.loss = rf.reduce_mean(weighted.view(-1), mode="mean")
+
+        def seed():
+            npix = self.noise_pred.numel()
+            ca = rb.hold(torch.full((1,), 2.0 * self.loss_weights[0] * self.grad_scale / npix, dtype=torch.float32, device=dev))
+            cb = rb.hold(torch.full((1,), -2.0 * self.loss_weights[0] * self.grad_scale / npix, dtype=torch.float32, device=dev))
+            dpred = rb.affine_rows(self.noise_pred.view(1, -1), ca, self.noise.view(1, -1), cb).view(self.noise_pred.shape)
+            oc = cfg.out_channels
+            kp = (oc * 9 + 63) // 64 * 64
+            dcols = rb.im2col3x3(dpred, batch=B, cin=oc, h=h, wd=w, kpad=kp)
+            wd_out = torch.zeros(c0, kp, dtype=torch.float16, device=dev)
+            wd_out[:, :oc * 9] = u.conv_out.weight.detach().flip(2, 3).permute(1, 0, 2, 3).reshape(c0, oc * 9).to(torch.float16)
+            xn.g = rb.gemm(dcols, wd_out, rows_per_image=h * w)
+        tp.back.append(seed)
+        tp.build_backward()
+
+    # ------------------------------------------------------------------ one iteration
+    def trainable_parameters(self) -> Dict[str, List[torch.nn.Parameter]]:
+        """The three clip groups of train.py:538-541 (text_adapter, image_adapter, unet)."""
+        from .attention_processor import PhotoVerseAttnProcessor2_0
+        un = []
+        for proc in self.unet.attn_processors.values():
+            if isinstance(proc, PhotoVerseAttnProcessor2_0):
+                un += [proc.to_k_ip[0].weight, proc.to_v_ip[0].weight]
+        for m in self.unet.modules():
+            if isinstance(m, LoRALinear):
+                un += [m.lora_A["default"].weight, m.lora_B["default"].weight]
+        return {"text_adapter": list(self.text_adapter.parameters()), "image_adapter": list(self.image_adapter.parameters()), "unet": un}
+
+    @torch.no_grad()
+    def step(self, *, noisy_latents, noise, timesteps, text_input_ids, placeholder_idx, image_embeddings, forced_fusion=None):
+        """Fill the static inputs, replay forward + backward, set ``.grad`` (= gradient x ``grad_scale``).  Returns the loss terms."""
+        self.noisy.copy_(noisy_latents)
+        self.noise.copy_(noise)
+        self.timesteps.copy_(timesteps.to(self.noisy.device, torch.float32))
+        self.ids.copy_(text_input_ids.view(self.B, -1))
+        self.pidx.copy_(placeholder_idx.view(-1))
+        self.pidx32.copy_(placeholder_idx.view(-1))
+        for dst, src in zip(self.embs, image_embeddings):
+            dst.copy_(src)
+        if forced_fusion is not None:
+            self.fusion_forced.copy_(torch.as_tensor(forced_fusion, dtype=torch.float32))
+        else:
+            self.fusion_forced.fill_(-1.0)
+        self.tape.load_weights()
+        self.tape.rf.run()
+        self.tape.rb.run()
+        for param, buf in self.pgrads:
+            param.grad = buf.view(param.shape)
+        for mod, dW in self.lora_pending:                       # rank-r factor gradients from the merged-weight gradient
+            A, Bm = mod.lora_A["default"].weight, mod.lora_B["default"].weight
+            A.grad = mod.scaling * (Bm.detach().t() @ dW)
+            Bm.grad = mod.scaling * (dW @ A.detach().t())
+        return {"loss": self.loss, "diffusion_loss": self.terms[0:1], "concept_text_loss": self.terms[1:2],
+                "cross_attn_visual_loss": self.terms[2:3], "noise_pred": self.noise_pred, "fusion_table": self.fusion_tab}

@@ -343,3 +343,115 @@ def test_adamw_and_clip_match_torch(grad_scale):
             assert abs(float(n) - w) < 1e-4 * w
         for p, q in zip(ref, mine):
             assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
+
+
+def test_training_step_backward_matches_oracle_autograd(need_gpu):
+    """The whole backward of a training step (train.py:495-536 without the optional face loss) on the HIP plans: gradient of
+    mse + 0.01 |concept| + 0.001 ||V_ip|| w.r.t. every trainable parameter - both adapters (through the UNet's cross-attention layers;
+    the text adapter additionally through the CLIP text encoder), to_k_ip / to_v_ip of every processor and the LoRA factors behind
+    attn2.to_q / to_k / to_v - against torch autograd over the fp32 oracle composition with the same forced fusion draws.  Then one
+    AdamW step with the reference's per-module gradient clipping, against torch.optim.AdamW on the oracle."""
+    import torch.nn.functional as F
+    from oracle.adapters_ref import PhotoVerseAdapterRef
+    from oracle.clip_ref import CLIPTextModelRef
+    from oracle.unet_ref import TINY_CONFIG, UNet2DConditionModelRef, get_visual_cross_attention_values_norm_ref, set_visual_cross_attention_adapter_ref
+    from photoverse_amd.lora import LoraConfig, LoRALinear, inject_adapter_in_model
+    from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.optim import AdamW
+    from photoverse_amd.train import TrainStep
+    ENT, B, T, D = 2, 2, 17, 256
+    lcfg = LoraConfig(r=4, lora_alpha=8)
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, ENT, use_lora=True, lora_config=lcfg, unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT,
+        vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1), seed=31)
+    g = torch.Generator().manual_seed(32)
+    for m in unet.modules():
+        if isinstance(m, LoRALinear):
+            m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)     # B = 0 at init would zero dA
+    r_unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
+    set_visual_cross_attention_adapter_ref(r_unet, (ENT + 1,))
+    inject_adapter_in_model(lcfg, r_unet)
+    r_unet.load_state_dict(unet.state_dict())
+    r_txt = CLIPTextModelRef(**TXT).eval(); r_txt.load_state_dict(text_encoder.state_dict())
+    r_ia = PhotoVerseAdapterRef(D, 768, ENT + 1).eval(); r_ia.load_state_dict(image_adapter.state_dict())
+    r_ta = PhotoVerseAdapterRef(D, 768, ENT + 1).eval(); r_ta.load_state_dict(text_adapter.state_dict())
+    for m in (unet, text_encoder, image_adapter, text_adapter):
+        m.to("cuda")
+    for p in list(r_unet.parameters()) + list(r_txt.parameters()):
+        p.requires_grad_(False)
+    train_names = [n for n, _ in r_unet.named_parameters() if "to_k_ip" in n or "to_v_ip" in n or "lora_" in n]
+    r_params = dict(r_unet.named_parameters())
+    for n in train_names:
+        r_params[n].requires_grad_(True)
+
+    noisy = torch.randn(B, 4, 16, 16, generator=g)
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    timesteps = torch.tensor([731, 42])
+    ids = torch.randint(0, 1000, (B, 77), generator=g)
+    pidx = torch.tensor([[5], [3]])
+    embs = [(torch.randn(B, T, D, generator=g)).half() for _ in range(ENT + 1)]
+    forced = [0.1, 0.5, 0.9, 0.4]
+
+    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=16, w=16, n_tokens=ENT + 1, clip_tokens=T, clip_dim=D,
+                   grad_scale=1024.0, fusion_seed=3)
+    out = ts.step(noisy_latents=noisy.cuda(), noise=noise.cuda(), timesteps=timesteps, text_input_ids=ids.cuda(), placeholder_idx=pidx.cuda(),
+                  image_embeddings=[e.cuda() for e in embs], forced_fusion=forced)
+    torch.cuda.synchronize()
+
+    # ---- oracle: same composition under autograd ----
+    LoRALinear.forward = lambda self, x: F.linear(x, self.weight, self.bias)      # the oracle calls attn.to_q(x); CPU fp32 only
+    try:
+        e32 = [e.float() for e in embs]
+        concept = r_ta(e32)
+        ehs = r_txt({"text_input_ids": ids, "concept_text_embeddings": concept, "concept_placeholder_idx": pidx})[0]
+        ehs_img = r_ia(e32)
+        mods = dict(r_unet.named_modules())
+        for name, u in zip(ts.fusion_names, forced):
+            mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = u
+        with torch.enable_grad():
+            pred = r_unet(noisy, timesteps, encoder_hidden_states=(ehs, ehs_img)).sample
+            vn = get_visual_cross_attention_values_norm_ref(r_unet)
+            d_loss, c_loss, v_loss = F.mse_loss(pred, noise), concept.abs().mean(), vn.mean()
+            loss = d_loss + 0.01 * c_loss + 0.001 * v_loss
+            loss.backward()
+    finally:
+        del LoRALinear.forward
+    assert out["loss"].item() == pytest.approx(loss.item(), rel=5e-3)
+    assert out["diffusion_loss"].item() == pytest.approx(d_loss.item(), rel=5e-3)
+    assert rel_l2(out["noise_pred"], pred.detach()) < 1e-2
+
+    S = ts.grad_scale
+    h_params = dict(unet.named_parameters())
+
+    def group_err(pairs):
+        a = torch.cat([(hp.grad.float().cpu() / S).flatten() for hp, _ in pairs])
+        b = torch.cat([rp.grad.flatten() for _, rp in pairs])
+        return rel_l2(a, b)
+    ip_pairs = [(h_params[n], r_params[n]) for n in train_names if "_ip" in n]
+    la_pairs = [(h_params[n], r_params[n]) for n in train_names if "lora_A" in n]
+    lb_pairs = [(h_params[n], r_params[n]) for n in train_names if "lora_B" in n]
+    ia_pairs = list(zip(image_adapter.parameters(), r_ia.parameters()))
+    ta_pairs = list(zip(text_adapter.parameters(), r_ta.parameters()))
+    assert len(ip_pairs) == 8 and len(la_pairs) == 12 and len(lb_pairs) == 12
+    errs = {k: group_err(v) for k, v in dict(ip=ip_pairs, lora_A=la_pairs, lora_B=lb_pairs, image_adapter=ia_pairs, text_adapter=ta_pairs).items()}
+    print("training-step gradient rel-L2 per group:", errs)
+    # fp16 activations + fp16 gradient operands across ~60 layers; the adapters add LeakyReLU / LayerNorm kinks (see the adapter test)
+    assert errs["ip"] < 3e-2 and errs["lora_A"] < 3e-2 and errs["lora_B"] < 3e-2, errs
+    assert errs["image_adapter"] < 6e-2 and errs["text_adapter"] < 6e-2, errs
+
+    # ---- optimizer: clip per module (train.py:538-541), AdamW (:372-377, :545) ----
+    groups = ts.trainable_parameters()
+    opt = AdamW([p for grp in groups.values() for p in grp], lr=1e-4, weight_decay=1e-2)
+    before = {n: h_params[n].detach().clone() for n in train_names}
+    norms = opt.step(clip_groups=list(groups.values()), max_norm=1.0, grad_scale=S)
+    r_all = [r_params[n] for n in train_names]
+    want_norms = [float(torch.nn.utils.clip_grad_norm_(list(r_ta.parameters()), 1.0)), float(torch.nn.utils.clip_grad_norm_(list(r_ia.parameters()), 1.0)),
+                  float(torch.nn.utils.clip_grad_norm_(r_all, 1.0))]
+    r_opt = torch.optim.AdamW(list(r_ta.parameters()) + list(r_ia.parameters()) + r_all, lr=1e-4, weight_decay=1e-2)
+    r_opt.step()
+    for got, want in zip(norms, want_norms):
+        assert float(got) == pytest.approx(want, rel=5e-2)
+    # first AdamW step moves every weight by ~lr * sign(g): compare the updates
+    upd_h = torch.cat([(h_params[n].detach().cpu() - before[n].cpu()).flatten() for n in train_names])
+    upd_r = torch.cat([(r_params[n].detach() - before[n].cpu()).flatten() for n in train_names])
+    assert rel_l2(upd_h, upd_r) < 0.15          # sign flips of near-zero gradient entries dominate: each flips a full +-lr step
