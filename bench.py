@@ -95,6 +95,73 @@ def spawn_ranks(n, argv, dry=False):
     return 0
 
 
+def train_step_leg(unet, B, S, dev, reps=3):
+    """Time one full training iteration at configs[3]'s shape: bs=16, 64x64 latents, 5 image tokens, LoRA (r=8) on attn2.to_q/k/v,
+    SD-v1.5-sized UNet, 12-layer CLIP text encoder, both adapters; forward + backward + clip + AdamW."""
+    import time
+    import torch
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    from photoverse_amd.clip import CLIPTextModel
+    from photoverse_amd.lora import LoraConfig, inject_adapter_in_model
+    from photoverse_amd.optim import AdamW
+    from photoverse_amd.train import TrainStep
+    torch.manual_seed(7)
+    inject_adapter_in_model(LoraConfig(r=8, lora_alpha=1), unet)
+    unet.to(dev)
+    for m in unet.modules():
+        if hasattr(m, "lora_B"):
+            m.lora_B["default"].weight.data.normal_(0, 0.02)
+    text_encoder = CLIPTextModel().to(dev)
+    text_adapter = PhotoVerseAdapter(1024, 768, 5).to(dev)
+    image_adapter = PhotoVerseAdapter(1024, 768, 5).to(dev)
+    t0 = time.perf_counter()
+    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=S, w=S, n_tokens=5, grad_scale=4096.0, fusion_seed=1)
+    build_s = time.perf_counter() - t0
+    groups = ts.trainable_parameters()
+    opt = AdamW([p for g_ in groups.values() for p in g_], lr=1e-5, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(99)
+    inputs = dict(noisy_latents=torch.randn(B, 4, S, S, generator=g).to(dev), noise=torch.randn(B, 4, S, S, generator=g).to(dev),
+                  timesteps=torch.randint(0, 1000, (B,), generator=g), text_input_ids=torch.randint(0, 49000, (B, 77), generator=g).to(dev),
+                  placeholder_idx=torch.full((B, 1), 5).to(dev),
+                  image_embeddings=[torch.randn(B, 257, 1024, generator=g).half().to(dev) for _ in range(5)])
+
+    def one():
+        out = ts.step(**inputs)
+        opt.step(clip_groups=list(groups.values()), max_norm=1.0, grad_scale=ts.grad_scale)
+        return out
+    out = one()                                              # warm-up (first-launch attribute setup, allocator)
+    torch.cuda.synchronize()
+    l0 = float(out["loss"])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t0 = time.perf_counter()
+    fb_ms = 0.0
+    for _ in range(reps):
+        ts.tape.load_weights()
+        ev[0].record()
+        ts.tape.rf.run()
+        ev[1].record()
+        ts.tape.rb.run()
+        ev[2].record()
+        out = one()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3 / 2     # each rep ran the plans twice (timed halves + the full iteration)
+    fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    # one more clean full iteration for the end-to-end figure
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = one()
+    torch.cuda.synchronize()
+    iter_ms = (time.perf_counter() - t1) * 1e3
+    n_train = sum(p.numel() for g_ in groups.values() for p in g_)
+    return {"workload": "configs[3] without the optional ArcFace term: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 on attn2.to_q/k/v; "
+                        "adapters + 12-layer CLIP text encoder + SD-v1.5 UNet forward, backward through all of them, per-module clip_grad_norm_, AdamW",
+            "ms_per_iteration": round(iter_ms, 2), "forward_plan_ms": round(fwd_ms, 2), "backward_plan_ms": round(bwd_ms, 2),
+            "launches_forward": len(ts.tape.rf), "launches_backward": len(ts.tape.rb), "trainable_parameters": n_train,
+            "activation_bytes": ts.tape.rf.bytes_allocated + ts.tape.rb.bytes_allocated, "plan_build_s": round(build_s, 2),
+            "loss_first": round(l0, 5), "loss_last": round(float(out["loss"]), 5), "finite": bool(torch.isfinite(out["loss"]).all().item()),
+            "hip_graph": False, "samples_per_s": round(B / (iter_ms * 1e-3), 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +339,7 @@ def main():
 
     # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
     # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.
-    # The backward is not built; this is NOT part of `value`.
+    # Inference-style engine (fused GEGLU / fused attn2, no activations kept); the whole iteration is `train_step` below.  NOT part of `value`.
     train_fwd = None
     launches_per_step = loop.launches_per_step
     if rank == 0 and world == 1 and not args.no_train_forward and S == 64:
@@ -305,7 +372,16 @@ def main():
                                  "per-sample timesteps, grad-mode branch fusion drawn on the device (no host sync), K/V projections included",
                      "ms_per_forward": round(ms, 3), "tflop_per_forward": round(tfl, 3), "achieved_tflops": round(tfl / (ms * 1e-3), 1),
                      "mfma_frac": round(tfl / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(eng.out).all().item()),
-                     "launches": len(eng.rec) + len(eng.rec_cond), "backward": "not built"}
+                     "launches": len(eng.rec) + len(eng.rec_cond), "backward": "see train_step"}
+
+    # third, separately labelled config (BASELINE configs[3] without the optional ArcFace term): a WHOLE training iteration -
+    # adapters + text encoder + UNet forward, the backward through all of them, per-module gradient clipping and AdamW - as two
+    # replayed launch plans (photoverse_amd/train.py TrainStep).  NOT part of `value`.
+    train_step = None
+    if rank == 0 and world == 1 and not args.no_train_forward and S == 64:
+        eng = gr = None
+        torch.cuda.empty_cache()
+        train_step = train_step_leg(unet, B, S, dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (contract); N > 1 runs stay short
@@ -326,7 +402,7 @@ def main():
                        "launches_per_step": launches_per_step},
             "finite": finite,
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "xattn_fused": xfused, "train_forward": train_fwd, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:
