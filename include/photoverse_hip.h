@@ -254,7 +254,7 @@ int pv_xattn_fused_wo_slot(int32_t slot);
  *   dq   fp16 [B*nq][C]         dkt, dvt  fp32 [B*nt][C]        dkip, dvip  fp32 [B*nip][C]
  * every output is multiplied by out_scale (un-scaling of a loss-scaled dout); dvip additionally gets
  * (vnorm_coef + vnorm_grad[b][h][p]) * v / ||v||_head (gradient through to_v_ip_norm, :397 / train.py:512-513)
- * before that scaling.  partial: fp32 workspace batch*heads*ceil(nq/64)*2*96*d.  Deterministic.
+ * before that scaling.  partial: fp32 workspace batch*heads*ceil(nq/512)*2*96*d.  MFMA (pv_train.hip).  Deterministic.
  */
 typedef struct pv_xattn_bwd_params {
     const void* q; int32_t ldq;
@@ -263,6 +263,7 @@ typedef struct pv_xattn_bwd_params {
     const void* dout; int32_t lddo;
     void* dq; int32_t lddq;
     float* partial;
+    float* stats;                      /* fp32 workspace [B][heads][nq][4]: per-query (lse_text, lse_ip, delta_text, delta_ip) */
     float* dkt; float* dvt; float* dkip; float* dvip;
     int32_t ld_dt, ld_di;              /* row strides (floats) of dkt / dvt and of dkip / dvip (e.g. 2C for a [dK | dV] buffer) */
     int32_t batch, heads, nq, nt, nip, d;

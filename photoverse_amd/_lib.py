@@ -73,7 +73,7 @@ class XAttnFusedParams(C.Structure):
 class XAttnBwdParams(C.Structure):
     _fields_ = [("q", c_void_p), ("ldq", c_int), ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int),
                 ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int), ("dout", c_void_p), ("lddo", c_int),
-                ("dq", c_void_p), ("lddq", c_int), ("partial", c_void_p), ("dkt", c_void_p), ("dvt", c_void_p), ("dkip", c_void_p),
+                ("dq", c_void_p), ("lddq", c_int), ("partial", c_void_p), ("stats", c_void_p), ("dkt", c_void_p), ("dvt", c_void_p), ("dkip", c_void_p),
                 ("dvip", c_void_p), ("ld_dt", c_int), ("ld_di", c_int), ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nt", c_int), ("nip", c_int), ("d", c_int),
                 ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p), ("out_scale", c_float), ("vnorm_coef", c_float), ("vnorm_grad", c_void_p)]
 

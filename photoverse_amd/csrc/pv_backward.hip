@@ -1,9 +1,6 @@
 // Backward of PhotoVerse's OWN trainable modules (the part of the training step that is the reference's code, not diffusers'):
 //
-//   pv_cross_attention_backward   gradient of the dual-branch SDPA of PhotoVerseAttnProcessor2_0
-//                                 (/root/reference/models/attention_processor.py:317-322 text branch, :392-420 image-token branch
-//                                 and fusion rule) with respect to q, the text K / V and the image-token K / V, plus the gradient of
-//                                 the to_v_ip_norm regulariser (:397, train.py:512-513) into V_ip
+//   (pv_cross_attention_backward - the dual-branch SDPA backward - lives in pv_train.hip with the other MFMA attention backward kernels)
 //   pv_transpose_f16              row-major fp16 transpose with zero padding (operand layout of the weight-gradient GEMMs
 //                                 dW = dY^T . X run on pv_gemm_conv)
 //   pv_layernorm_backward         LayerNorm (+ LeakyReLU) backward of the adapter MLPs (adapters.py:15-19)
@@ -14,177 +11,6 @@
 #include "pv_common.h"
 
 namespace {
-
-constexpr int BK_KEYS = 96;    // key rows of the K / V image: text [0, nt), image tokens [BK_IP0, BK_IP0 + nip)
-constexpr int BK_IP0 = 80;
-constexpr int BQ = 64;         // query rows per workgroup
-
-// One workgroup = 64 query rows of one (sample, head).  Thread t: row t / 4, key quarter t % 4 (24 keys).
-//   S = scale q K^T; P_b = softmax_b(S) per branch b in {text, ip}; O = sum_b w_b P_b V_b
-//   dP = dO V^T; dS_b = w_b P_b (dP - rowsum_b(P_b dP)); dQ = scale dS K; dK = scale dS^T Q; dV_b = w_b P_b^T dO
-template <int D>
-__global__ __launch_bounds__(256) void xattn_bwd_kernel(const pv_xattn_bwd_params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sQ = reinterpret_cast<half_t*>(smem);          // [BQ][D]
-    half_t* sDO = sQ + BQ * D;                              // [BQ][D]
-    half_t* sK = sDO + BQ * D;                              // [96][D]
-    half_t* sV = sK + BK_KEYS * D;                          // [96][D]
-    float* sDS = reinterpret_cast<float*>(sV + BK_KEYS * D);   // [BQ][96]  scale * dS
-    float* sPW = sDS + BQ * BK_KEYS;                        // [BQ][96]  w_b * P_b
-
-    const int tid = threadIdx.x;
-    const int ntile = (p.nq + BQ - 1) / BQ;
-    const int tile = blockIdx.x % ntile, h = (blockIdx.x / ntile) % p.heads, b = blockIdx.x / (ntile * p.heads);
-    const float w_text = p.fusion ? p.fusion[0] : p.w_text, w_ip = p.fusion ? p.fusion[1] : p.w_ip;
-    const float scale = rsqrtf((float)D);
-    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
-    const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
-
-    for (int i = tid; i < BQ * D; i += 256) {
-        const int r = i / D, c = i - r * D, m = tile * BQ + r;
-        sQ[i] = m < p.nq ? Q[(size_t)m * p.ldq + c] : (half_t)0.f;
-        sDO[i] = m < p.nq ? DO[(size_t)m * p.lddo + c] : (half_t)0.f;
-    }
-    for (int i = tid; i < BK_KEYS * D; i += 256) {
-        const int j = i / D, c = i - j * D;
-        half_t k = (half_t)0.f, v = (half_t)0.f;
-        if (j < p.nt) {
-            k = reinterpret_cast<const half_t*>(p.kt)[((size_t)b * p.nt + j) * p.ldkt + h * D + c];
-            v = reinterpret_cast<const half_t*>(p.vt)[((size_t)b * p.nt + j) * p.ldvt + h * D + c];
-        } else if (j >= BK_IP0 && j < BK_IP0 + p.nip) {
-            k = reinterpret_cast<const half_t*>(p.kip)[((size_t)b * p.nip + j - BK_IP0) * p.ldkip + h * D + c];
-            v = reinterpret_cast<const half_t*>(p.vip)[((size_t)b * p.nip + j - BK_IP0) * p.ldvip + h * D + c];
-        }
-        sK[i] = k;
-        sV[i] = v;
-    }
-    __syncthreads();
-
-    const int r = tid >> 2, part = tid & 3;
-    float s[24], dp[24];
-    float mt = -INFINITY, mi = -INFINITY;
-#pragma unroll
-    for (int jj = 0; jj < 24; ++jj) {
-        const int j = part * 24 + jj;
-        float a = 0.f, d2 = 0.f;
-        for (int c = 0; c < D; ++c) {
-            a += (float)sQ[r * D + c] * (float)sK[j * D + c];
-            d2 += (float)sDO[r * D + c] * (float)sV[j * D + c];
-        }
-        s[jj] = a * scale;
-        dp[jj] = d2;
-        if (j < p.nt) mt = fmaxf(mt, s[jj]);
-        if (j >= BK_IP0 && j < BK_IP0 + p.nip) mi = fmaxf(mi, s[jj]);
-    }
-    // the four threads of a row are adjacent lanes: xor-shuffles 1, 2
-    mt = fmaxf(mt, __shfl_xor(mt, 1, 64)); mt = fmaxf(mt, __shfl_xor(mt, 2, 64));
-    mi = fmaxf(mi, __shfl_xor(mi, 1, 64)); mi = fmaxf(mi, __shfl_xor(mi, 2, 64));
-    float lt = 0.f, li = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < 24; ++jj) {
-        const int j = part * 24 + jj;
-        float e = 0.f;
-        if (j < p.nt) { e = __expf(s[jj] - mt); lt += e; }
-        else if (j >= BK_IP0 && j < BK_IP0 + p.nip) { e = __expf(s[jj] - mi); li += e; }
-        s[jj] = e;
-    }
-    lt += __shfl_xor(lt, 1, 64); lt += __shfl_xor(lt, 2, 64);
-    li += __shfl_xor(li, 1, 64); li += __shfl_xor(li, 2, 64);
-    float dt = 0.f, di = 0.f;          // rowsum_b(P_b dP)
-#pragma unroll
-    for (int jj = 0; jj < 24; ++jj) {
-        const int j = part * 24 + jj;
-        const bool is_t = j < p.nt;
-        s[jj] = s[jj] / (is_t ? lt : li);                     // P (0 on padding keys: e was 0)
-        if (is_t) dt += s[jj] * dp[jj]; else di += s[jj] * dp[jj];
-    }
-    dt += __shfl_xor(dt, 1, 64); dt += __shfl_xor(dt, 2, 64);
-    di += __shfl_xor(di, 1, 64); di += __shfl_xor(di, 2, 64);
-#pragma unroll
-    for (int jj = 0; jj < 24; ++jj) {
-        const int j = part * 24 + jj;
-        const bool is_t = j < p.nt;
-        const float w = is_t ? w_text : w_ip;
-        sPW[r * BK_KEYS + j] = w * s[jj];
-        sDS[r * BK_KEYS + j] = scale * w * s[jj] * (dp[jj] - (is_t ? dt : di));
-    }
-    __syncthreads();
-
-    // dQ[r][c] for this thread's quarter of the head dimension
-    {
-        const int m = tile * BQ + r;
-        half_t* dQ = reinterpret_cast<half_t*>(p.dq) + (size_t)b * p.nq * p.lddq + h * D;
-        for (int c = part * (D / 4); c < (part + 1) * (D / 4); ++c) {
-            float a = 0.f;
-            for (int j = 0; j < BK_KEYS; ++j) a += sDS[r * BK_KEYS + j] * (float)sK[j * D + c];
-            if (m < p.nq) dQ[(size_t)m * p.lddq + c] = (half_t)(a * p.out_scale);
-        }
-    }
-    // this tile's contribution to dK / dV: partial[b][h][tile][2][96][D]
-    float* part_out = p.partial + ((((size_t)b * p.heads + h) * ntile + tile) * 2) * BK_KEYS * D;
-    for (int i = tid; i < BK_KEYS * D; i += 256) {
-        const int j = i / D, c = i - j * D;
-        float dk = 0.f, dv = 0.f;
-        for (int rr = 0; rr < BQ; ++rr) {
-            dk += sDS[rr * BK_KEYS + j] * (float)sQ[rr * D + c];
-            dv += sPW[rr * BK_KEYS + j] * (float)sDO[rr * D + c];
-        }
-        part_out[i] = dk;
-        part_out[BK_KEYS * D + i] = dv;
-    }
-}
-
-// sum the per-tile partials in tile order (deterministic) and scatter to the four gradient tensors (fp32 rows [B*nt | B*nip][C]);
-// adds the to_v_ip_norm regulariser gradient vnorm_coef * v / ||v|| to dV_ip
-template <int D>
-__global__ void xattn_bwd_reduce_kernel(const pv_xattn_bwd_params p, const int ntile) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.batch * p.heads * BK_KEYS * D;
-    if (idx >= total) return;
-    const int c = (int)(idx % D), j = (int)((idx / D) % BK_KEYS), h = (int)((idx / ((long)D * BK_KEYS)) % p.heads), b = (int)(idx / ((long)D * BK_KEYS * p.heads));
-    const bool is_t = j < p.nt, is_i = j >= BK_IP0 && j < BK_IP0 + p.nip;
-    if (!is_t && !is_i) return;
-    const float* src = p.partial + (((size_t)b * p.heads + h) * ntile * 2) * BK_KEYS * D + (size_t)j * D + c;
-    float dk = 0.f, dv = 0.f;
-    for (int t = 0; t < ntile; ++t) {
-        dk += src[(size_t)t * 2 * BK_KEYS * D];
-        dv += src[(size_t)t * 2 * BK_KEYS * D + BK_KEYS * D];
-    }
-    if (is_t) {
-        p.dkt[((size_t)b * p.nt + j) * p.ld_dt + h * D + c] = dk * p.out_scale;
-        p.dvt[((size_t)b * p.nt + j) * p.ld_dt + h * D + c] = dv * p.out_scale;
-    } else {
-        const int pi = j - BK_IP0;
-        if (p.vnorm_coef != 0.f || p.vnorm_grad) {
-            const half_t* v = reinterpret_cast<const half_t*>(p.vip) + ((size_t)b * p.nip + pi) * p.ldvip + h * D;
-            float n2 = 0.f;
-            for (int cc = 0; cc < D; ++cc) n2 += (float)v[cc] * (float)v[cc];
-            const float gnorm = p.vnorm_coef + (p.vnorm_grad ? p.vnorm_grad[((size_t)b * p.heads + h) * p.nip + pi] : 0.f);
-            dv += gnorm * (float)v[c] * rsqrtf(fmaxf(n2, 1e-30f));
-        }
-        p.dkip[((size_t)b * p.nip + pi) * p.ld_di + h * D + c] = dk * p.out_scale;
-        p.dvip[((size_t)b * p.nip + pi) * p.ld_di + h * D + c] = dv * p.out_scale;
-    }
-}
-
-template <int D>
-int launch_xattn_bwd(const pv_xattn_bwd_params& p, hipStream_t s) {
-    constexpr int smem = (2 * BQ + 2 * BK_KEYS) * D * 2 + 2 * BQ * BK_KEYS * 4;
-    static bool attr_set_dev[64] = {};
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    bool& attr_set = attr_set_dev[dev_id & 63];
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int ntile = (p.nq + BQ - 1) / BQ;
-    hipLaunchKernelGGL(xattn_bwd_kernel<D>, dim3((unsigned)(ntile * p.heads * p.batch)), dim3(256), smem, s, p);
-    const long total = (long)p.batch * p.heads * BK_KEYS * D;
-    hipLaunchKernelGGL(xattn_bwd_reduce_kernel<D>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, ntile);
-    return PV_CHECK_LAUNCH();
-}
 
 // out[c][r] = x[r][c] for r < rows, 0 for rows <= r < rows_pad
 __global__ void transpose_f16_kernel(const half_t* x, int ldx, int rows, int cols, half_t* out, int ldo, int rows_pad) {
@@ -318,19 +144,6 @@ extern "C" int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float
     if (!sumsq || !out || n <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, n, max_norm, base, out);
     return PV_CHECK_LAUNCH();
-}
-
-extern "C" int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream) {
-    if (!p->q || !p->kt || !p->vt || !p->kip || !p->vip || !p->dout || !p->dq || !p->partial || !p->dkt || !p->dvt || !p->dkip || !p->dvip ||
-        p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nt <= 0 || p->nt > BK_IP0 || p->nip <= 0 || p->nip > BK_KEYS - BK_IP0 || p->out_scale == 0.f || p->ld_dt < p->heads * p->d || p->ld_di < p->heads * p->d)
-        return (int)hipErrorInvalidValue;
-    hipStream_t s = (hipStream_t)stream;
-    switch (p->d) {
-        case 40: return launch_xattn_bwd<40>(*p, s);
-        case 80: return launch_xattn_bwd<80>(*p, s);
-        case 160: return launch_xattn_bwd<160>(*p, s);
-        default: return (int)hipErrorInvalidValue;
-    }
 }
 
 extern "C" int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, void* out, int32_t ldo, int32_t rows_pad, void* stream) {

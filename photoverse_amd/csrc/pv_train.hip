@@ -24,43 +24,57 @@ struct BCfg {
     static constexpr int KSTEPS = DK / 32;
     static constexpr int DT = (D + 15) / 16;        // 16-row fragments of the d-major outputs
     static constexpr int RS = DK + 8;               // row stride (halfs) of the row-major tiles
-    static constexpr int TS = 64 + 8;               // row stride of the transposed tiles [d][64]
     static constexpr int CH = D / 8;                // 16-byte chunks per row
     static constexpr int TILE = 64 * RS;            // halfs of one row-major tile
-    static constexpr int TTILE = DT * 16 * TS;      // halfs of one transposed tile
 };
 
-// stage 64 rows of a [rows][ld] fp16 matrix (columns [0, D) of head h already applied to the base pointer) into LDS as a row-major
-// tile (zero beyond D / beyond the last row) and, when sT != nullptr, as its transpose [d][row]
-template <int D>
-__device__ __forceinline__ void stage_tile(const half_t* g, int ld, int row0, int nrows, half_t* sR, half_t* sT, float mul) {
-    using C = BCfg<D>;
-    constexpr int CHP = C::DK / 8;
-    for (int i = threadIdx.x; i < 64 * CHP; i += 256) {
-        const int r = i / CHP, c = i - r * CHP;
-        half8_t v = tz8();
-        if (c < C::CH && row0 + r < nrows) v = *reinterpret_cast<const half8_t*>(g + (size_t)(row0 + r) * ld + c * 8);
-        if (mul != 1.0f) {
+// 64 rows of a [rows][ld] fp16 matrix (columns [0, D) of one head) -> registers (gload), registers -> a row-major LDS tile with zero
+// padding beyond D / beyond the last row (swrite).  Split so the next tile's global loads are in flight while the current tile computes.
+template <int D, int NT = 256>
+struct TileRegs {
+    static constexpr int CHP = BCfg<D>::DK / 8;
+    static constexpr int NI = (64 * CHP + NT - 1) / NT;
+    half8_t v[NI];
+    __device__ __forceinline__ void gload(const half_t* g, int ld, int row0, int nrows) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * mul);
-        }
-        *reinterpret_cast<half8_t*>(sR + r * C::RS + c * 8) = v;
-        if (sT != nullptr && c * 8 < C::DT * 16) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (c * 8 + j < C::DT * 16) sT[(c * 8 + j) * C::TS + r] = v[j];
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int r = idx / CHP, c = idx - r * CHP;
+            v[i] = (idx < 64 * CHP && c < BCfg<D>::CH && row0 + r < nrows) ? *reinterpret_cast<const half8_t*>(g + (size_t)(row0 + r) * ld + c * 8) : tz8();
         }
     }
-}
+    __device__ __forceinline__ void swrite(half_t* sR, float mul) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int r = idx / CHP, c = idx - r * CHP;
+            if (idx < 64 * CHP) {
+                half8_t x = v[i];
+                if (mul != 1.0f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = (half_t)((float)x[j] * mul);
+                }
+                *reinterpret_cast<half8_t*>(sR + r * BCfg<D>::RS + c * 8) = x;
+            }
+        }
+    }
+};
 
-// MFMA-A fragment from a transposed tile: rows d = f*16 + fr, the 8 contraction slots {s2*32 + fq*4 + 0..3, s2*32 + 16 + fq*4 + 0..3}
+// MFMA-A fragment of the TRANSPOSE of a row-major tile, read with the gfx950 transposing LDS load (ds_read_b64_tr_b16, as the
+// forward kernel's V^T operand): rows d = f*16 + fr, the 8 contraction slots {s2*32 + fq*4 + 0..3, s2*32 + 16 + fq*4 + 0..3}
 template <int D>
-__device__ __forceinline__ half8_t tfrag(const half_t* sT, int f, int s2, int fr, int fq) {
+__device__ __forceinline__ half8_t tfrag(const half_t* sR, int f, int s2, int fr, int fq) {
     using C = BCfg<D>;
-    const half_t* a = sT + (f * 16 + fr) * C::TS + s2 * 32 + fq * 4;
-    const half4_t lo = *reinterpret_cast<const half4_t*>(a);
-    const half4_t hi = *reinterpret_cast<const half4_t*>(a + 16);
-    return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const half_t* a = sR + (s2 * 32 + fq * 4 + (fr >> 2)) * C::RS + f * 16 + (fr & 3) * 4;
+    const fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
+    const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * C::RS));
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (half_t)t1[j];
+        r[j + 4] = (half_t)t2[j];
+    }
+    return r;
 }
 
 // delta[b][h][q] = sum_c dO[q][c] * O[q][c]
@@ -89,7 +103,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sK = reinterpret_cast<half_t*>(smem);
     half_t* sV = sK + C::TILE;
-    half_t* sKT = sV + C::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
     const int nqt = (p.nq + 63) / 64;
@@ -122,11 +135,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
 
     int ntiles = (p.nk + 63) / 64;
     if (p.causal) ntiles = min(ntiles, min(qt * 64 + 63, p.nq - 1) / 64 + 1);
+    TileRegs<D> rk, rv;
+    rk.gload(Kg, p.ldk, 0, p.nk);
+    rv.gload(Vg, p.ldv, 0, p.nk);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        stage_tile<D>(Kg, p.ldk, t * 64, p.nk, sK, sKT, 1.0f);
-        stage_tile<D>(Vg, p.ldv, t * 64, p.nk, sV, nullptr, 1.0f);
+        rk.swrite(sK, 1.0f);
+        rv.swrite(sV, 1.0f);
         __syncthreads();
+        if (t + 1 < ntiles) {
+            rk.gload(Kg, p.ldk, (t + 1) * 64, p.nk);
+            rv.gload(Vg, p.ldv, (t + 1) * 64, p.nk);
+        }
         const bool masked = p.causal || (t + 1) * 64 > p.nk;
         float4_t ds[4];
 #pragma unroll
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
                 bsl[r + 4] = (half_t)ds[2 * s2 + 1][r];
             }
 #pragma unroll
-            for (int f = 0; f < C::DT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sKT, f, s2, fr, fq), bsl, acc[f], 0, 0, 0);
+            for (int f = 0; f < C::DT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sK, f, s2, fr, fq), bsl, acc[f], 0, 0, 0);
         }
     }
     if (qok) {
@@ -185,9 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sQ = reinterpret_cast<half_t*>(smem);
     half_t* sDO = sQ + C::TILE;
-    half_t* sQT = sDO + C::TILE;
-    half_t* sDOT = sQT + C::TTILE;
-    float* sL = reinterpret_cast<float*>(sDOT + C::TTILE);     // -lse of the 64 staged queries (-inf beyond nq)
+    float* sL = reinterpret_cast<float*>(sDO + C::TILE);       // -lse of the 64 staged queries (-inf beyond nq)
     float* sDl = sL + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
@@ -216,16 +234,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
 
     const int nqt = (p.nq + 63) / 64;
     const int t0 = p.causal ? (kt * 64) / 64 : 0;          // causal: queries before this key tile never see it
-    for (int t = t0; t < nqt; ++t) {
-        __syncthreads();
-        stage_tile<D>(Q, p.ldq, t * 64, p.nq, sQ, sQT, qscale);
-        stage_tile<D>(DO, p.lddo, t * 64, p.nq, sDO, sDOT, 1.0f);
+    TileRegs<D> rq, rdo;
+    float pl = -INFINITY, pd = 0.f;
+    auto gload_stats = [&](int t) {
         if (tid < 64) {
             const int qr = t * 64 + tid;
-            sL[tid] = qr < p.nq ? -p.lse[bh + qr] : -INFINITY;
-            sDl[tid] = qr < p.nq ? p.delta[bh + qr] : 0.f;
+            pl = qr < p.nq ? -p.lse[bh + qr] : -INFINITY;
+            pd = qr < p.nq ? p.delta[bh + qr] : 0.f;
+        }
+    };
+    if (t0 < nqt) {
+        rq.gload(Q, p.ldq, t0 * 64, p.nq);
+        rdo.gload(DO, p.lddo, t0 * 64, p.nq);
+        gload_stats(t0);
+    }
+    for (int t = t0; t < nqt; ++t) {
+        __syncthreads();
+        rq.swrite(sQ, qscale);
+        rdo.swrite(sDO, 1.0f);
+        if (tid < 64) {
+            sL[tid] = pl;
+            sDl[tid] = pd;
         }
         __syncthreads();
+        if (t + 1 < nqt) {
+            rq.gload(Q, p.ldq, (t + 1) * 64, p.nq);
+            rdo.gload(DO, p.lddo, (t + 1) * 64, p.nq);
+            gload_stats(t + 1);
+        }
         float4_t pw[4], ds[4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
@@ -260,8 +296,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
             }
 #pragma unroll
             for (int f = 0; f < C::DT; ++f) {
-                accV[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sDOT, f, s2, fr, fq), bp, accV[f], 0, 0, 0);
-                accK[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sQT, f, s2, fr, fq), bs, accK[f], 0, 0, 0);
+                accV[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sDO, f, s2, fr, fq), bp, accV[f], 0, 0, 0);
+                accK[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sQ, f, s2, fr, fq), bs, accK[f], 0, 0, 0);
             }
         }
     }
@@ -288,8 +324,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
 template <int D>
 int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
     using C = BCfg<D>;
-    constexpr int smem_dq = (2 * C::TILE + C::TTILE) * 2;
-    constexpr int smem_dkv = (2 * C::TILE + 2 * C::TTILE) * 2 + 128 * 4;
+    constexpr int smem_dq = 2 * C::TILE * 2;
+    constexpr int smem_dkv = 2 * C::TILE * 2 + 128 * 4;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -305,6 +341,325 @@ int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3((unsigned)(((p.nk + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dkv, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)(((p.nq + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dq, s, p);
+    return PV_CHECK_LAUNCH();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Dual-branch cross attention backward (PhotoVerseAttnProcessor2_0, attention_processor.py:317-322 text branch, :392-420 image-token
+// branch + fusion): O = w_t softmax(S_t) V_t + w_i softmax(S_i) V_i over the 96-row K / V image (text rows [0, nt), image-token rows
+// [80, 80 + nip)).  Same MFMA scheme as the self-attention backward; the key set is one tile, so
+//   pass 1 (xattn_bwd_dq): 64 queries per workgroup - both softmaxes in registers, dQ, and the per-(query, branch) statistics
+//                          (lse, delta = sum_j P_j dP_j) for pass 2
+//   pass 2 (xattn_bwd_dkv): 6 waves = the 96 keys, one workgroup per chunk of 512 queries -> fp32 partial dK / dV, summed in chunk
+//                          order by xattn_bwd_reduce (deterministic), which also adds the to_v_ip_norm regulariser gradient.
+constexpr int XB_KEYS = 96;
+constexpr int XB_IP0 = 80;
+constexpr int XB_QCH = 512;     // queries per pass-2 workgroup
+
+// stage the 96-row K (or V) image of (b, h) from its two sources into a row-major LDS tile
+template <int D, int NT>
+__device__ __forceinline__ void xb_stage_kv(const pv_xattn_bwd_params& p, int b, int h, bool want_v, half_t* sR) {
+    using C = BCfg<D>;
+    constexpr int CHP = C::DK / 8;
+    const half_t* t = reinterpret_cast<const half_t*>(want_v ? p.vt : p.kt);
+    const half_t* ipp = reinterpret_cast<const half_t*>(want_v ? p.vip : p.kip);
+    const int ldt = want_v ? p.ldvt : p.ldkt, ldi = want_v ? p.ldvip : p.ldkip;
+    for (int i = threadIdx.x; i < XB_KEYS * CHP; i += NT) {
+        const int j = i / CHP, c = i - j * CHP;
+        half8_t v = tz8();
+        if (c < C::CH) {
+            if (j < p.nt) v = *reinterpret_cast<const half8_t*>(t + ((size_t)b * p.nt + j) * ldt + h * D + c * 8);
+            else if (j >= XB_IP0 && j < XB_IP0 + p.nip) v = *reinterpret_cast<const half8_t*>(ipp + ((size_t)b * p.nip + j - XB_IP0) * ldi + h * D + c * 8);
+        }
+        *reinterpret_cast<half8_t*>(sR + j * C::RS + c * 8) = v;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const pv_xattn_bwd_params p) {
+    using C = BCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sK = reinterpret_cast<half_t*>(smem);
+    half_t* sV = sK + XB_KEYS * C::RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nqt = (p.nq + 63) / 64;
+    const int qt = blockIdx.x % nqt, h = (blockIdx.x / nqt) % p.heads, b = blockIdx.x / (nqt * p.heads);
+    const float w_text = p.fusion ? p.fusion[0] : p.w_text, w_ip = p.fusion ? p.fusion[1] : p.w_ip;
+    const float scale = rsqrtf((float)D), qscale = scale * 1.4426950408889634f;
+    xb_stage_kv<D, 256>(p, b, h, false, sK);
+    xb_stage_kv<D, 256>(p, b, h, true, sV);
+
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
+    const int qrow = qt * 64 + wave * 16 + fr;
+    const bool qok = qrow < p.nq;
+    const int qc = qok ? qrow : p.nq - 1;
+    half8_t qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const int c = ks * 4 + fq;
+        qf[ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)qc * p.ldq + c * 8) : tz8();
+        dof[ks] = (c < C::CH && qok) ? *reinterpret_cast<const half8_t*>(DO + (size_t)qc * p.lddo + c * 8) : tz8();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * qscale);
+    }
+    __syncthreads();
+
+    float4_t s[6], dp[6];
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        s[kb] = dp[kb] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const half8_t ka = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+            const half8_t va = *reinterpret_cast<const half8_t*>(sV + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], s[kb], 0, 0, 0);
+            dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, dof[ks], dp[kb], 0, 0, 0);
+        }
+    }
+    // key (kb, r) = kb*16 + fq*4 + r: subtiles 0..4 are text rows (valid below nt), subtile 5 the image-token rows (valid below nip)
+    float mt = -INFINITY, mi = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kb * 16 + fq * 4 + r;
+            if (kb < 5) { if (key < p.nt) mt = fmaxf(mt, s[kb][r]); }
+            else if (key - XB_IP0 < p.nip) mi = fmaxf(mi, s[kb][r]);
+        }
+    mt = pv_quad_max(mt);
+    mi = pv_quad_max(mi);
+    float lt = 0.f, li = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kb * 16 + fq * 4 + r;
+            float e = 0.f;
+            if (kb < 5) { if (key < p.nt) { e = PV_EXP2(s[kb][r] - mt); lt += e; } }
+            else if (key - XB_IP0 < p.nip) { e = PV_EXP2(s[kb][r] - mi); li += e; }
+            s[kb][r] = e;
+        }
+    lt = pv_quad_sum(lt);
+    li = pv_quad_sum(li);
+    const float it = lt > 0.f ? 1.0f / lt : 0.f, ii = li > 0.f ? 1.0f / li : 0.f;
+    float dt = 0.f, di = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[kb][r] *= kb < 5 ? it : ii;                       // P
+            if (kb < 5) dt += s[kb][r] * dp[kb][r]; else di += s[kb][r] * dp[kb][r];
+        }
+    dt = pv_quad_sum(dt);
+    di = pv_quad_sum(di);
+    if (qok && fq == 0) {
+        float4_t st = float4_t{mt + __log2f(lt), mi + __log2f(li), dt, di};
+        *reinterpret_cast<float4_t*>(p.stats + (((size_t)b * p.heads + h) * p.nq + qrow) * 4) = st;
+    }
+    float4_t acc[C::DT];
+#pragma unroll
+    for (int f = 0; f < C::DT; ++f) acc[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+        half8_t bsl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+            bsl[r] = (half_t)((k0 < 5 ? w_text : w_ip) * s[k0][r] * (dp[k0][r] - (k0 < 5 ? dt : di)));
+            bsl[r + 4] = (half_t)((k1 < 5 ? w_text : w_ip) * s[k1][r] * (dp[k1][r] - (k1 < 5 ? dt : di)));
+        }
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sK, f, s2, fr, fq), bsl, acc[f], 0, 0, 0);
+    }
+    if (qok) {
+        half_t* dQ = reinterpret_cast<half_t*>(p.dq) + ((size_t)b * p.nq + qrow) * p.lddq + h * D;
+        const float os = scale * p.out_scale;
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) {
+            const int dv = f * 16 + fq * 4;
+            if (dv < D) {
+                half4_t o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[f][r] * os);
+                *reinterpret_cast<half4_t*>(dQ + dv) = o;
+            }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(384) void xattn_bwd_dkv_kernel(const pv_xattn_bwd_params p, const int nchunk) {
+    using C = BCfg<D>;
+    constexpr int NT = 384;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sQ = reinterpret_cast<half_t*>(smem);
+    half_t* sDO = sQ + C::TILE;
+    float* sSt = reinterpret_cast<float*>(sDO + C::TILE);      // [64][4]: lse_t, lse_i, delta_t, delta_i of the staged queries
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int chunk = blockIdx.x % nchunk, h = (blockIdx.x / nchunk) % p.heads, b = blockIdx.x / (nchunk * p.heads);
+    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
+    const bool is_ip = wave == 5;                              // wave-uniform branch: waves 0..4 own text rows, wave 5 the image-token rows
+    const float wb = p.fusion ? p.fusion[is_ip ? 1 : 0] : (is_ip ? p.w_ip : p.w_text);
+    const int key = wave * 16 + fr;
+    const bool kok = is_ip ? (key - XB_IP0 < p.nip) : (key < p.nt);
+    const half_t* Ksrc = is_ip ? reinterpret_cast<const half_t*>(p.kip) + ((size_t)b * p.nip + (kok ? key - XB_IP0 : 0)) * p.ldkip
+                               : reinterpret_cast<const half_t*>(p.kt) + ((size_t)b * p.nt + (kok ? key : 0)) * p.ldkt;
+    const half_t* Vsrc = is_ip ? reinterpret_cast<const half_t*>(p.vip) + ((size_t)b * p.nip + (kok ? key - XB_IP0 : 0)) * p.ldvip
+                               : reinterpret_cast<const half_t*>(p.vt) + ((size_t)b * p.nt + (kok ? key : 0)) * p.ldvt;
+    half8_t kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const int c = ks * 4 + fq;
+        kf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Ksrc + h * D + c * 8) : tz8();
+        vf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Vsrc + h * D + c * 8) : tz8();
+    }
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
+    const float* stats = p.stats + ((size_t)b * p.heads + h) * p.nq * 4;
+    float4_t accK[C::DT], accV[C::DT];
+#pragma unroll
+    for (int f = 0; f < C::DT; ++f) accK[f] = accV[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int q0 = chunk * XB_QCH, q1 = min(q0 + XB_QCH, p.nq);
+    const int nt_ = (q1 - q0 + 63) / 64;
+    TileRegs<D, NT> rq, rdo;
+    float4_t pst = float4_t{INFINITY, INFINITY, 0.f, 0.f};
+    auto gstats = [&](int t) {
+        if (tid < 64) {
+            const int qr = q0 + t * 64 + tid;
+            pst = qr < q1 ? *reinterpret_cast<const float4_t*>(stats + (size_t)qr * 4) : float4_t{INFINITY, INFINITY, 0.f, 0.f};
+        }
+    };
+    rq.gload(Q, p.ldq, q0, q1);
+    rdo.gload(DO, p.lddo, q0, q1);
+    gstats(0);
+    for (int t = 0; t < nt_; ++t) {
+        __syncthreads();
+        rq.swrite(sQ, qscale);
+        rdo.swrite(sDO, 1.0f);
+        if (tid < 64) *reinterpret_cast<float4_t*>(sSt + tid * 4) = pst;
+        __syncthreads();
+        if (t + 1 < nt_) {
+            rq.gload(Q, p.ldq, q0 + (t + 1) * 64, q1);
+            rdo.gload(DO, p.lddo, q0 + (t + 1) * 64, q1);
+            gstats(t + 1);
+        }
+        float4_t pw[4], ds[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            float4_t sc, dl, dpv = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* st = sSt + (qb * 16 + fq * 4 + r) * 4;
+                sc[r] = -st[is_ip ? 1 : 0];
+                dl[r] = st[is_ip ? 3 : 2];
+            }
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const half8_t qa = *reinterpret_cast<const half8_t*>(sQ + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                const half8_t da = *reinterpret_cast<const half8_t*>(sDO + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kf[ks], sc, 0, 0, 0);
+                dpv = __builtin_amdgcn_mfma_f32_16x16x32_f16(da, vf[ks], dpv, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = kok ? wb * PV_EXP2(sc[r]) : 0.f;
+                pw[qb][r] = pr;
+                ds[qb][r] = pr * (dpv[r] - dl[r]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8_t bp, bs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bp[r] = (half_t)pw[2 * s2][r];
+                bp[r + 4] = (half_t)pw[2 * s2 + 1][r];
+                bs[r] = (half_t)ds[2 * s2][r];
+                bs[r + 4] = (half_t)ds[2 * s2 + 1][r];
+            }
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) {
+                accV[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sDO, f, s2, fr, fq), bp, accV[f], 0, 0, 0);
+                accK[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sQ, f, s2, fr, fq), bs, accK[f], 0, 0, 0);
+            }
+        }
+    }
+    float* part = p.partial + ((((size_t)b * p.heads + h) * nchunk + chunk) * 2) * XB_KEYS * D + (size_t)key * D;
+#pragma unroll
+    for (int f = 0; f < C::DT; ++f) {
+        const int dv = f * 16 + fq * 4;
+        if (dv < D) {
+            float4_t k4, v4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                k4[r] = accK[f][r] * 0.6931471805599453f;
+                v4[r] = accV[f][r];
+            }
+            *reinterpret_cast<float4_t*>(part + dv) = k4;
+            *reinterpret_cast<float4_t*>(part + XB_KEYS * D + dv) = v4;
+        }
+    }
+}
+
+// sum the per-tile partials in tile order (deterministic) and scatter to the four gradient tensors (fp32 rows [B*nt | B*nip][C]);
+// adds the to_v_ip_norm regulariser gradient vnorm_coef * v / ||v|| to dV_ip
+template <int D>
+__global__ void xattn_bwd_reduce_kernel(const pv_xattn_bwd_params p, const int ntile) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.batch * p.heads * XB_KEYS * D;
+    if (idx >= total) return;
+    const int c = (int)(idx % D), j = (int)((idx / D) % XB_KEYS), h = (int)((idx / ((long)D * XB_KEYS)) % p.heads), b = (int)(idx / ((long)D * XB_KEYS * p.heads));
+    const bool is_t = j < p.nt, is_i = j >= XB_IP0 && j < XB_IP0 + p.nip;
+    if (!is_t && !is_i) return;
+    const float* src = p.partial + (((size_t)b * p.heads + h) * ntile * 2) * XB_KEYS * D + (size_t)j * D + c;
+    float dk = 0.f, dv = 0.f;
+    for (int t = 0; t < ntile; ++t) {
+        dk += src[(size_t)t * 2 * XB_KEYS * D];
+        dv += src[(size_t)t * 2 * XB_KEYS * D + XB_KEYS * D];
+    }
+    if (is_t) {
+        p.dkt[((size_t)b * p.nt + j) * p.ld_dt + h * D + c] = dk * p.out_scale;
+        p.dvt[((size_t)b * p.nt + j) * p.ld_dt + h * D + c] = dv * p.out_scale;
+    } else {
+        const int pi = j - XB_IP0;
+        if (p.vnorm_coef != 0.f || p.vnorm_grad) {
+            const half_t* v = reinterpret_cast<const half_t*>(p.vip) + ((size_t)b * p.nip + pi) * p.ldvip + h * D;
+            float n2 = 0.f;
+            for (int cc = 0; cc < D; ++cc) n2 += (float)v[cc] * (float)v[cc];
+            const float gnorm = p.vnorm_coef + (p.vnorm_grad ? p.vnorm_grad[((size_t)b * p.heads + h) * p.nip + pi] : 0.f);
+            dv += gnorm * (float)v[c] * rsqrtf(fmaxf(n2, 1e-30f));
+        }
+        p.dkip[((size_t)b * p.nip + pi) * p.ld_di + h * D + c] = dk * p.out_scale;
+        p.dvip[((size_t)b * p.nip + pi) * p.ld_di + h * D + c] = dv * p.out_scale;
+    }
+}
+
+template <int D>
+int launch_xattn_bwd(const pv_xattn_bwd_params& p, hipStream_t s) {
+    using C = BCfg<D>;
+    constexpr int smem_dq = 2 * XB_KEYS * C::RS * 2;
+    constexpr int smem_dkv = 2 * C::TILE * 2 + 64 * 4 * 4;
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& attr_set = attr_set_dev[dev_id & 63];
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nqt = (p.nq + 63) / 64, nchunk = (p.nq + XB_QCH - 1) / XB_QCH;
+    hipLaunchKernelGGL(xattn_bwd_dq_kernel<D>, dim3((unsigned)(nqt * p.heads * p.batch)), dim3(256), smem_dq, s, p);
+    hipLaunchKernelGGL(xattn_bwd_dkv_kernel<D>, dim3((unsigned)(nchunk * p.heads * p.batch)), dim3(384), smem_dkv, s, p, nchunk);
+    const long total = (long)p.batch * p.heads * XB_KEYS * D;
+    hipLaunchKernelGGL(xattn_bwd_reduce_kernel<D>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, nchunk);
     return PV_CHECK_LAUNCH();
 }
 
@@ -604,6 +959,21 @@ __global__ void gather_rows_kernel(const half_t* x, int ldx, const int32_t* idx,
 }
 
 }  // namespace
+
+extern "C" int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream) {
+    if (!p || !p->q || !p->kt || !p->vt || !p->kip || !p->vip || !p->dout || !p->dq || !p->partial || !p->stats || !p->dkt || !p->dvt || !p->dkip || !p->dvip ||
+        p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nt <= 0 || p->nt > XB_IP0 || p->nip <= 0 || p->nip > XB_KEYS - XB_IP0 || p->out_scale == 0.f ||
+        p->ld_dt < p->heads * p->d || p->ld_di < p->heads * p->d)
+        return (int)hipErrorInvalidValue;
+    if ((p->ldq | p->ldkt | p->ldvt | p->ldkip | p->ldvip | p->lddo | p->lddq) % 8) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->d) {
+        case 40: return launch_xattn_bwd<40>(*p, s);
+        case 80: return launch_xattn_bwd<80>(*p, s);
+        case 160: return launch_xattn_bwd<160>(*p, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
 
 extern "C" int pv_attention_backward(const pv_attn_bwd_params* p, void* stream) {
     if (!p || !p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->delta || !p->dq || !p->dk || !p->dv) return (int)hipErrorInvalidValue;

@@ -363,10 +363,11 @@ class Recorder:
         dkv_t = self.empty((batch * nt, 2 * C_), torch.float32)
         dkv_i = self.empty((batch * nip, 2 * C_), torch.float32)
         dkt, dvt, dkip, dvip = dkv_t[:, :C_], dkv_t[:, C_:], dkv_i[:, :C_], dkv_i[:, C_:]
-        ntile = (nq + 63) // 64
-        partial = self.empty((batch * heads * ntile * 2 * 96 * d,), torch.float32)
+        nchunk = (nq + 511) // 512
+        partial = self.empty((batch * heads * nchunk * 2 * 96 * d,), torch.float32)
+        stats = self.empty((batch, heads, nq, 4), torch.float32)
         p = XAttnBwdParams(_ptr(q), _rows(q)[0], _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0], _rows(vip)[0],
-                           _ptr(dout), _rows(dout)[0], _ptr(dq), C_, _ptr(partial), _ptr(dkt), _ptr(dvt), _ptr(dkip), _ptr(dvip), 2 * C_, 2 * C_, batch, heads, nq, nt,
+                           _ptr(dout), _rows(dout)[0], _ptr(dq), C_, _ptr(partial), _ptr(stats), _ptr(dkt), _ptr(dvt), _ptr(dkip), _ptr(dvip), 2 * C_, 2 * C_, batch, heads, nq, nt,
                            nip, d, float(w_text), float(w_ip), _ptr(fusion), float(out_scale), float(vnorm_coef), _ptr(vnorm_grad))
         self.keep.extend(t for t in (q, kt, vt, kip, vip, dout, fusion, vnorm_grad) if t is not None)
         self._add(self.lib.pv_cross_attention_backward, p)
