@@ -133,25 +133,21 @@ def train_step_leg(unet, B, S, dev, reps=3):
     torch.cuda.synchronize()
     l0 = float(out["loss"])
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    t0 = time.perf_counter()
-    fb_ms = 0.0
-    for _ in range(reps):
-        ts.tape.load_weights()
-        ev[0].record()
-        ts.tape.rf.run()
-        ev[1].record()
-        ts.tape.rb.run()
-        ev[2].record()
-        out = one()
+    ts.tape.load_weights()                                   # the two plans eagerly, timed separately
+    ev[0].record()
+    ts.tape.rf.run()
+    ev[1].record()
+    ts.tape.rb.run()
+    ev[2].record()
     torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) / reps * 1e3 / 2     # each rep ran the plans twice (timed halves + the full iteration)
     fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-    # one more clean full iteration for the end-to-end figure
+    out = one()                                              # captures the HIP graph
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    out = one()
+    for _ in range(reps):
+        out = one()
     torch.cuda.synchronize()
-    iter_ms = (time.perf_counter() - t1) * 1e3
+    iter_ms = (time.perf_counter() - t1) * 1e3 / reps
     n_train = sum(p.numel() for g_ in groups.values() for p in g_)
     return {"workload": "configs[3] without the optional ArcFace term: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 on attn2.to_q/k/v; "
                         "adapters + 12-layer CLIP text encoder + SD-v1.5 UNet forward, backward through all of them, per-module clip_grad_norm_, AdamW",
@@ -159,7 +155,7 @@ def train_step_leg(unet, B, S, dev, reps=3):
             "launches_forward": len(ts.tape.rf), "launches_backward": len(ts.tape.rb), "trainable_parameters": n_train,
             "activation_bytes": ts.tape.rf.bytes_allocated + ts.tape.rb.bytes_allocated, "plan_build_s": round(build_s, 2),
             "loss_first": round(l0, 5), "loss_last": round(float(out["loss"]), 5), "finite": bool(torch.isfinite(out["loss"]).all().item()),
-            "hip_graph": False, "samples_per_s": round(B / (iter_ms * 1e-3), 2)}
+            "hip_graph": ts.graph is not None, "samples_per_s": round(B / (iter_ms * 1e-3), 2)}
 
 
 def main():

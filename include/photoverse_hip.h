@@ -275,8 +275,8 @@ typedef struct pv_xattn_bwd_params {
 int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream);
 /* out[c][r] = x[r][c] (fp16), rows zero-padded to rows_pad: operand layout of dW = dY^T . X on pv_gemm_conv */
 int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, void* out, int32_t ldo, int32_t rows_pad, void* stream);
-/* LayerNorm (+ LeakyReLU) backward (adapters.py:15-19): dx fp16; dgb_partial (optional) fp32 [ceil(rows/4)][2][cols] =
- * per-4-row-block (dgamma, dbeta) terms, to be summed with pv_reduce_blocks */
+/* LayerNorm (+ LeakyReLU) backward (adapters.py:15-19): dx fp16; dgb_partial (optional) fp32 [ceil(rows / (4 * rows_per_wave))][2][cols] =
+ * per-row-block (dgamma, dbeta) terms, to be summed with pv_reduce_blocks */
 typedef struct pv_layernorm_bwd_params {
     const void* x; int32_t ldx;
     const void* dy; int32_t lddy;
@@ -288,6 +288,7 @@ typedef struct pv_layernorm_bwd_params {
     int32_t act;
     int32_t dy_group, dy_skip;         /* dy_group > 1: row r reads dy row r / dy_group; the first dy_skip rows of a group get 0 */
     float dy_scale;                    /* multiplies dy (1 / count of a mean; 1.0 otherwise) */
+    int32_t rows_per_wave;             /* rows each wave walks (0 = 1): dgb_partial has ceil(rows / (4 * rows_per_wave)) blocks */
 } pv_layernorm_bwd_params;
 int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
 /* out[i] = scale * sum_b x[b][i], b in order (deterministic) */

@@ -33,11 +33,13 @@ __global__ void transpose_f16_kernel(const half_t* x, int ldx, int rows, int col
 //   dgamma / dbeta: per-row-block partials [blocks][2][cols] (summed by the caller's reduce: pv_reduce_cols)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_bwd_params p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int rpw = p.rows_per_wave > 0 ? p.rows_per_wave : 1;     // rows a wave walks: fewer, larger dgamma / dbeta partial blocks
     extern __shared__ float sacc[];     // [4 waves][2][cols] partial dgamma / dbeta of this block's rows
     for (int i = threadIdx.x; i < 8 * p.cols; i += 256) sacc[i] = 0.f;
     __syncthreads();
-    if (row < p.rows) {
+    for (int ri = 0; ri < rpw; ++ri) {
+        const int row = (blockIdx.x * 4 + wave) * rpw + ri;
+        if (row >= p.rows) break;
         const half_t* x = reinterpret_cast<const half_t*>(p.x) + (size_t)row * p.ldx;
         // dy may be shared by groups of rows (the patch-token mean of adapters.py:36: every patch row of a sample receives
         // dy[sample] / count, the leading `dy_skip` rows of a group - the CLS row - receive nothing)
@@ -60,8 +62,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
             const float dxh = g * p.gamma[c];
             s1 += dxh;
             s2 += dxh * xh;
-            sacc[(wave * 2 + 0) * p.cols + c] = g * xh;      // this row's dgamma / dbeta terms (one row per wave)
-            sacc[(wave * 2 + 1) * p.cols + c] = g;
+            sacc[(wave * 2 + 0) * p.cols + c] += g * xh;      // this row's dgamma / dbeta terms (one row per wave)
+            sacc[(wave * 2 + 1) * p.cols + c] += g;
         }
         s1 = pv_wave_sum(s1) / (float)p.cols;
         s2 = pv_wave_sum(s2) / (float)p.cols;
@@ -155,7 +157,7 @@ extern "C" int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_
 
 extern "C" int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream) {
     if (!p->x || !p->dy || !p->dx || !p->gamma || !p->beta || p->rows <= 0 || p->cols <= 0 || p->cols > 2048) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((p->rows + 3) / 4)), dim3(256), 8 * p->cols * sizeof(float), (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((p->rows + 4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1) - 1) / (4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1)))), dim3(256), 8 * p->cols * sizeof(float), (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }
 

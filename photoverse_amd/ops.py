@@ -395,10 +395,11 @@ class Recorder:
         dy[r // dy_group] * dy_scale, except the first ``dy_skip`` rows of each group (zero)."""
         rows, cols = x.shape
         dx = self.empty((rows, cols), torch.float16)
-        nblk = (rows + 3) // 4
+        rpw = 8 if rows >= 2048 else 1                   # rows per wave: 32-row blocks keep the dgamma / dbeta reduce short
+        nblk = (rows + 4 * rpw - 1) // (4 * rpw)
         part = self.empty((nblk, 2, cols), torch.float32) if want_affine else None
         p = LayerNormBwdParams(_ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, _ptr(gamma), _ptr(beta), _ptr(part), rows, cols,
-                               float(eps), act, int(dy_group), int(dy_skip), float(dy_scale))
+                               float(eps), act, int(dy_group), int(dy_skip), float(dy_scale), rpw)
         self.keep.extend((x, dy, gamma, beta))
         self._add(self.lib.pv_layernorm_backward, p)
         dgb = None

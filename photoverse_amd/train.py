@@ -138,8 +138,9 @@ class TrainStep:
 
     def __init__(self, unet, text_encoder, text_adapter, image_adapter, *, batch: int, h: int, w: int, n_tokens: int, seq: int = 77,
                  clip_tokens: int = 257, clip_dim: int = 1024, grad_scale: float = 4096.0, fusion_seed: int = 0,
-                 loss_weights=(1.0, 0.01, 0.001)):
+                 loss_weights=(1.0, 0.01, 0.001), use_graph: bool = True):
         dev = unet.device
+        self.use_graph, self.graph, self._warm = bool(use_graph), None, False
         self.unet, self.text_encoder, self.text_adapter, self.image_adapter = unet, text_encoder, text_adapter, image_adapter
         self.B, self.H, self.W, self.E, self.S_len = batch, h, w, n_tokens, seq
         self.grad_scale = float(grad_scale)
@@ -456,8 +457,21 @@ class TrainStep:
         else:
             self.fusion_forced.fill_(-1.0)
         self.tape.load_weights()
-        self.tape.rf.run()
-        self.tape.rb.run()
+        if self.graph is not None:
+            self.graph.replay()
+        elif self.use_graph and self._warm:
+            # second iteration on: forward + backward plans as ONE HIP graph (launches enqueue on the capturing stream)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self.tape.rf.run()
+                self.tape.rb.run()
+            self.graph = gr
+            gr.replay()
+        else:
+            self.tape.rf.run()
+            self.tape.rb.run()
+            self._warm = True
         for param, buf in self.pgrads:
             param.grad = buf.view(param.shape)
         for mod, dW in self.lora_pending:                       # rank-r factor gradients from the merged-weight gradient
