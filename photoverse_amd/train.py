@@ -1,15 +1,18 @@
-"""Forward half of one PhotoVerse training step (``/root/reference/train.py:466-516``) on the HIP kernels.
+"""One PhotoVerse training step (``/root/reference/train.py:466-545``) on the HIP kernels.
 
-What a training iteration evaluates before ``accelerator.backward(loss)``: VAE-encode the pixels and sample the posterior
-(``:473-474``), draw noise and per-sample timesteps and add the noise (``:477-484``), CLIP image features -> both adapters in FULL
-mode (all ``extra_num_tokens + 1`` tokens, ``:487-502``), the dict-input text encoder with concept injection (``:497-499``), the UNet
+``training_step_forward``: what an iteration evaluates before ``accelerator.backward(loss)`` - VAE-encode the pixels and sample the
+posterior (``:473-474``), draw noise and per-sample timesteps and add the noise (``:477-484``), CLIP image features -> both adapters in
+FULL mode (all ``extra_num_tokens + 1`` tokens, ``:487-502``), the dict-input text encoder with concept injection (``:497-499``), the UNet
 in grad mode - per-sample timesteps ``(B,)``, every cross-attention layer drawing its branch fusion
 (``attention_processor.py:413-420``; here on the device, ``pv_fusion_draw``) - and the three loss terms (``:509-516,541``):
 
     loss = mse(noise_pred, noise) + 0.01 * mean|concept_text_embeddings| + 0.001 * mean(to_v_ip_norm stack)   [+ 0.01 * face loss]
 
-The BACKWARD (dX through every kernel, dW of the adapters / ``to_k_ip`` / ``to_v_ip`` / LoRA, AdamW) and the ArcFace face loss are not
-built; this module is the forward they will hang off, and what ``bench.py``'s ``train_forward`` object times.
+on the inference-style engine (fused GEGLU / fused attn2, nothing kept for a backward).
+
+``TrainStep`` (below): the trainable part of the step - adapters, text encoder, UNet, losses - as a forward AND a backward launch plan
+(``tape.py``), leaving gradients on every parameter ``train.py:366-377`` optimises; ``optim.AdamW`` finishes the iteration
+(``:538-545``).  The optional ArcFace face-loss term (``:521-535``) is not built.
 """
 from __future__ import annotations
 
