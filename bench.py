@@ -21,7 +21,7 @@ if ROOT not in sys.path:
 # analytic algorithmic FLOPs of one SD-v1.5 UNet forward per sample at 64x64 latents, P=1
 UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-DOMINANT_KERNEL = "gemm_conv_kernel<5, true, false, true>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
+DOMINANT_KERNEL = "gemm_conv_kernel<5, true, false, true, false>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
 
 
 def cpu_baseline(seconds_budget=40.0):
@@ -286,9 +286,9 @@ def main():
         # collected in their own runs, so the number is read from the committed summary, not measured in this process)
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r01_d_pmc_traffic.json: " + pmc.get("note", "")
+            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r02_pmc_traffic.json: " + pmc.get("note", "")
         except (OSError, ValueError):
             pass
         algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl
