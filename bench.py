@@ -96,7 +96,7 @@ def spawn_ranks(n, argv, dry=False):
 
 
 def train_step_leg(unet, B, S, dev, reps=3):
-    """Time one full training iteration at configs[3]'s shape: bs=16, 64x64 latents, 5 image tokens, LoRA (r=8) on attn2.to_q/k/v,
+    """Time one full training iteration at configs[3]'s shape: bs=16, 64x64 latents, 5 image tokens, LoRA (r=8, dropout 0.1) on attn2.to_q/k/v,
     SD-v1.5-sized UNet, 12-layer CLIP text encoder, both adapters; forward + backward + clip + AdamW."""
     import time
     import torch
@@ -106,7 +106,7 @@ def train_step_leg(unet, B, S, dev, reps=3):
     from photoverse_amd.optim import AdamW
     from photoverse_amd.train import TrainStep
     torch.manual_seed(7)
-    inject_adapter_in_model(LoraConfig(r=8, lora_alpha=1), unet)
+    inject_adapter_in_model(LoraConfig(r=8, lora_alpha=1, lora_dropout=0.1), unet)      # train.py:258-275 defaults
     unet.to(dev)
     for m in unet.modules():
         if hasattr(m, "lora_B"):
@@ -149,7 +149,7 @@ def train_step_leg(unet, B, S, dev, reps=3):
     torch.cuda.synchronize()
     iter_ms = (time.perf_counter() - t1) * 1e3 / reps
     n_train = sum(p.numel() for g_ in groups.values() for p in g_)
-    return {"workload": "configs[3] without the optional ArcFace term: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 on attn2.to_q/k/v; "
+    return {"workload": "configs[3] without the optional ArcFace term: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 / alpha=1 / dropout=0.1 (the reference defaults) on attn2.to_q/k/v; "
                         "adapters + 12-layer CLIP text encoder + SD-v1.5 UNet forward, backward through all of them, per-module clip_grad_norm_, AdamW",
             "ms_per_iteration": round(iter_ms, 2), "forward_plan_ms": round(fwd_ms, 2), "backward_plan_ms": round(bwd_ms, 2),
             "launches_forward": len(ts.tape.rf), "launches_backward": len(ts.tape.rb), "trainable_parameters": n_train,

@@ -179,6 +179,12 @@ int pv_act_backward(const void* x, int32_t ldx, const void* dy, int32_t lddy, vo
                     void* stream);
 /* y = act(x) as its own pass (the training forward keeps the pre-activation) */
 int pv_act_forward(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t rows, int32_t cols, int32_t act, void* stream);
+/* Dropout on the input of a LoRA branch (peft LoRA layer: result += B(A(dropout(x))) * scaling; train.py:265-270).  Counter-based
+ * (Philox4x32-10): the keep mask is a function of (rng key, site, rng[2] = iteration, copy, element), recomputed by the backward.
+ * forward: out[r][k*cols + c] = x[r][c] * keep_k / (1-p), k < copies (several independently masked copies side by side);
+ * backward: out[r][c] = sum_k x[r][k*cols + c] * keep_k / (1-p) (+ add).  rng: the {key lo, key hi, counter} block of pv_fusion_draw. */
+int pv_dropout_f16(const void* x, int32_t ldx, void* out, int32_t ldo, const void* add, int32_t ldadd, int32_t rows, int32_t cols, int32_t copies,
+                   float p, const int32_t* rng, int32_t site, int32_t backward, void* stream);
 /* out = a + b over fp16 rows (gradient accumulation) */
 int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream);
 /* z (B,2h,2w,c) = x (B,h,w,c) at the even positions, 0 elsewhere: input of the data gradient of a stride-2 3x3 conv (Downsample2D) */

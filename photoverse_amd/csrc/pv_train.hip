@@ -885,6 +885,62 @@ __global__ void act_fwd_kernel(const half_t* x, int ldx, half_t* y, int ldy, int
     *reinterpret_cast<half8_t*>(y + (size_t)r * ldy + c) = o;
 }
 
+// Philox4x32-10 (Salmon et al. 2011), all four output words
+__device__ __forceinline__ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Dropout on the input of a LoRA branch (peft: result += B(A(dropout(x))) * scaling; train.py:265 lora_dropout).  Counter-based: the
+// keep mask of element (row, col) of copy k is a pure function of (key, site, iteration, k, row, col) - the backward launch recomputes
+// it, nothing is stored.  rng = {key lo, key hi, iteration counter} (the block pv_fusion_draw advances once per forward).
+//   forward  (bwd = 0): out[r][k * cols + c] = x[r][c] * keep_k / (1 - p)                        k < copies
+//   backward (bwd = 1): out[r][c] = sum_k x[r][k * cols + c] * keep_k / (1 - p) (+ add[r][c])
+__global__ void dropout_kernel(const half_t* x, int ldx, half_t* out, int ldo, const half_t* add, int ldadd, int rows, int cols, int copies, float p,
+                               const uint32_t* rng, uint32_t site, int bwd) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch);
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    const float inv = 1.0f / (1.0f - p);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (bwd && add) {
+        const half8_t a = *reinterpret_cast<const half8_t*>(add + (size_t)r * ldadd + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (float)a[j];
+    }
+    half8_t xin = tz8();
+    if (!bwd) xin = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + c * 8);
+    for (int k = 0; k < copies; ++k) {
+        uint32_t w[4];
+        philox4(rng[0], rng[1], (uint32_t)idx, site, rng[2], (uint32_t)k, w);
+        if (bwd) xin = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + k * cols + c * 8);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool keep = ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr;
+            const float v = keep ? (float)xin[j] * inv : 0.f;
+            if (bwd) acc[j] += v; else o[j] = (half_t)v;
+        }
+        if (!bwd) *reinterpret_cast<half8_t*>(out + (size_t)r * ldo + k * cols + c * 8) = o;
+    }
+    if (bwd) {
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+        *reinterpret_cast<half8_t*>(out + (size_t)r * ldo + c * 8) = o;
+    }
+}
+
 __global__ void add_rows_kernel(const half_t* a, int lda, const half_t* b, int ldb, half_t* out, int ldo, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = cols / 8;
@@ -1025,6 +1081,16 @@ extern "C" int pv_act_forward(const void* x, int32_t ldx, void* y, int32_t ldy, 
     const long total = (long)rows * (cols / 8);
     hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (half_t*)y, ldy, rows, cols,
                        act);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_dropout_f16(const void* x, int32_t ldx, void* out, int32_t ldo, const void* add, int32_t ldadd, int32_t rows, int32_t cols, int32_t copies,
+                              float p, const int32_t* rng, int32_t site, int32_t backward, void* stream) {
+    if (!x || !out || !rng || rows <= 0 || cols <= 0 || cols % 8 || copies < 1 || copies > 4 || !(p >= 0.f && p < 1.f) || (ldx | ldo | ldadd) % 8)
+        return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (half_t*)out, ldo,
+                       (const half_t*)add, ldadd, rows, cols, copies, p, reinterpret_cast<const uint32_t*>(rng), (uint32_t)site, backward);
     return PV_CHECK_LAUNCH();
 }
 

@@ -1,7 +1,9 @@
 """Minimal LoRA support compatible with the checkpoint layout the reference writes through peft
 (``/root/reference/models/modeling_utils.py:15-18,45-46,86-88``; ``train.py:348-354``): injected Linear layers are renamed
 ``<name>.base_layer`` and gain ``<name>.lora_A.default`` (r x in) and ``<name>.lora_B.default`` (out x r).
-For the HIP inference path the low-rank update is merged into the packed fp16 weight (W + alpha/r * B @ A).
+For the HIP inference path the low-rank update is merged into the packed fp16 weight (W + alpha/r * B @ A); the training plan
+(``train.TrainStep``) does the same when ``lora_dropout == 0`` and runs the low-rank branch separately, with a device-side dropout on
+its input, otherwise.
 peft itself is not installable here ([EXT] peft==0.10.0), so ``LoraConfig`` mirrors only the fields the reference uses.
 """
 from __future__ import annotations
@@ -26,8 +28,9 @@ class LoraConfig:
 
 
 class LoRALinear(nn.Module):
-    def __init__(self, base: nn.Linear, r: int, alpha: float):
+    def __init__(self, base: nn.Linear, r: int, alpha: float, dropout: float = 0.0):
         super().__init__()
+        self.dropout_p = float(dropout)      # peft: result += B(A(dropout(x))) * scaling in train mode (identity at inference)
         self.base_layer = base
         self.lora_A = nn.ModuleDict({"default": nn.Linear(base.in_features, r, bias=False)})
         self.lora_B = nn.ModuleDict({"default": nn.Linear(r, base.out_features, bias=False)})
@@ -58,7 +61,7 @@ def inject_adapter_in_model(config: LoraConfig, model: nn.Module) -> nn.Module:
         parent_name, _, leaf = name.rpartition(".")
         parent = model.get_submodule(parent_name) if parent_name else model
         base = getattr(parent, leaf)
-        wrapped = LoRALinear(base, config.r, config.lora_alpha).to(base.weight.device)
+        wrapped = LoRALinear(base, config.r, config.lora_alpha, config.lora_dropout).to(base.weight.device)
         setattr(parent, leaf, wrapped)
     if hasattr(model, "repack"):
         model.repack()

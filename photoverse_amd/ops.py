@@ -271,6 +271,17 @@ class Recorder:
         self._add(self.lib.pv_act_forward, _ptr(x), _rows(x)[0], _ptr(y), cols, rows, cols, act)
         return y
 
+    def dropout(self, x, *, p, rng, site, copies=1, backward=False, add=None):
+        """Forward: [rows, copies * cols] independently masked, 1/(1-p)-scaled copies of x; backward: x = the gradient of that, returns its
+        masked sum over the copies (+ add).  Same (rng, site) -> same masks."""
+        rows = x.shape[0]
+        cols = x.shape[1] // copies if backward else x.shape[1]
+        out = self.empty((rows, cols if backward else cols * copies))
+        self.keep.extend(t for t in (x, rng, add) if t is not None)
+        self._add(self.lib.pv_dropout_f16, _ptr(x), _rows(x)[0], _ptr(out), _rows(out)[0], _ptr(add), _rows(add)[0] if add is not None else 0, rows, cols,
+                  copies, float(p), _ptr(rng), int(site), int(backward))
+        return out
+
     def add_rows(self, a, b, out=None):
         rows, cols = a.shape
         if out is None:

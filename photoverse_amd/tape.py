@@ -229,6 +229,16 @@ class Tape:
         self.back.append(bwd)
         return out
 
+    def dropout(self, x: Var, *, p, rng, site, copies=1) -> Var:
+        """``copies`` independently masked copies of x side by side (the inputs of the LoRA branches of to_k / to_v share one tensor)."""
+        out = Var(self.rf.dropout(x.t, p=p, rng=rng, site=site, copies=copies), x.needs)
+
+        def bwd():
+            if out.g is not None and x.needs:
+                x.g = self.rb.dropout(out.g, p=p, rng=rng, site=site, copies=copies, backward=True, add=x.g)
+        self.back.append(bwd)
+        return out
+
     def add_into(self, a: Var, b: Var, dst: torch.Tensor) -> Var:
         """dst (a column slice of a wider buffer) = a + b."""
         self.rf.add_rows(a.t, b.t, out=dst)

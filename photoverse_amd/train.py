@@ -12,7 +12,8 @@ on the inference-style engine (fused GEGLU / fused attn2, nothing kept for a bac
 
 ``TrainStep`` (below): the trainable part of the step - adapters, text encoder, UNet, losses - as a forward AND a backward launch plan
 (``tape.py``), leaving gradients on every parameter ``train.py:366-377`` optimises; ``optim.AdamW`` finishes the iteration
-(``:538-545``).  The optional ArcFace face-loss term (``:521-535``) is not built.
+(``:538-545``).  ``lora_dropout > 0`` (the reference default, 0.1) runs the low-rank branches un-merged with a device-side dropout.  The optional ArcFace
+face-loss term (``:521-535``) is not built.
 """
 from __future__ import annotations
 
@@ -253,6 +254,53 @@ class TrainStep:
             return tp.trainable(lambda m=lin_mod: m.weight), lin_mod
         return tp.frozen(lin_mod.weight), None
 
+    def _lora_branch(self, x: Var, mods, site: int, rows_per_image) -> Var:
+        """peft's un-merged LoRA forward for ``len(mods)`` projections of the same input (train.py:348-354 with lora_dropout > 0):
+        y = [W_i x]_i + [s_i B_i A_i dropout_i(x)]_i.  The low-rank factors are zero-padded to 128 rows / columns per projection (the MFMA
+        GEMM's tile width) and stacked block-diagonally, so the branch is: one dropout launch (``len(mods)`` independently masked copies
+        side by side), one GEMM to the stacked rank space, one GEMM back with the base projection as its residual."""
+        tp = self.tape
+        n, RP = len(mods), 128
+        cin = mods[0].in_features
+        couts = [m.out_features for m in mods]
+        p = mods[0].dropout_p
+        for m in mods:
+            if m.lora_A["default"].weight.shape[0] > RP:
+                raise NotImplementedError("LoRA rank > 128")
+        base = tp.linear(x, *tp.frozen(torch.cat([m.base_layer.weight for m in mods], 0)), rows_per_image=rows_per_image)
+        xd = tp.dropout(x, p=p, rng=self.fusion_rng, site=site, copies=n)                       # [M, n * cin]
+        self.dropout_sites.append((site, n, cin, p))
+
+        def a_bd():
+            w = torch.zeros(n * RP, n * cin, dtype=torch.float32, device=tp.device)
+            for i, m in enumerate(mods):
+                A = m.lora_A["default"].weight
+                w[i * RP:i * RP + A.shape[0], i * cin:(i + 1) * cin] = A.detach()
+            return w
+
+        def b_bd():
+            w = torch.zeros(sum(couts), n * RP, dtype=torch.float32, device=tp.device)
+            r0 = 0
+            for i, m in enumerate(mods):
+                Bm = m.lora_B["default"].weight
+                w[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]] = m.scaling * Bm.detach()
+                r0 += couts[i]
+            return w
+
+        def sink_a(dW):                                   # [n * 128, n * cin]
+            for i, m in enumerate(mods):
+                A = m.lora_A["default"].weight
+                self.pgrads.append((A, lambda dW=dW, i=i, A=A: dW[i * RP:i * RP + A.shape[0], i * cin:(i + 1) * cin].contiguous()))
+
+        def sink_b(dW):                                   # [sum couts, n * 128]; B_pad = s * B -> dB = s * dB_pad
+            r0 = 0
+            for i, m in enumerate(mods):
+                Bm = m.lora_B["default"].weight
+                self.pgrads.append((Bm, lambda dW=dW, i=i, r0=r0, m=m, Bm=Bm: m.scaling * dW[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]]))
+                r0 += couts[i]
+        u = tp.linear(xd, *tp.trainable(a_bd), rows_per_image=rows_per_image, on_wgrad=sink_a)   # [M, n * 128]
+        return tp.linear(u, *tp.trainable(b_bd), residual=base, rows_per_image=rows_per_image, on_wgrad=sink_b)
+
     def _lora_sink(self, mods_rows):
         """mods_rows: [(LoRALinear or None, row0, row1)] - slices of a stacked merged-weight gradient."""
         def sink(dW):
@@ -279,14 +327,25 @@ class TrainStep:
         # attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435), grad mode: fusion drawn on the device
         a2, proc = blk.attn2, blk.attn2.processor
         n2 = tp.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
-        (wq, wqT), lq = self._maybe_lora(a2.to_q)
-        q = tp.linear(n2, wq, wqT, rows_per_image=n, on_wgrad=self._lora_sink([(lq, 0, C)]) if lq is not None else None)
         lk = a2.to_k if isinstance(a2.to_k, LoRALinear) else None
         lv = a2.to_v if isinstance(a2.to_v, LoRALinear) else None
-        kv_fn = lambda a2=a2: torch.cat([a2.to_k.weight, a2.to_v.weight], 0)
-        wkv, wkvT = tp.trainable(kv_fn) if (lk is not None or lv is not None) else tp.frozen(kv_fn())
-        kvt = tp.linear(text, wkv, wkvT, rows_per_image=self.S_len,
-                        on_wgrad=self._lora_sink([(lk, 0, C), (lv, C, 2 * C)]) if (lk is not None or lv is not None) else None)
+        site = 4 * len(self.fusion_names)                 # dropout stream ids of this layer: site (q), site + 1 (k and v: copies 0 / 1)
+        if isinstance(a2.to_q, LoRALinear) and a2.to_q.dropout_p > 0:
+            q = self._lora_branch(n2, [a2.to_q], site, rows_per_image=n)
+        else:
+            (wq, wqT), lq = self._maybe_lora(a2.to_q)
+            q = tp.linear(n2, wq, wqT, rows_per_image=n, on_wgrad=self._lora_sink([(lq, 0, C)]) if lq is not None else None)
+        if lk is not None and lv is not None and (lk.dropout_p > 0 or lv.dropout_p > 0):
+            if lk.dropout_p != lv.dropout_p:
+                raise NotImplementedError("to_k / to_v LoRA layers with different dropout rates")
+            kvt = self._lora_branch(text, [lk, lv], site + 1, rows_per_image=self.S_len)
+        else:
+            if any(m is not None and m.dropout_p > 0 for m in (lk, lv)):
+                raise NotImplementedError("lora_dropout on only one of attn2.to_k / attn2.to_v")
+            kv_fn = lambda a2=a2: torch.cat([a2.to_k.weight, a2.to_v.weight], 0)
+            wkv, wkvT = tp.trainable(kv_fn) if (lk is not None or lv is not None) else tp.frozen(kv_fn())
+            kvt = tp.linear(text, wkv, wkvT, rows_per_image=self.S_len,
+                            on_wgrad=self._lora_sink([(lk, 0, C), (lv, C, 2 * C)]) if (lk is not None or lv is not None) else None)
         kip, vip = proc.to_k_ip[0], proc.to_v_ip[0]
         wkvip, wkvipT = tp.trainable(lambda kip=kip, vip=vip: torch.cat([kip.weight, vip.weight], 0))
 
@@ -322,6 +381,7 @@ class TrainStep:
         self.vnorms: Dict[str, torch.Tensor] = {}
         self.fusion_names: List[str] = []
         self.lora_pending: List[tuple] = []
+        self.dropout_sites: List[tuple] = []              # (site, copies, cols, p) of every LoRA dropout launch (tests rebuild the masks)
         procs = [m.processor for _, m in u.named_modules() if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0)]
         self.n_xattn = len(procs)
         # grad-mode branch fusion, one device-side draw per forward (attention_processor.py:413-420; pv_fusion_draw)
@@ -476,7 +536,7 @@ class TrainStep:
             self.tape.rb.run()
             self._warm = True
         for param, buf in self.pgrads:
-            param.grad = buf.view(param.shape)
+            param.grad = buf() if callable(buf) else buf.view(param.shape)
         for mod, dW in self.lora_pending:                       # rank-r factor gradients from the merged-weight gradient
             A, Bm = mod.lora_A["default"].weight, mod.lora_B["default"].weight
             A.grad = mod.scaling * (Bm.detach().t() @ dW)

@@ -345,12 +345,15 @@ def test_adamw_and_clip_match_torch(grad_scale):
             assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
 
 
-def test_training_step_backward_matches_oracle_autograd(need_gpu):
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop):
     """The whole backward of a training step (train.py:495-536 without the optional face loss) on the HIP plans: gradient of
     mse + 0.01 |concept| + 0.001 ||V_ip|| w.r.t. every trainable parameter - both adapters (through the UNet's cross-attention layers;
     the text adapter additionally through the CLIP text encoder), to_k_ip / to_v_ip of every processor and the LoRA factors behind
     attn2.to_q / to_k / to_v - against torch autograd over the fp32 oracle composition with the same forced fusion draws.  Then one
-    AdamW step with the reference's per-module gradient clipping, against torch.optim.AdamW on the oracle."""
+    AdamW step with the reference's per-module gradient clipping, against torch.optim.AdamW on the oracle.
+    p_drop = 0.1: the reference's default lora_dropout (train.py:265) - the low-rank branches run un-merged with the device-side dropout;
+    the oracle applies the SAME keep masks (rebuilt from the counter-based generator after the step)."""
     import torch.nn.functional as F
     from oracle.adapters_ref import PhotoVerseAdapterRef
     from oracle.clip_ref import CLIPTextModelRef
@@ -360,7 +363,7 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu):
     from photoverse_amd.optim import AdamW
     from photoverse_amd.train import TrainStep
     ENT, B, T, D = 2, 2, 17, 256
-    lcfg = LoraConfig(r=4, lora_alpha=8)
+    lcfg = LoraConfig(r=4, lora_alpha=8, lora_dropout=p_drop)
     tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
         None, ENT, use_lora=True, lora_config=lcfg, unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT,
         vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1), seed=31)
@@ -399,13 +402,42 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu):
     torch.cuda.synchronize()
 
     # ---- oracle: same composition under autograd ----
-    LoRALinear.forward = lambda self, x: F.linear(x, self.weight, self.bias)      # the oracle calls attn.to_q(x); CPU fp32 only
+    masks = {}
+    mods = dict(r_unet.named_modules())
+    if p_drop > 0:
+        from photoverse_amd.ops import Recorder
+        assert len(ts.dropout_sites) == 8                  # 4 cross-attention layers x (q, k|v)
+        rec = Recorder("cuda")
+        got = []
+        for site, copies, cols, p in ts.dropout_sites:
+            rows = B * 77 if copies == 2 else {320: B * 256, 640: B * 64}[cols]
+            got.append((site, copies, cols, rec.dropout(torch.ones(rows, cols, dtype=torch.float16, device="cuda"), p=p, rng=ts.fusion_rng, site=site,
+                                                        copies=copies)))
+        rec.run()
+        torch.cuda.synchronize()
+        for site, copies, cols, m in got:
+            base = ts.fusion_names[site // 4] + ".transformer_blocks.0.attn2."
+            m = m.float().cpu()
+            keep = (m > 0).float().mean().item()
+            assert abs(keep - (1 - p_drop)) < 0.02 and torch.all((m == 0) | ((m - 1 / (1 - p_drop)).abs() < 1e-3))
+            if copies == 1:
+                masks[mods[base + "to_q"]] = m
+            else:
+                masks[mods[base + "to_k"]], masks[mods[base + "to_v"]] = m[:, :cols], m[:, cols:]
+        assert not torch.equal(masks[mods[base + "to_k"]], masks[mods[base + "to_v"]])
+
+    def lora_forward(self, x):                            # the oracle calls attn.to_q(x); CPU fp32 only
+        if self not in masks:
+            return F.linear(x, self.weight, self.bias)
+        xd = (x.reshape(-1, x.shape[-1]) * masks[self]).view_as(x)        # peft: base(x) + B(A(dropout(x))) * scaling
+        return F.linear(x, self.base_layer.weight, self.bias) + self.scaling * F.linear(F.linear(xd, self.lora_A["default"].weight),
+                                                                                        self.lora_B["default"].weight)
+    LoRALinear.forward = lora_forward
     try:
         e32 = [e.float() for e in embs]
         concept = r_ta(e32)
         ehs = r_txt({"text_input_ids": ids, "concept_text_embeddings": concept, "concept_placeholder_idx": pidx})[0]
         ehs_img = r_ia(e32)
-        mods = dict(r_unet.named_modules())
         for name, u in zip(ts.fusion_names, forced):
             mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = u
         with torch.enable_grad():
