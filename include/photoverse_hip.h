@@ -185,6 +185,27 @@ int pv_act_forward(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t row
  * backward: out[r][c] = sum_k x[r][k*cols + c] * keep_k / (1-p) (+ add).  rng: the {key lo, key hi, counter} block of pv_fusion_draw. */
 int pv_dropout_f16(const void* x, int32_t ldx, void* out, int32_t ldo, const void* add, int32_t ldadd, int32_t rows, int32_t cols, int32_t copies,
                    float p, const int32_t* rng, int32_t site, int32_t backward, void* stream);
+/* ---- the ArcFace identity loss (models/loss.py, models/arcface_resnet.py; train.py:521-535) and the VAE-decoder backward under it ---- */
+/* y = x * scale[c] + shift[c] over fp16 rows: an eval-mode BatchNorm in FRONT of a zero-padded conv (IRBlock.bn0, bn4, arcface_resnet.py:18,82);
+ * shift == NULL: its backward */
+int pv_col_affine_f16(const void* x, int32_t ldx, const float* scale, const float* shift, void* y, int32_t ldy, int32_t rows, int32_t cols, void* stream);
+/* nn.PReLU() with one slope (device scalar): dy == NULL: out = prelu(x); else out = dy * prelu'(x) */
+int pv_prelu_f16(const void* x, int32_t ldx, const void* dy, int32_t lddy, const float* slope, void* out, int32_t ldo, int32_t rows, int32_t cols,
+                 void* stream);
+/* nn.MaxPool2d(2, 2) over NHWC fp16 (B,h,w,c): dy == NULL: out (B,h/2,w/2,c); else out (B,h,w,c) = dy routed to each window's first maximum */
+int pv_maxpool2x2(const void* x, const void* dy, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* FaceLoss.preprocess (loss.py:26-62): y (B,1,size,size) = bilinear(align_corners=False) of gray(x) * mul + add; x fp32 (B,3,h,w) with the given
+ * image stride (elements).  _backward: dx (B,3,h,w) contiguous from dy (B,1,size,size) with its image stride; deterministic gather */
+int pv_gray_resize(const float* x, int64_t x_image_stride, float* y, int32_t batch, int32_t h, int32_t w, int32_t size, float mul, float add, void* stream);
+int pv_gray_resize_backward(const float* dy, int64_t dy_image_stride, float* dx, int32_t batch, int32_t h, int32_t w, int32_t size, float mul, void* stream);
+/* nn.CosineEmbeddingLoss (margin 0) per sample: target > 0: 1 - cos(e1, e2), else max(0, cos); e1 / e2 fp16 [batch][dim];
+ * de2 (optional, fp16) = gscale / batch * d(loss_b)/d(e2_b) - the gradient of the batch MEAN times gscale */
+int pv_cosine_embedding_loss(const void* e1, const void* e2, int32_t batch, int32_t dim, float target, float gscale, float* per_sample, void* de2,
+                             void* stream);
+/* in-place backward of pv_softmax_rows: dp <- scale * p * (dp - sum_j p_j dp_j) per row */
+int pv_softmax_rows_backward(const void* p, int32_t ldp, void* dp, int32_t lddp, int32_t rows, int32_t cols, float scale, void* stream);
+/* out = dy where lo < y < hi else 0: gradient of images.clamp(-1, 1) (infer.py:122) */
+int pv_clamp_mask_f32(const float* y, const float* dy, float lo, float hi, float* out, int64_t n, void* stream);
 /* out = a + b over fp16 rows (gradient accumulation) */
 int pv_add_rows_f16(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ldo, int32_t rows, int32_t cols, void* stream);
 /* z (B,2h,2w,c) = x (B,h,w,c) at the even positions, 0 elsewhere: input of the data gradient of a stride-2 3x3 conv (Downsample2D) */
@@ -324,7 +345,7 @@ int pv_geglu(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t rows, i
 int pv_timestep_embedding(const float* timesteps, const int32_t* state, int32_t rows, int32_t dim,
                           void* out, void* stream);
 /* conv_out: NHWC fp16 (B,H,W,cin) -> NCHW fp32 (B,cout,H,W), 3x3 pad 1; w fp16 [cout][3][3][cin]; cout 4 (UNet) or 3 (VAE);
- * cin in {64, 128, 256, 320} */
+ * cin in {64, 128, 256, 320, 512} (512: the data gradient of the VAE decoder's conv_in) */
 int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin,
                 int32_t h, int32_t wd, int32_t cout, void* stream);
 /* CFG combine (infer.py:116) + DPM-Solver++(2M) update (infer.py:119) on fp32 NCHW latents.

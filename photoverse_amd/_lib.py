@@ -114,6 +114,14 @@ SIGNATURES = {
     "pv_dilate2x": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_pool2x_sum": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_dropout_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "pv_col_affine_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_prelu_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_maxpool2x2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pv_gray_resize": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "pv_gray_resize_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "pv_cosine_embedding_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pv_softmax_rows_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pv_clamp_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "pv_act_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_sign_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "pv_gather_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

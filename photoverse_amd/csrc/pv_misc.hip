@@ -122,6 +122,7 @@ int launch_conv_out(const half_t* x, const half_t* w, const float* bias, float* 
         case 2: hipLaunchKernelGGL((conv_out_kernel<COUT, 2>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
         case 4: hipLaunchKernelGGL((conv_out_kernel<COUT, 4>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
         case 5: hipLaunchKernelGGL((conv_out_kernel<COUT, 5>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
+        case 8: hipLaunchKernelGGL((conv_out_kernel<COUT, 8>), grid, block, smem, stream, x, w, bias, out, batch, cin, h, wd); break;
         default: return (int)hipErrorInvalidValue;
     }
     return PV_CHECK_LAUNCH();
@@ -509,7 +510,7 @@ extern "C" int pv_timestep_embedding(const float* timesteps, const int32_t* stat
 extern "C" int pv_conv_out(const void* x, const void* w, const float* bias, float* out, int32_t batch, int32_t cin, int32_t h,
                            int32_t wd, int32_t cout, void* stream) {
     if (batch <= 0 || (cin % 64) || (cout != 4 && cout != 3) || !x || !w || !out) return (int)hipErrorInvalidValue;
-    // cin in {64, 128, 256, 320}: the filter (<= 23 KB) lives in LDS
+    // cin in {64, 128, 256, 320, 512}: the filter (<= 37 KB) lives in LDS
     if (cout == 4)
         return launch_conv_out<4>(reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd, (hipStream_t)stream);
     return launch_conv_out<3>(reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(w), bias, out, batch, cin, h, wd, (hipStream_t)stream);

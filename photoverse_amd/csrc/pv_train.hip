@@ -941,6 +941,190 @@ __global__ void dropout_kernel(const half_t* x, int ldx, half_t* out, int ldo, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pieces of the ArcFace identity loss (models/loss.py:26-78, models/arcface_resnet.py:12-133) and of the VAE-decoder backward it needs
+
+// y[r][c] = x[r][c] * scale[c] + shift[c]: eval-mode BatchNorm that cannot be folded into a convolution (IRBlock.bn0 / bn4 sit in FRONT of a
+// zero-padded conv); its backward is the same launch with shift = NULL
+__global__ void col_affine_kernel(const half_t* x, int ldx, const float* scale, const float* shift, half_t* y, int ldy, int rows, int cols) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const half8_t v = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + c);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)v[j] * scale[c + j] + (shift ? shift[c + j] : 0.f));
+    *reinterpret_cast<half8_t*>(y + (size_t)r * ldy + c) = o;
+}
+
+// PReLU with ONE learned slope (nn.PReLU(), arcface_resnet.py:21,73): forward y = x > 0 ? x : a x; backward dx = dy (x > 0 ? 1 : a)
+__global__ void prelu_kernel(const half_t* x, int ldx, const half_t* dy, int lddy, const float* slope, half_t* out, int ldo, int rows, int cols) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = cols / 8;
+    if (idx >= (long)rows * nch) return;
+    const int r = (int)(idx / nch), c = (int)(idx % nch) * 8;
+    const float a = slope[0];
+    const half8_t v = *reinterpret_cast<const half8_t*>(x + (size_t)r * ldx + c);
+    half8_t o;
+    if (dy) {
+        const half8_t g = *reinterpret_cast<const half8_t*>(dy + (size_t)r * lddy + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)g[j] * ((float)v[j] > 0.f ? 1.0f : a));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)v[j] > 0.f ? (float)v[j] : a * (float)v[j]);
+    }
+    *reinterpret_cast<half8_t*>(out + (size_t)r * ldo + c) = o;
+}
+
+// MaxPool2d(2, 2) over NHWC rows (arcface_resnet.py:74).  dy == NULL: out (B, h/2, w/2, c) = window max; else out (B, h, w, c) = dy routed
+// to the FIRST maximal element of each window (row-major), zero elsewhere
+__global__ void maxpool2_kernel(const half_t* x, const half_t* dy, half_t* out, int batch, int h, int w, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = c / 8, ho = h / 2, wo = w / 2;
+    if (idx >= (long)batch * ho * wo * nch) return;
+    const int ch = (int)(idx % nch);
+    const long px = idx / nch;
+    const int j = (int)(px % wo), i = (int)((px / wo) % ho), b = (int)(px / ((long)ho * wo));
+    half8_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const half8_t*>(x + (((size_t)b * h + 2 * i + (t >> 1)) * w + 2 * j + (t & 1)) * c + ch * 8);
+    if (!dy) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)fmaxf(fmaxf((float)v[0][e], (float)v[1][e]), fmaxf((float)v[2][e], (float)v[3][e]));
+        *reinterpret_cast<half8_t*>(out + (size_t)px * c + ch * 8) = o;
+        return;
+    }
+    const half8_t g = *reinterpret_cast<const half8_t*>(dy + (size_t)px * c + ch * 8);
+    half8_t o[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int best = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t) if ((float)v[t][e] > (float)v[best][e]) best = t;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t][e] = t == best ? g[e] : (half_t)0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<half8_t*>(out + (((size_t)b * h + 2 * i + (t >> 1)) * w + 2 * j + (t & 1)) * c + ch * 8) = o[t];
+}
+
+// FaceLoss.preprocess (loss.py:26-36): RGB -> grayscale (0.2989, 0.5870, 0.1140) and F.interpolate(bilinear, align_corners=False) to
+// (S, S), optionally / 127.5 - 1.  x: fp32 NCHW (B, 3, H, W) (channel stride H*W, image stride xs); y: fp32 (B, 1, S, S).
+__device__ __forceinline__ void bilin_taps(int o, int in, int out, int& i0, int& i1, float& w1) {
+    float src = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 < in - 1 ? i0 + 1 : i0;
+    w1 = src - (float)i0;
+}
+__global__ void gray_resize_kernel(const float* x, long xs, float* y, int batch, int h, int w, int S, float mul, float add) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * S * S) return;
+    const int ox = (int)(idx % S), oy = (int)((idx / S) % S), b = (int)(idx / ((long)S * S));
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bilin_taps(oy, h, S, y0, y1, wy);
+    bilin_taps(ox, w, S, x0, x1, wx);
+    const float* p = x + (size_t)b * xs;
+    const long hw = (long)h * w;
+    auto gray = [&](int yy, int xx) { const long o = (long)yy * w + xx; return 0.2989f * p[o] + 0.5870f * p[hw + o] + 0.1140f * p[2 * hw + o]; };
+    const float v = (1.f - wy) * ((1.f - wx) * gray(y0, x0) + wx * gray(y0, x1)) + wy * ((1.f - wx) * gray(y1, x0) + wx * gray(y1, x1));
+    y[idx] = v * mul + add;
+}
+// backward: one thread per INPUT pixel gathers from the output pixels whose two taps per axis include it (deterministic, no atomics)
+__global__ void gray_resize_bwd_kernel(const float* dy, long dys, float* dx, int batch, int h, int w, int S, float mul) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * h * w) return;
+    const int ix = (int)(idx % w), iy = (int)((idx / w) % h), b = (int)(idx / ((long)h * w));
+    const float sy = (float)S / (float)h, sx = (float)S / (float)w;
+    const int oy0 = max(0, (int)floorf(((float)iy - 1.0f + 0.5f) * sy - 0.5f) - 1), oy1 = min(S - 1, (int)ceilf(((float)iy + 1.0f + 0.5f) * sy - 0.5f) + 1);
+    const int ox0 = max(0, (int)floorf(((float)ix - 1.0f + 0.5f) * sx - 0.5f) - 1), ox1 = min(S - 1, (int)ceilf(((float)ix + 1.0f + 0.5f) * sx - 0.5f) + 1);
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        int y0, y1;
+        float wy;
+        bilin_taps(oy, h, S, y0, y1, wy);
+        const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+        if (cy == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            int x0, x1;
+            float wx;
+            bilin_taps(ox, w, S, x0, x1, wx);
+            const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+            if (cx != 0.f) acc += cy * cx * dy[(size_t)b * dys + (size_t)oy * S + ox];
+        }
+    }
+    acc *= mul;
+    const long hw = (long)h * w, o = (long)iy * w + ix;
+    float* d = dx + (size_t)b * 3 * hw;
+    d[o] = 0.2989f * acc;
+    d[hw + o] = 0.5870f * acc;
+    d[2 * hw + o] = 0.1140f * acc;
+}
+
+// torch.nn.CosineEmbeddingLoss (loss.py:17,78; margin 0, mean): target +1: 1 - cos(e1, e2); target -1: max(0, cos).  One wave per sample;
+// per-sample losses to ls[b], de2 = gscale / B * dloss/de2 (fp16).  e1 fp16 (the real image's embedding, no gradient), e2 fp16.
+__global__ void cosine_loss_kernel(const half_t* e1, const half_t* e2, int dim, float target, float gscale, int batch, float* ls, half_t* de2) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const half_t* a = e1 + (size_t)b * dim;
+    const half_t* c = e2 + (size_t)b * dim;
+    float ab = 0.f, aa = 0.f, cc = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float x = (float)a[i], y = (float)c[i];
+        ab += x * y; aa += x * x; cc += y * y;
+    }
+    ab = pv_wave_sum(ab); aa = pv_wave_sum(aa); cc = pv_wave_sum(cc);
+    const float eps = 1e-8f;                        // torch: cos = ab / sqrt((aa + eps) * (cc + eps))
+    const float den = sqrtf((aa + eps) * (cc + eps));
+    const float cs = ab / den;
+    float loss, dcos;
+    if (target > 0.f) { loss = 1.f - cs; dcos = -1.f; }
+    else { loss = cs > 0.f ? cs : 0.f; dcos = cs > 0.f ? 1.f : 0.f; }
+    if (lane == 0) ls[b] = loss;
+    if (de2) {
+        const float k = gscale * dcos / (float)batch;
+        for (int i = lane; i < dim; i += 64) {
+            const float x = (float)a[i], y = (float)c[i];
+            de2[(size_t)b * dim + i] = (half_t)(k * (x / den - cs * y / (cc + eps)));
+        }
+    }
+}
+
+// in-place backward of softmax_rows: dp <- scale * p * (dp - sum_j p_j dp_j) per row (the GEMM-composed attention of the VAE mid block)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const half_t* __restrict__ pm, int ldp, half_t* __restrict__ dp, int lddp, int cols, float scale) {
+    __shared__ float red[4];
+    const half_t* prow = pm + (size_t)blockIdx.x * ldp;
+    half_t* drow = dp + (size_t)blockIdx.x * lddp;
+    const int nch = cols >> 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const half8_t a = *reinterpret_cast<const half8_t*>(prow + ch * 8), g = *reinterpret_cast<const half8_t*>(drow + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)g[j];
+    }
+    s = pv_wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const float dot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const half8_t a = *reinterpret_cast<const half8_t*>(prow + ch * 8), g = *reinterpret_cast<const half8_t*>(drow + ch * 8);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(scale * (float)a[j] * ((float)g[j] - dot));
+        *reinterpret_cast<half8_t*>(drow + ch * 8) = o;
+    }
+}
+
+// out = dy where lo < y < hi, else 0 (gradient of .clamp(lo, hi), infer.py:122)
+__global__ void clamp_mask_kernel(const float* y, const float* dy, float lo, float hi, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (y[i] > lo && y[i] < hi) ? dy[i] : 0.f;
+}
+
 __global__ void add_rows_kernel(const half_t* a, int lda, const half_t* b, int ldb, half_t* out, int ldo, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = cols / 8;
@@ -1091,6 +1275,69 @@ extern "C" int pv_dropout_f16(const void* x, int32_t ldx, void* out, int32_t ldo
     const long total = (long)rows * (cols / 8);
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (half_t*)out, ldo,
                        (const half_t*)add, ldadd, rows, cols, copies, p, reinterpret_cast<const uint32_t*>(rng), (uint32_t)site, backward);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_col_affine_f16(const void* x, int32_t ldx, const float* scale, const float* shift, void* y, int32_t ldy, int32_t rows, int32_t cols, void* stream) {
+    if (!x || !scale || !y || rows <= 0 || cols <= 0 || cols % 8 || (ldx | ldy) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(col_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, scale, shift, (half_t*)y, ldy,
+                       rows, cols);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_prelu_f16(const void* x, int32_t ldx, const void* dy, int32_t lddy, const float* slope, void* out, int32_t ldo, int32_t rows, int32_t cols,
+                            void* stream) {
+    if (!x || !slope || !out || rows <= 0 || cols <= 0 || cols % 8 || (ldx | lddy | ldo) % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(prelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (const half_t*)dy, lddy, slope,
+                       (half_t*)out, ldo, rows, cols);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_maxpool2x2(const void* x, const void* dy, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!x || !out || batch <= 0 || h <= 0 || w <= 0 || (h | w) & 1 || c <= 0 || c % 8) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * (h / 2) * (w / 2) * (c / 8);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, (half_t*)out,
+                       batch, h, w, c);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_gray_resize(const float* x, int64_t x_image_stride, float* y, int32_t batch, int32_t h, int32_t w, int32_t size, float mul, float add,
+                              void* stream) {
+    if (!x || !y || batch <= 0 || h <= 0 || w <= 0 || size <= 0) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * size * size;
+    hipLaunchKernelGGL(gray_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)x_image_stride, y, batch, h, w, size, mul,
+                       add);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_gray_resize_backward(const float* dy, int64_t dy_image_stride, float* dx, int32_t batch, int32_t h, int32_t w, int32_t size, float mul,
+                                       void* stream) {
+    if (!dy || !dx || batch <= 0 || h <= 0 || w <= 0 || size <= 0) return (int)hipErrorInvalidValue;
+    const long total = (long)batch * h * w;
+    hipLaunchKernelGGL(gray_resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (long)dy_image_stride, dx, batch, h, w,
+                       size, mul);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_cosine_embedding_loss(const void* e1, const void* e2, int32_t batch, int32_t dim, float target, float gscale, float* per_sample, void* de2,
+                                        void* stream) {
+    if (!e1 || !e2 || !per_sample || batch <= 0 || dim <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cosine_loss_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, (const half_t*)e1, (const half_t*)e2, dim, target, gscale, batch,
+                       per_sample, (half_t*)de2);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_softmax_rows_backward(const void* p, int32_t ldp, void* dp, int32_t lddp, int32_t rows, int32_t cols, float scale, void* stream) {
+    if (!p || !dp || rows <= 0 || cols <= 0 || cols % 8 || (ldp | lddp) % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const half_t*)p, ldp, (half_t*)dp, lddp, cols, scale);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_clamp_mask_f32(const float* y, const float* dy, float lo, float hi, float* out, int64_t n, void* stream) {
+    if (!y || !dy || !out || n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(clamp_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, lo, hi, out, (long)n);
     return PV_CHECK_LAUNCH();
 }
 

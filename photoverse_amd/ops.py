@@ -282,6 +282,69 @@ class Recorder:
                   copies, float(p), _ptr(rng), int(site), int(backward))
         return out
 
+    # ---- ArcFace identity loss / VAE-decoder backward pieces ----
+    def col_affine(self, x, scale, shift=None):
+        rows, cols = x.shape
+        y = self.empty((rows, cols))
+        self.keep.extend(t for t in (x, scale, shift) if t is not None)
+        self._add(self.lib.pv_col_affine_f16, _ptr(x), _rows(x)[0], _ptr(scale), _ptr(shift), _ptr(y), cols, rows, cols)
+        return y
+
+    def prelu(self, x, slope, dy=None):
+        """dy None: prelu(x); else dy * prelu'(x).  ``slope``: fp32 device scalar (nn.PReLU().weight)."""
+        rows, cols = x.shape
+        out = self.empty((rows, cols))
+        self.keep.extend(t for t in (x, slope, dy) if t is not None)
+        self._add(self.lib.pv_prelu_f16, _ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0] if dy is not None else 0, _ptr(slope), _ptr(out), cols, rows, cols)
+        return out
+
+    def maxpool2x2(self, x, *, batch, h, w, dy=None):
+        c = x.shape[1]
+        assert x.is_contiguous() and (dy is None or dy.is_contiguous())
+        out = self.empty((batch * h * w, c)) if dy is not None else self.empty((batch * (h // 2) * (w // 2), c))
+        self.keep.extend(t for t in (x, dy) if t is not None)
+        self._add(self.lib.pv_maxpool2x2, _ptr(x), _ptr(dy), _ptr(out), batch, h, w, c)
+        return out
+
+    def gray_resize(self, x, *, size, mul=1.0, add=0.0):
+        """fp32 (B, 3, H, W) (images may be strided) -> fp32 (B, 1, size, size): grayscale + bilinear resize (+ affine)."""
+        B, _, H, W = x.shape
+        assert x.dtype == torch.float32 and x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W
+        y = self.empty((B, 1, size, size), torch.float32)
+        self.keep.append(x)
+        self._add(self.lib.pv_gray_resize, _ptr(x), x.stride(0), _ptr(y), B, H, W, size, float(mul), float(add))
+        return y
+
+    def gray_resize_backward(self, dy, *, h, w, mul=1.0):
+        B, _, S, _ = dy.shape
+        assert dy.dtype == torch.float32 and dy.stride(3) == 1 and dy.stride(2) == S
+        dx = self.empty((B, 3, h, w), torch.float32)
+        self.keep.append(dy)
+        self._add(self.lib.pv_gray_resize_backward, _ptr(dy), dy.stride(0), _ptr(dx), B, h, w, S, float(mul))
+        return dx
+
+    def cosine_embedding_loss(self, e1, e2, *, target=1.0, gscale=1.0, want_grad=True):
+        """(per-sample losses fp32 [B], de2 fp16 [B, dim] = gscale * d(mean loss)/d(e2))."""
+        B, dim = e2.shape
+        ls = self.empty((B,), torch.float32)
+        de2 = self.empty((B, dim)) if want_grad else None
+        assert e1.is_contiguous() and e2.is_contiguous() and e1.dtype == torch.float16 and e2.dtype == torch.float16
+        self.keep.extend((e1, e2))
+        self._add(self.lib.pv_cosine_embedding_loss, _ptr(e1), _ptr(e2), B, dim, float(target), float(gscale), _ptr(ls), _ptr(de2))
+        return ls, de2
+
+    def softmax_rows_backward(self, p, dp, *, scale):
+        self.keep.extend((p, dp))
+        self._add(self.lib.pv_softmax_rows_backward, _ptr(p), _rows(p)[0], _ptr(dp), _rows(dp)[0], p.shape[0], p.shape[1], float(scale))
+        return dp
+
+    def clamp_mask(self, y, dy, lo, hi):
+        out = self.empty(tuple(y.shape), torch.float32)
+        assert y.is_contiguous() and dy.is_contiguous()
+        self.keep.extend((y, dy))
+        self._add(self.lib.pv_clamp_mask_f32, _ptr(y), _ptr(dy), float(lo), float(hi), _ptr(out), y.numel())
+        return out
+
     def add_rows(self, a, b, out=None):
         rows, cols = a.shape
         if out is None:

@@ -239,6 +239,45 @@ class Tape:
         self.back.append(bwd)
         return out
 
+    def col_affine(self, x: Var, scale, shift) -> Var:
+        """Per-channel affine (an eval-mode BatchNorm that cannot be folded into a neighbouring conv)."""
+        out = Var(self.rf.col_affine(x.t, scale, shift), x.needs)
+
+        def bwd():
+            if out.g is not None and x.needs:
+                self._accum(x, self.rb.col_affine(out.g, scale, None))
+        self.back.append(bwd)
+        return out
+
+    def prelu(self, x: Var, slope) -> Var:
+        out = Var(self.rf.prelu(x.t, slope), x.needs)
+
+        def bwd():
+            if out.g is not None and x.needs:
+                self._accum(x, self.rb.prelu(x.t, slope, dy=out.g))
+        self.back.append(bwd)
+        return out
+
+    def maxpool2x2(self, x: Var, *, batch, h, w) -> Var:
+        out = Var(self.rf.maxpool2x2(x.t, batch=batch, h=h, w=w), x.needs)
+
+        def bwd():
+            if out.g is not None and x.needs:
+                g = out.g if out.g.is_contiguous() else self.rb.add_rows(out.g, torch.zeros_like(out.t))
+                self._accum(x, self.rb.maxpool2x2(x.t, batch=batch, h=h, w=w, dy=g))
+        self.back.append(bwd)
+        return out
+
+    def reshape(self, x: Var, shape) -> Var:
+        """A contiguous buffer seen with another 2-D shape (NHWC rows -> one row per image for the ArcFace fc5)."""
+        out = Var(x.t.view(shape), x.needs)
+
+        def bwd():
+            if out.g is not None and x.needs:
+                self._accum(x, out.g.view(x.t.shape))
+        self.back.append(bwd)
+        return out
+
     def add_into(self, a: Var, b: Var, dst: torch.Tensor) -> Var:
         """dst (a column slice of a wider buffer) = a + b."""
         self.rf.add_rows(a.t, b.t, out=dst)
