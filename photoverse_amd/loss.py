@@ -140,7 +140,7 @@ class FaceLoss(nn.Module):
             h, w = h // 2, w // 2
         return tp.prelu(y, slope), h, w
 
-    def embed(self, tp: Tape, img: torch.Tensor, *, normalize: bool, want_grad: bool):
+    def embed(self, tp: Tape, img: torch.Tensor, *, normalize: bool, want_grad: bool, unscale: float = 1.0):
         """img: fp32 (B, 3, H, W) buffer (or (B, 1, H, W) gray).  Returns (embedding Var [B, 512] fp16, holder whose ``.g`` becomes the
         fp32 gradient w.r.t. ``img`` when the backward plan is built)."""
         m, S = self.model, self.input_size
@@ -165,7 +165,7 @@ class FaceLoss(nn.Module):
             wdg[0] = w1.flip(2, 3).permute(1, 2, 3, 0)[0]
             assert y.g.is_contiguous()
             dg3 = tp.rb.conv_out(y.g, wdg.reshape(3, -1).to(torch.float16).contiguous(), None, batch=B, cin=128, h=S, wd=S, cout=3)
-            holder.g = tp.rb.gray_resize_backward(dg3[:, :1], h=H, w=W, mul=mul)
+            holder.g = tp.rb.gray_resize_backward(dg3[:, :1], h=H, w=W, mul=mul * unscale)
         tp.back.append(conv1_bwd)
         x = tp.prelu(y, m.prelu.weight.detach().float().contiguous())
         x = tp.maxpool2x2(x, batch=B, h=S, w=S)
@@ -182,11 +182,13 @@ class FaceLoss(nn.Module):
         emb = tp.linear(flat, *tp.frozen(wf), bias=bf)
         return emb, holder
 
-    def attach(self, tp: Tape, img_real: torch.Tensor, img_gen: torch.Tensor, *, weight: float = 1.0, maximize: bool = True, normalize: bool = True):
+    def attach(self, tp: Tape, img_real: torch.Tensor, img_gen: torch.Tensor, *, weight: float = 1.0, maximize: bool = True, normalize: bool = True,
+               unscale: float = 1.0):
         """Hang the loss off ``img_gen`` (a buffer some other part of ``tp``'s forward plan writes).  Returns a namespace: ``loss`` (device
-        scalar, fp32), ``per_sample``, ``dimg`` (holder: ``.g`` = weight * grad_scale * d loss / d img_gen after ``tp.build_backward()``)."""
+        scalar, fp32), ``per_sample``, ``dimg`` (holder: ``.g`` = unscale * weight * grad_scale * d loss / d img_gen after
+        ``tp.build_backward()``; the fp16 gradients in between carry the tape's loss scale)."""
         e1, _ = self.embed(tp, img_real, normalize=normalize, want_grad=False)
-        e2, holder = self.embed(tp, img_gen, normalize=normalize, want_grad=True)
+        e2, holder = self.embed(tp, img_gen, normalize=normalize, want_grad=True, unscale=unscale)
         per_sample, de2 = tp.rf.cosine_embedding_loss(e1.t, e2.t, target=1.0 if maximize else -1.0, gscale=weight * tp.S)
         loss = tp.rf.reduce_mean(per_sample, mode="mean")
 
@@ -197,10 +199,10 @@ class FaceLoss(nn.Module):
 
     # ------------------------------------------------------------------ stand-alone use
     def _plan(self, B, H, W, maximize, normalize):
-        tp = Tape(self.device, 1.0)
+        tp = Tape(self.device, 16384.0)        # image-level gradients are ~1e-7: fp16 storage in between needs the loss scale
         x = tp.rf.hold(torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.device))
         xg = tp.rf.hold(torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.device))
-        out = self.attach(tp, x, xg, maximize=maximize, normalize=normalize)
+        out = self.attach(tp, x, xg, maximize=maximize, normalize=normalize, unscale=1.0 / tp.S)
         tp.build_backward()
         return SimpleNamespace(tape=tp, x=x, xg=xg, out=out)
 

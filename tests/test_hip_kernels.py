@@ -545,3 +545,65 @@ def test_elementwise_backward_pieces(rec_cls):
     assert torch.equal(sg.cpu(), 0.25 * torch.sign(v))
     want_g = torch.stack([0.5 * rows.float().view(4, 77, 768)[b, idx[b]] for b in range(4)]).view(4, 1, 768)
     assert torch.equal(gr.cpu(), want_g)
+
+
+def test_arcface_loss_pieces(rec_cls):
+    """Per-channel affine, PReLU, 2x2 max-pool, gray + bilinear resize (each with its backward), cosine embedding loss, softmax-rows backward,
+    clamp mask - against torch on the same fp16-rounded inputs."""
+    g = torch.Generator().manual_seed(8)
+    rec = rec_cls("cuda")
+    x = torch.randn(2 * 8 * 8, 128, generator=g).half()
+    dy = torch.randn(2 * 8 * 8, 128, generator=g).half()
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    slope = torch.tensor([0.25])
+    ca = rec.col_affine(x.cuda(), sc.cuda(), sh.cuda())
+    cab = rec.col_affine(dy.cuda(), sc.cuda(), None)
+    pr = rec.prelu(x.cuda(), slope.cuda())
+    prb = rec.prelu(x.cuda(), slope.cuda(), dy=dy.cuda())
+    mp = rec.maxpool2x2(x.cuda(), batch=2, h=8, w=8)
+    dmp = torch.randn(2 * 4 * 4, 128, generator=g).half()
+    mpb = rec.maxpool2x2(x.cuda(), batch=2, h=8, w=8, dy=dmp.cuda())
+    imgs, outs = {}, {}
+    for H, W, S in ((24, 24, 32), (64, 48, 16), (32, 32, 32), (100, 100, 128)):
+        img = torch.randn(2, 3, H, W, generator=g)
+        dg = torch.randn(2, 3, S, S, generator=g)               # gradient arrives as channel 0 of a 3-channel buffer (image stride 3 S^2)
+        imgs[(H, W, S)] = (img, dg)
+        outs[(H, W, S)] = (rec.gray_resize(img.cuda(), size=S, mul=0.5, add=-1.0), rec.gray_resize_backward(dg.cuda()[:, :1], h=H, w=W, mul=0.5))
+    e1, e2 = torch.randn(3, 512, generator=g).half(), torch.randn(3, 512, generator=g).half()
+    ls_p, de_p = rec.cosine_embedding_loss(e1.cuda(), e2.cuda(), target=1.0, gscale=4.0)
+    ls_n, de_n = rec.cosine_embedding_loss(e1.cuda(), (e1 + 0.5 * e2).half().cuda(), target=-1.0, gscale=1.0)
+    P = torch.softmax(torch.randn(16, 256, generator=g), -1).half()
+    dP = torch.randn(16, 256, generator=g).half()
+    dS = rec.softmax_rows_backward(P.cuda(), dP.clone().cuda(), scale=0.3)
+    yv, dyv = torch.randn(1000, generator=g) * 1.5, torch.randn(1000, generator=g)
+    cm = rec.clamp_mask(yv.cuda(), dyv.cuda(), -1.0, 1.0)
+    rec.run()
+    torch.cuda.synchronize()
+    xf = x.float()
+    assert rel_l2(ca, xf * sc + sh) < 1e-3 and rel_l2(cab, dy.float() * sc) < 1e-3
+    assert rel_l2(pr, torch.where(xf > 0, xf, 0.25 * xf)) < 1e-3 and rel_l2(prb, dy.float() * torch.where(xf > 0, 1.0, 0.25)) < 1e-3
+    xr = xf.view(2, 8, 8, 128).permute(0, 3, 1, 2).clone().requires_grad_()
+    pooled = F.max_pool2d(xr, 2, 2)
+    pooled.backward(dmp.float().view(2, 4, 4, 128).permute(0, 3, 1, 2))
+    assert torch.equal(mp.float().cpu().view(2, 4, 4, 128), pooled.detach().permute(0, 2, 3, 1))
+    assert rel_l2(mpb.float().cpu().view(2, 8, 8, 128), xr.grad.permute(0, 2, 3, 1)) < 1e-6
+    wts = torch.tensor([0.2989, 0.5870, 0.1140])
+    for (H, W, S), (img, dg) in imgs.items():
+        ir = img.clone().requires_grad_()
+        gray = torch.tensordot(ir, wts, dims=([1], [0])).unsqueeze(1)
+        ref = F.interpolate(gray, size=(S, S), mode="bilinear", align_corners=False) * 0.5 - 1.0
+        ref.backward(dg[:, :1])
+        got, gotb = outs[(H, W, S)]
+        assert rel_l2(got, ref.detach()) < 1e-5, (H, W, S)
+        assert rel_l2(gotb, ir.grad) < 1e-5, (H, W, S)
+    e2r = e2.float().requires_grad_()
+    lp = torch.nn.CosineEmbeddingLoss()(e1.float(), e2r, torch.ones(3))
+    lp.backward()
+    assert ls_p.mean().item() == pytest.approx(lp.item(), rel=1e-4) and rel_l2(de_p, 4.0 * e2r.grad) < 2e-3
+    e3 = (e1 + 0.5 * e2).half().float().requires_grad_()
+    ln = torch.nn.CosineEmbeddingLoss()(e1.float(), e3, -torch.ones(3))
+    ln.backward()
+    assert ls_n.mean().item() == pytest.approx(ln.item(), rel=1e-4) and rel_l2(de_n, e3.grad) < 2e-3
+    Pf, dPf = P.float(), dP.float()
+    assert rel_l2(dS, 0.3 * Pf * (dPf - (Pf * dPf).sum(-1, keepdim=True))) < 2e-3
+    assert torch.equal(cm.cpu(), torch.where((yv > -1) & (yv < 1), dyv, torch.zeros(())))
