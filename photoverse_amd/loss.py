@@ -140,7 +140,7 @@ class FaceLoss(nn.Module):
             h, w = h // 2, w // 2
         return tp.prelu(y, slope), h, w
 
-    def embed(self, tp: Tape, img: torch.Tensor, *, normalize: bool, want_grad: bool, unscale: float = 1.0):
+    def embed(self, tp: Tape, img: torch.Tensor, *, normalize: bool, want_grad: bool, unscale: float = 1.0, holder=None):
         """img: fp32 (B, 3, H, W) buffer (or (B, 1, H, W) gray).  Returns (embedding Var [B, 512] fp16, holder whose ``.g`` becomes the
         fp32 gradient w.r.t. ``img`` when the backward plan is built)."""
         m, S = self.model, self.input_size
@@ -153,7 +153,7 @@ class FaceLoss(nn.Module):
         w1, b1 = _fold(m.conv1.weight, m.bn1, 128, 1)                                          # [128, 1, 3, 3]
         w1c = torch.zeros(128, 64, dtype=torch.float16, device=img.device)
         w1c[:, :9] = w1.reshape(128, 9).to(torch.float16)
-        holder = SimpleNamespace(g=None)
+        holder = holder if holder is not None else SimpleNamespace(g=None)
         y = tp.linear(Var(cols, False), w1c, w1c.t().contiguous(), bias=b1, rows_per_image=S * S)
         y.needs = want_grad
 
@@ -183,12 +183,13 @@ class FaceLoss(nn.Module):
         return emb, holder
 
     def attach(self, tp: Tape, img_real: torch.Tensor, img_gen: torch.Tensor, *, weight: float = 1.0, maximize: bool = True, normalize: bool = True,
-               unscale: float = 1.0):
+               unscale: float = 1.0, holder=None):
         """Hang the loss off ``img_gen`` (a buffer some other part of ``tp``'s forward plan writes).  Returns a namespace: ``loss`` (device
         scalar, fp32), ``per_sample``, ``dimg`` (holder: ``.g`` = unscale * weight * grad_scale * d loss / d img_gen after
-        ``tp.build_backward()``; the fp16 gradients in between carry the tape's loss scale)."""
+        ``tp.build_backward()``; the fp16 gradients in between carry the tape's loss scale).  ``holder``: write that gradient into an existing
+        holder instead (e.g. ``vae_train.decode_on_tape(...).dimg``, chaining the decoder's backward behind the loss)."""
         e1, _ = self.embed(tp, img_real, normalize=normalize, want_grad=False)
-        e2, holder = self.embed(tp, img_gen, normalize=normalize, want_grad=True, unscale=unscale)
+        e2, holder = self.embed(tp, img_gen, normalize=normalize, want_grad=True, unscale=unscale, holder=holder)
         per_sample, de2 = tp.rf.cosine_embedding_loss(e1.t, e2.t, target=1.0 if maximize else -1.0, gscale=weight * tp.S)
         loss = tp.rf.reduce_mean(per_sample, mode="mean")
 

@@ -180,3 +180,47 @@ def test_full_size_vae_decode_matches_oracle():
     err = rel_l2(got, exp)
     print(f"full-size VAE decode rel-L2 vs fp32 oracle: {err:.3e}")
     assert got.shape == (1, 3, 512, 512) and err < 5e-3
+
+
+@pytest.mark.gpu
+def test_decoder_data_gradient_on_the_training_tape():
+    """vae_train.decode_on_tape: forward = AutoencoderKL.decode + clamp(-1, 1) (infer.py:121-123), backward = d<R, image>/dz against torch
+    autograd over the oracle decoder (GroupNorm / conv / GEMM-composed mid-block attention / upsampling / conv_out / clamp mask)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from oracle.vae_ref import AutoencoderKLDecoderRef
+    from photoverse_amd.tape import Tape
+    from photoverse_amd.vae import AutoencoderKL
+    from photoverse_amd.vae_train import decode_on_tape
+    cfg = dict(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
+    torch.manual_seed(3)
+    ref = AutoencoderKLDecoderRef(**cfg).eval()
+    vae = AutoencoderKL(**cfg)
+    vae.load_state_dict(ref.state_dict(), strict=False)
+    vae.to("cuda")
+    g = torch.Generator().manual_seed(4)
+    B, h = 2, 16
+    z = torch.randn(B, 4, h, h, generator=g) * 3.0          # large latents: part of the image saturates the clamp
+    R = torch.randn(B, 3, 8 * h, 8 * h, generator=g)
+    S = 256.0
+    tp = Tape("cuda", S)
+    zbuf = tp.rf.hold(z.cuda())
+    dec = decode_on_tape(tp, vae, zbuf)
+    seed = tp.rb.hold((R * S).cuda())
+
+    def set_seed():
+        dec.dimg.g = seed
+    tp.back.append(set_seed)
+    tp.build_backward()
+    tp.rf.run()
+    tp.rb.run()
+    torch.cuda.synchronize()
+    zr = z.clone().requires_grad_()
+    img = ref.decode(zr).sample.clamp(-1, 1)
+    (img * R).sum().backward()
+    sat = (img.detach().abs() >= 1).float().mean().item()
+    err_img, err_g = rel_l2(dec.img, img.detach()), rel_l2(dec.dz.g / S, zr.grad)
+    print(f"decoder on tape: image rel-L2 {err_img:.3e}, dz rel-L2 {err_g:.3e}, clamped fraction {sat:.3f}")
+    assert 0.01 < sat < 0.9
+    assert err_img < 5e-3
+    assert err_g < 2e-2
