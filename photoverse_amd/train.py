@@ -118,6 +118,7 @@ def training_step_forward(batch, tokenizer, image_encoder, text_encoder, unet, t
 # ======================================================================================================================
 # The full step: forward + backward as two static launch plans (tape.py), AdamW on the device (optim.py)
 # ======================================================================================================================
+from types import SimpleNamespace  # noqa: E402
 from typing import Dict, List  # noqa: E402
 
 from . import ops as _ops  # noqa: E402
@@ -142,9 +143,16 @@ class TrainStep:
 
     def __init__(self, unet, text_encoder, text_adapter, image_adapter, *, batch: int, h: int, w: int, n_tokens: int, seq: int = 77,
                  clip_tokens: int = 257, clip_dim: int = 1024, grad_scale: float = 4096.0, fusion_seed: int = 0,
-                 loss_weights=(1.0, 0.01, 0.001), use_graph: bool = True):
+                 loss_weights=(1.0, 0.01, 0.001), use_graph: bool = True, face_loss=None, vae=None, noise_scheduler=None,
+                 face_samples: Optional[int] = None, face_weight: float = 0.01, guidance_scale: float = 2.0, infer_steps: int = 10,
+                 image_size: Optional[int] = None):
+        """``face_loss`` (a ``loss.FaceLoss``) + ``vae`` switch on the identity-loss branch of train.py:521-535: for ``face_samples``
+        images of the batch (default ``max(int(0.25 * batch), 1)``, train.py:247,522) ``run_inference(from_noised_image=True,
+        training_mode=True, timesteps=infer_steps, guidance_scale=..., token_index=0)`` is replayed - the first ``infer_steps - 1``
+        denoising steps without gradient, the last one, the VAE decode and the ArcFace trunk inside the differentiated plan."""
         dev = unet.device
         self.use_graph, self.graph, self._warm = bool(use_graph), None, False
+        self.face_loss, self.vae, self.face = face_loss, vae, None
         self.unet, self.text_encoder, self.text_adapter, self.image_adapter = unet, text_encoder, text_adapter, image_adapter
         self.B, self.H, self.W, self.E, self.S_len = batch, h, w, n_tokens, seq
         self.grad_scale = float(grad_scale)
@@ -161,7 +169,13 @@ class TrainStep:
         self.pidx = rf.hold(torch.zeros((batch,), dtype=torch.int64, device=dev))
         self.pidx32 = rf.hold(torch.zeros((batch,), dtype=torch.int32, device=dev))
         self.embs = [rf.hold(torch.zeros((batch, clip_tokens, clip_dim), dtype=torch.float16, device=dev)) for _ in range(n_tokens)]
+        self.t_state = None                               # per-sample timesteps (a loop pass reads one timestep through a step counter)
         self._build(fusion_seed)
+        if face_loss is not None:
+            if vae is None:
+                raise ValueError("the face-loss branch needs the VAE (run_inference decodes the generated latents, infer.py:121-123)")
+            self._build_face(face_samples if face_samples is not None else max(int(0.25 * batch), 1), float(face_weight), float(guidance_scale),
+                             int(infer_steps), noise_scheduler, fusion_seed, clip_tokens, clip_dim, image_size or 8 * h)
 
     # ------------------------------------------------------------------ parameter-gradient sinks
     def _to(self, param):
@@ -190,12 +204,15 @@ class TrainStep:
                           mean_group=group)
         return lin(6, a4)
 
-    def _adapter(self, adapter) -> Var:
+    def _adapter(self, adapter, embs=None) -> Var:
+        """Tokens 0 .. len(embs)-1 of the adapter (adapters.py:30-44: all of them in the training forward, token_index=0 alone inside
+        run_inference)."""
         tp, B = self.tape, self.B
+        embs = self.embs if embs is None else embs
         cout = getattr(adapter, "mapping_0")[6].out_features
-        whole = tp.rf.empty((B, self.E * cout))
+        whole = tp.rf.empty((B, len(embs) * cout))
         parts = []
-        for i, emb in enumerate(self.embs):
+        for i, emb in enumerate(embs):
             T, D = emb.shape[1], emb.shape[2]
             cls = self._mlp(getattr(adapter, f"mapping_{i}"), Var(emb.view(B, T * D)[:, :D]), 1)
             pat = self._mlp(getattr(adapter, f"mapping_patch_{i}"), Var(emb.view(B * T, D)), T)
@@ -211,11 +228,12 @@ class TrainStep:
         x0 = tp.rf.clip_text_embed(self.ids, _f32(tm.embeddings.token_embedding.weight), _f32(tm.embeddings.position_embedding.weight),
                                    concept.t.view(B * E, dim), self.pidx, n_concept=E, batch=B, seq=S, dim=dim)
         x = Var(x0, True)
+        pidx32 = self.pidx32
 
         def embed_bwd(x=x):
             if x.g is None:
                 return
-            g32 = tp.rb.gather_rows(x.g, self.pidx32, batch=B, seq=S, n_e=E)
+            g32 = tp.rb.gather_rows(x.g, pidx32, batch=B, seq=S, n_e=E)
             tp._accum(concept, tp.rb.cast_to_f16(g32.view(B, E * dim)))
         tp.back.append(embed_bwd)
         for lyr in tm.encoder.layers:
@@ -238,7 +256,7 @@ class TrainStep:
         cout = m.conv1.out_channels
         hn = tp.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=B, hw=h * w, x1=x1, eps=m.norm1.eps, act=_ops.ACT_SILU)
         h1 = tp.conv3(hn, _conv3_w(m.conv1.weight), conv3_dgrad_weight(m.conv1.weight), bias=_f32(m.conv1.bias), batch=B, h=h, w=w,
-                      rowadd=temb_all[:, toff:toff + cout], rowadd_ld=temb_all.stride(0))
+                      rowadd=temb_all[:, toff:toff + cout], rowadd_ld=temb_all.stride(0) if temb_all.shape[0] > 1 else 0)
         h2 = tp.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=B, hw=h * w, eps=m.norm2.eps, act=_ops.ACT_SILU)
         if m.conv_shortcut is not None:
             sc = tp.linear(x, *tp.frozen(_conv1_w(m.conv_shortcut.weight)), bias=_f32(m.conv_shortcut.bias), x1=x1, rows_per_image=h * w)
@@ -329,7 +347,7 @@ class TrainStep:
         n2 = tp.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
         lk = a2.to_k if isinstance(a2.to_k, LoRALinear) else None
         lv = a2.to_v if isinstance(a2.to_v, LoRALinear) else None
-        site = 4 * len(self.fusion_names)                 # dropout stream ids of this layer: site (q), site + 1 (k and v: copies 0 / 1)
+        site = self.site_base + 4 * len(self.fusion_names)   # dropout stream ids of this layer: site (q), site + 1 (k and v: copies 0 / 1)
         if isinstance(a2.to_q, LoRALinear) and a2.to_q.dropout_p > 0:
             q = self._lora_branch(n2, [a2.to_q], site, rows_per_image=n)
         else:
@@ -355,10 +373,10 @@ class TrainStep:
         kvip = tp.linear(ip, wkvip, wkvipT, rows_per_image=self.E, on_wgrad=ip_sink)
         vnorm = tp.rf.empty((B, heads, self.E), torch.float32)
         self.vnorms[name] = vnorm
-        fus = self.fusion_tab[len(self.fusion_names)]
+        fus = self.fusion_tab[len(self.fusion_names)] if self.fusion_tab is not None else None     # None: (1, 1), the no_grad rule (:411-412)
         self.fusion_names.append(name)
         xa = tp.cross_attention(q, kvt, kvip, batch=B, heads=heads, n=n, nt=self.S_len, nip=self.E, d=d, fusion=fus, vnorm=vnorm,
-                                vnorm_coef=self.loss_weights[2] * self.grad_scale / (self.n_xattn * B * heads * self.E))
+                                vnorm_coef=self.vnorm_weight * self.grad_scale / (self.n_xattn * B * heads * self.E))
         hs = tp.linear(xa, *tp.frozen(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         # GEGLU feed-forward (pre-activation kept for the backward)
         n3 = tp.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
@@ -368,6 +386,80 @@ class TrainStep:
         return tp.linear(hs, *tp.frozen(_conv1_w(m.proj_out.weight)), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n, colstats=True)
 
     # ------------------------------------------------------------------ the plan
+    def _unet_pass(self, noisy: torch.Tensor, text: Var, ip_rows: Var):
+        """One UNet forward on the current tape (``noisy``: fp32 (B, 4, h, w) buffer; timesteps from ``self.timesteps`` or, in a loop pass,
+        from ``self.t_state``).  Returns (noise_pred fp32 NCHW, seed): ``seed(dpred)`` - called while the backward plan is built -
+        turns the fp32 gradient of the prediction into the gradient of conv_out's input.  No gradient is computed upstream of the first
+        cross-attention layer."""
+        tp, u, B = self.tape, self.unet, self.B
+        rf, rb = tp.rf, tp.rb
+        dev = tp.device
+        cfg = u.config
+        h, w = self.H, self.W
+        c0 = cfg.block_out_channels[0]
+        if self.t_state is not None:                      # a loop pass: one timestep for all rows, read through the device step counter
+            te = rf.timestep_embedding(self.t_state[0], self.t_state[1], 1, c0)
+        else:
+            te = rf.timestep_embedding(self.timesteps, None, B, c0)
+        e1 = rf.gemm(te, _f16(u.time_embedding.linear_1.weight), bias=_f32(u.time_embedding.linear_1.bias), act=_ops.ACT_SILU)
+        e2 = rf.gemm(e1, _f16(u.time_embedding.linear_2.weight), bias=_f32(u.time_embedding.linear_2.bias), act=_ops.ACT_SILU)
+        resnets = [m for m in u.modules() if isinstance(m, ResnetBlock2D)]
+        toffs, off = {}, 0
+        for m in resnets:
+            toffs[id(m)] = off
+            off += m.conv1.out_channels
+        pad = (-off) % 160
+        wt = torch.cat([_f16(m.time_emb_proj.weight) for m in resnets] +
+                       ([torch.zeros(pad, resnets[0].time_emb_proj.in_features, dtype=torch.float16, device=dev)] if pad else []), 0)
+        bt = torch.cat([_f32(m.time_emb_proj.bias) for m in resnets] + ([torch.zeros(pad, device=dev)] if pad else []), 0)
+        temb_all = rf.gemm(e2, wt.contiguous(), bias=bt.contiguous(), out_f32=True)
+        kin = cfg.in_channels * 9
+        kpad = (kin + 63) // 64 * 64
+        cols = rf.im2col3x3(noisy, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
+        w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=dev)
+        w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
+        x = Var(rf.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True), False)
+        skips = [(x, h, w)]
+        for bi, blk in enumerate(u.down_blocks):
+            for i, res in enumerate(blk.resnets):
+                x = self._resnet(res, x, None, h, w, temb_all, toffs[id(res)])
+                if blk.has_attn:
+                    x = self._transformer(f"down_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
+                skips.append((x, h, w))
+            if blk.downsamplers is not None:
+                conv = blk.downsamplers[0].conv
+                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, stride=2)
+                h, w = h // 2, w // 2
+                skips.append((x, h, w))
+        mb = u.mid_block
+        x = self._resnet(mb.resnets[0], x, None, h, w, temb_all, toffs[id(mb.resnets[0])])
+        x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, h, w, text, ip_rows)
+        x = self._resnet(mb.resnets[1], x, None, h, w, temb_all, toffs[id(mb.resnets[1])])
+        for bi, blk in enumerate(u.up_blocks):
+            for i, res in enumerate(blk.resnets):
+                sk, sh, sw = skips.pop()
+                assert (sh, sw) == (h, w)
+                x = self._resnet(res, x, sk, h, w, temb_all, toffs[id(res)])
+                if blk.has_attn:
+                    x = self._transformer(f"up_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
+            if blk.upsamplers is not None:
+                conv = blk.upsamplers[0].conv
+                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, upsample=1)
+                h, w = h * 2, w * 2
+        xn = tp.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w, eps=u.conv_norm_out.eps, act=_ops.ACT_SILU)
+        wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
+        noise_pred = rf.conv_out(xn.t, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels)
+
+
+        def seed(dpred):
+            oc = cfg.out_channels
+            kp = (oc * 9 + 63) // 64 * 64
+            dcols = rb.im2col3x3(dpred, batch=B, cin=oc, h=h, wd=w, kpad=kp)
+            wd_out = torch.zeros(c0, kp, dtype=torch.float16, device=dev)
+            wd_out[:, :oc * 9] = u.conv_out.weight.detach().flip(2, 3).permute(1, 0, 2, 3).reshape(c0, oc * 9).to(torch.float16)
+            xn.g = rb.gemm(dcols, wd_out, rows_per_image=h * w)
+        return noise_pred, seed
+
     def _build(self, fusion_seed: int):
         import numpy as np
         from .attention_processor import PhotoVerseAttnProcessor2_0
@@ -382,6 +474,7 @@ class TrainStep:
         self.fusion_names: List[str] = []
         self.lora_pending: List[tuple] = []
         self.dropout_sites: List[tuple] = []              # (site, copies, cols, p) of every LoRA dropout launch (tests rebuild the masks)
+        self.site_base, self.vnorm_weight = 0, self.loss_weights[2]
         procs = [m.processor for _, m in u.named_modules() if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0)]
         self.n_xattn = len(procs)
         # grad-mode branch fusion, one device-side draw per forward (attention_processor.py:413-420; pv_fusion_draw)
@@ -416,56 +509,7 @@ class TrainStep:
         tp.back.append(ip_rows_bwd)
         self.text_states, self.ip_states = text, ip_rows
 
-        # --- UNet forward (no gradient needed upstream of the first cross-attention layer)
-        te = rf.timestep_embedding(self.timesteps, None, B, c0)
-        e1 = rf.gemm(te, _f16(u.time_embedding.linear_1.weight), bias=_f32(u.time_embedding.linear_1.bias), act=_ops.ACT_SILU)
-        e2 = rf.gemm(e1, _f16(u.time_embedding.linear_2.weight), bias=_f32(u.time_embedding.linear_2.bias), act=_ops.ACT_SILU)
-        resnets = [m for m in u.modules() if isinstance(m, ResnetBlock2D)]
-        toffs, off = {}, 0
-        for m in resnets:
-            toffs[id(m)] = off
-            off += m.conv1.out_channels
-        pad = (-off) % 160
-        wt = torch.cat([_f16(m.time_emb_proj.weight) for m in resnets] +
-                       ([torch.zeros(pad, resnets[0].time_emb_proj.in_features, dtype=torch.float16, device=dev)] if pad else []), 0)
-        bt = torch.cat([_f32(m.time_emb_proj.bias) for m in resnets] + ([torch.zeros(pad, device=dev)] if pad else []), 0)
-        temb_all = rf.gemm(e2, wt.contiguous(), bias=bt.contiguous(), out_f32=True)
-        kin = cfg.in_channels * 9
-        kpad = (kin + 63) // 64 * 64
-        cols = rf.im2col3x3(self.noisy, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
-        w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=dev)
-        w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
-        x = Var(rf.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True), False)
-        skips = [(x, h, w)]
-        for bi, blk in enumerate(u.down_blocks):
-            for i, res in enumerate(blk.resnets):
-                x = self._resnet(res, x, None, h, w, temb_all, toffs[id(res)])
-                if blk.has_attn:
-                    x = self._transformer(f"down_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
-                skips.append((x, h, w))
-            if blk.downsamplers is not None:
-                conv = blk.downsamplers[0].conv
-                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, stride=2)
-                h, w = h // 2, w // 2
-                skips.append((x, h, w))
-        mb = u.mid_block
-        x = self._resnet(mb.resnets[0], x, None, h, w, temb_all, toffs[id(mb.resnets[0])])
-        x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, h, w, text, ip_rows)
-        x = self._resnet(mb.resnets[1], x, None, h, w, temb_all, toffs[id(mb.resnets[1])])
-        for bi, blk in enumerate(u.up_blocks):
-            for i, res in enumerate(blk.resnets):
-                sk, sh, sw = skips.pop()
-                assert (sh, sw) == (h, w)
-                x = self._resnet(res, x, sk, h, w, temb_all, toffs[id(res)])
-                if blk.has_attn:
-                    x = self._transformer(f"up_blocks.{bi}.attentions.{i}", blk.attentions[i], x, h, w, text, ip_rows)
-            if blk.upsamplers is not None:
-                conv = blk.upsamplers[0].conv
-                x = tp.conv3(x, _conv3_w(conv.weight), conv3_dgrad_weight(conv.weight), bias=_f32(conv.bias), batch=B, h=h, w=w, upsample=1)
-                h, w = h * 2, w * 2
-        xn = tp.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w, eps=u.conv_norm_out.eps, act=_ops.ACT_SILU)
-        wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
-        self.noise_pred = rf.conv_out(xn.t, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels)
+        self.noise_pred, seed_pred = self._unet_pass(self.noisy, text, ip_rows)
 
         # --- losses (train.py:509-516, :536): values in the forward plan, gradient seeds at the head of the backward plan
         rf.reduce_mean(self.noise_pred, self.noise, mode="mse", out=self.terms[0:1])
@@ -481,15 +525,157 @@ class TrainStep:
             npix = self.noise_pred.numel()
             ca = rb.hold(torch.full((1,), 2.0 * self.loss_weights[0] * self.grad_scale / npix, dtype=torch.float32, device=dev))
             cb = rb.hold(torch.full((1,), -2.0 * self.loss_weights[0] * self.grad_scale / npix, dtype=torch.float32, device=dev))
-            dpred = rb.affine_rows(self.noise_pred.view(1, -1), ca, self.noise.view(1, -1), cb).view(self.noise_pred.shape)
-            oc = cfg.out_channels
-            kp = (oc * 9 + 63) // 64 * 64
-            dcols = rb.im2col3x3(dpred, batch=B, cin=oc, h=h, wd=w, kpad=kp)
-            wd_out = torch.zeros(c0, kp, dtype=torch.float16, device=dev)
-            wd_out[:, :oc * 9] = u.conv_out.weight.detach().flip(2, 3).permute(1, 0, 2, 3).reshape(c0, oc * 9).to(torch.float16)
-            xn.g = rb.gemm(dcols, wd_out, rows_per_image=h * w)
+            seed_pred(rb.affine_rows(self.noise_pred.view(1, -1), ca, self.noise.view(1, -1), cb).view(self.noise_pred.shape))
         tp.back.append(seed)
         tp.build_backward()
+
+
+    # ------------------------------------------------------------------ the identity-loss branch (train.py:521-535)
+    _PASS_FIELDS = ("tape", "B", "E", "embs", "ids", "pidx", "pidx32", "timesteps", "t_state", "fusion_tab", "fusion_names", "vnorms",
+                    "site_base", "vnorm_weight", "fusion_rng")
+
+    def _enter(self, **kw):
+        for k, v in kw.items():
+            assert k in self._PASS_FIELDS, k
+            setattr(self, k, v)
+
+    def _snapshot(self):
+        return {k: getattr(self, k) for k in self._PASS_FIELDS}
+
+    def _build_face(self, ns, weight, guidance, T, noise_scheduler, fusion_seed, clip_tokens, clip_dim, image_size):
+        """run_inference(sliced_batch, ..., guidance_scale, timesteps=T, token_index=0, from_noised_image=True, training_mode=True)
+        (infer.py:7-123) + face_loss(pixel_values, gen_images, normalize=False) (loss.py:64-78) for ``ns`` samples:
+
+            A  conditioning WITH gradient: text_adapter / image_adapter token 0, injected text encoder         (one recorder)
+            L  one denoising step without gradient: uncond + cond UNet forward, CFG + DPM-Solver++ update       (replayed T - 1 times)
+            B  the last step with gradient: both forwards (per-layer fusion drawn on the device), the update,
+               latents / scaling_factor -> VAE decode -> clamp -> ArcFace loss                                   (one recorder)
+            backward of B and A in one plan.
+
+        All UNet passes share the master weights (re-packed per step); the passes of L run the training-mode LoRA path (dropout active,
+        like peft under set_cross_attention_layers_to_train) with the (1, 1) fusion of the no_grad rule."""
+        import numpy as np
+        from .attention_processor import PhotoVerseAttnProcessor2_0
+        from .ops import Recorder
+        from .scheduler import DPMSolverMultistepScheduler
+        from .unet import Attention
+        from .vae_train import decode_on_tape
+        u, dev = self.unet, self.unet.device
+        cfg = u.config
+        h, w, seq = self.H, self.W, self.S_len
+        main = self._snapshot()
+        f = self.face = SimpleNamespace(ns=ns, weight=weight, guidance=guidance, T=T)
+        sch = DPMSolverMultistepScheduler.from_config(noise_scheduler.config) if noise_scheduler is not None else DPMSolverMultistepScheduler()
+        sch.set_timesteps(T)
+        f.scheduler = sch
+        coef_host = sch.coefficient_table()
+        ft = f.tape = Tape(dev, self.grad_scale)
+        hold = ft.rf.hold
+        z32 = lambda *shape: hold(torch.zeros(shape, dtype=torch.float32, device=dev))
+        f.lat, f.x0_prev = z32(ns, cfg.in_channels, h, w), z32(ns, cfg.in_channels, h, w)
+        f.state = hold(torch.tensor([0, T, 0, 0], dtype=torch.int32, device=dev))
+        f.coef = hold(coef_host.to(dev))
+        f.ts = hold(sch.timesteps.to(dev, torch.float32))
+        f.t_last = hold(torch.full((ns,), float(sch.timesteps[-1]), dtype=torch.float32, device=dev))
+        f.embs_c = [hold(torch.zeros((ns, clip_tokens, clip_dim), dtype=torch.float16, device=dev))]
+        f.embs_u = [hold(torch.zeros((ns, clip_tokens, clip_dim), dtype=torch.float16, device=dev))]
+        f.ids = hold(torch.zeros((ns, seq), dtype=torch.int64, device=dev))
+        f.pidx = hold(torch.zeros((ns,), dtype=torch.int64, device=dev))
+        f.pidx32 = hold(torch.zeros((ns,), dtype=torch.int32, device=dev))
+        f.text_u = hold(torch.zeros((ns * seq, cfg.cross_attention_dim), dtype=torch.float16, device=dev))
+        f.real = z32(ns, 3, image_size, image_size)
+        key = np.array([(fusion_seed + 0x51ED) & 0xFFFFFFFF, 0x2545F491, 0, 0], dtype=np.uint32).view(np.int32)
+        rng = hold(torch.from_numpy(key.copy()).to(dev))
+        procs = [m.processor for _, m in u.named_modules() if isinstance(m, Attention) and isinstance(m.processor, PhotoVerseAttnProcessor2_0)]
+        nl = len(procs)
+
+        # ---- A: conditioning with gradient (infer.py:86-96, token_index = 0)
+        f.rec_cond = ft.rf
+        self._enter(tape=ft, B=ns, E=1, embs=f.embs_c, ids=f.ids, pidx=f.pidx, pidx32=f.pidx32, timesteps=f.t_last, t_state=None, fusion_tab=None,
+                    fusion_names=[], vnorms={}, site_base=1000, vnorm_weight=0.0, fusion_rng=rng)
+        concept = self._adapter(self.text_adapter, f.embs_c)
+        text_c = self._text(concept)
+        ip_c = self._adapter(self.image_adapter, f.embs_c)
+        ip_u = self._adapter(self.image_adapter, f.embs_u)
+        text_u = Var(f.text_u, False)
+
+        # ---- L: one denoising step without gradient, replayed T - 1 times (infer.py:98-119 under set_grad_enabled(False))
+        tl = f.loop_tape = Tape(dev, 1.0)
+        self._enter(tape=tl, t_state=(f.ts, f.state), fusion_names=[], site_base=2000)
+        eps_u, _ = self._unet_pass(f.lat, text_u, Var(ip_u.t, False))
+        self._enter(fusion_names=[], site_base=2500, vnorms={})
+        eps_c, _ = self._unet_pass(f.lat, Var(text_c.t, False), Var(ip_c.t, False))
+        tl.rf.cfg_dpm_step(eps_u, eps_c, f.lat, f.x0_prev, f.coef, f.state, guidance)
+        tl.rf.step_advance(f.state)
+        tl.back = []
+
+        # ---- B: the last step, in grad mode (infer.py:99), decode, loss
+        f.rec_last = ft.rf = Recorder(dev)
+        rf = ft.rf
+        p0 = procs[0]
+        f.fusion_tabs, f.fusion_forced = [], []
+        for _ in range(2):
+            tab = rf.hold(torch.ones((nl, 2), dtype=torch.float32, device=dev))
+            forced = rf.hold(torch.full((nl,), -1.0, dtype=torch.float32, device=dev))
+            rf.fusion_draw(None, rng, forced, tab, n_layers=nl, rule1=p0.fusion_rule1, rule2=p0.fusion_rule2, scale=float(p0.scale[0]), only_last_step=False)
+            f.fusion_tabs.append(tab)
+            f.fusion_forced.append(forced)
+        self._enter(tape=ft, t_state=None, fusion_tab=f.fusion_tabs[0], fusion_names=[], site_base=3000, vnorms={})
+        eps_u, seed_u = self._unet_pass(f.lat, text_u, ip_u)
+        self._enter(fusion_tab=f.fusion_tabs[1], fusion_names=[], site_base=3500, vnorms={})
+        eps_c, seed_c = self._unet_pass(f.lat, text_c, ip_c)
+        f.fusion_names = list(self.fusion_names)
+        rf.cfg_dpm_step(eps_u, eps_c, f.lat, f.x0_prev, f.coef, f.state, guidance)            # state[0] = T - 1 here: the final, first-order row
+        sf = float(self.vae.config.scaling_factor)
+        z = rf.affine_rows(f.lat.view(1, -1), rf.hold(torch.full((1,), 1.0 / sf, dtype=torch.float32, device=dev))).view(ns, cfg.in_channels, h, w)
+        row = coef_host[T - 1]
+        d_eps = float(row[3] * row[1])                     # d latents_final / d eps = c0 * cb   (x' = cx x + c0 (ca x + cb eps))
+        rb = ft.rb
+
+        def seeds():
+            dz = dec.dz.g
+            if dz is None:
+                return
+            cc = rb.hold(torch.full((1,), guidance * d_eps / sf, dtype=torch.float32, device=dev))
+            seed_c(rb.affine_rows(dz.reshape(1, -1), cc).view(dz.shape))
+            if guidance != 1.0:
+                cu = rb.hold(torch.full((1,), (1.0 - guidance) * d_eps / sf, dtype=torch.float32, device=dev))
+                seed_u(rb.affine_rows(dz.reshape(1, -1), cu).view(dz.shape))
+        ft.back.append(seeds)
+        dec = decode_on_tape(ft, self.vae, z)
+        fl = self.face_loss.attach(ft, f.real, dec.img, weight=weight, maximize=True, normalize=False, holder=dec.dimg)
+        f.loss, f.images = fl.loss, dec.img
+        ft.build_backward()
+        self._enter(**main)
+
+    @torch.no_grad()
+    def _run_face(self, fi):
+        """``fi``: pixel_values (ns, 3, H, W) fp32 - the real images; start_latents (ns, 4, h, w) - vae-encoded, scaled and noised to the
+        first timestep of the inference schedule (infer.py:62-68); image_embeddings / uncond_image_embeddings: token-0 CLIP hidden states
+        (ns, 257, 1024) of the image and of the zero image (:76-84); text_input_ids / placeholder_idx of "a photo of *"; uncond_input_ids."""
+        f = self.face
+        f.real.copy_(fi["pixel_values"])
+        f.lat.copy_(fi["start_latents"])
+        f.x0_prev.zero_()
+        f.state.copy_(torch.tensor([0, f.T, 0, 0], dtype=torch.int32))
+        f.embs_c[0].copy_(fi["image_embeddings"])
+        f.embs_u[0].copy_(fi["uncond_image_embeddings"])
+        f.ids.copy_(fi["text_input_ids"].view(f.ns, -1))
+        f.pidx.copy_(fi["placeholder_idx"].view(-1))
+        f.pidx32.copy_(fi["placeholder_idx"].view(-1))
+        f.text_u.copy_(self.text_encoder({"text_input_ids": fi["uncond_input_ids"].to(f.ids.device)})[0].reshape(f.text_u.shape))
+        for forced, src in zip(f.fusion_forced, fi.get("forced_fusion") or (None, None)):
+            if src is None:
+                forced.fill_(-1.0)
+            else:
+                forced.copy_(torch.as_tensor(src, dtype=torch.float32))
+        f.tape.load_weights()
+        f.loop_tape.load_weights()
+        f.rec_cond.run()
+        for _ in range(f.T - 1):
+            f.loop_tape.rf.run()
+        f.rec_last.run()
+        f.tape.rb.run()
 
     # ------------------------------------------------------------------ one iteration
     def trainable_parameters(self) -> Dict[str, List[torch.nn.Parameter]]:
@@ -505,8 +691,11 @@ class TrainStep:
         return {"text_adapter": list(self.text_adapter.parameters()), "image_adapter": list(self.image_adapter.parameters()), "unet": un}
 
     @torch.no_grad()
-    def step(self, *, noisy_latents, noise, timesteps, text_input_ids, placeholder_idx, image_embeddings, forced_fusion=None):
-        """Fill the static inputs, replay forward + backward, set ``.grad`` (= gradient x ``grad_scale``).  Returns the loss terms."""
+    def step(self, *, noisy_latents, noise, timesteps, text_input_ids, placeholder_idx, image_embeddings, forced_fusion=None, face_inputs=None):
+        """Fill the static inputs, replay forward + backward, set ``.grad`` (= gradient x ``grad_scale``).  Returns the loss terms.
+        ``face_inputs`` (see ``_run_face``): required when the step was built with a face loss."""
+        if (self.face is None) != (face_inputs is None):
+            raise ValueError("face_inputs must be given exactly when the TrainStep was built with face_loss")
         self.noisy.copy_(noisy_latents)
         self.noise.copy_(noise)
         self.timesteps.copy_(timesteps.to(self.noisy.device, torch.float32))
@@ -535,11 +724,34 @@ class TrainStep:
             self.tape.rf.run()
             self.tape.rb.run()
             self._warm = True
-        for param, buf in self.pgrads:
-            param.grad = buf() if callable(buf) else buf.view(param.shape)
+        if self.face is not None:
+            self._run_face(face_inputs)
+        seen = set()
+        for param, buf in self.pgrads:                          # a parameter used by several passes has several buffers: summed here
+            self._give(param, buf() if callable(buf) else buf.view(param.shape), seen)
         for mod, dW in self.lora_pending:                       # rank-r factor gradients from the merged-weight gradient
             A, Bm = mod.lora_A["default"].weight, mod.lora_B["default"].weight
-            A.grad = mod.scaling * (Bm.detach().t() @ dW)
-            Bm.grad = mod.scaling * (dW @ A.detach().t())
-        return {"loss": self.loss, "diffusion_loss": self.terms[0:1], "concept_text_loss": self.terms[1:2],
-                "cross_attn_visual_loss": self.terms[2:3], "noise_pred": self.noise_pred, "fusion_table": self.fusion_tab}
+            self._give(A, mod.scaling * (Bm.detach().t() @ dW), seen)
+            self._give(Bm, mod.scaling * (dW @ A.detach().t()), seen)
+        out = {"loss": self.loss, "diffusion_loss": self.terms[0:1], "concept_text_loss": self.terms[1:2],
+               "cross_attn_visual_loss": self.terms[2:3], "noise_pred": self.noise_pred, "fusion_table": self.fusion_tab}
+        if self.face is not None:
+            # loss (train.py:535) = the three terms + 0.01 * floss: one more row-affine launch
+            rec = _ops.Recorder(self.noisy.device)
+            wv = rec.hold(torch.full((1,), self.face.weight, dtype=torch.float32, device=self.noisy.device))
+            one = rec.hold(torch.ones((1,), dtype=torch.float32, device=self.noisy.device))
+            out["loss"] = rec.affine_rows(self.loss.view(1, 1), one, self.face.loss.view(1, 1), wv).view(1)
+            rec.run()
+            out["face_loss"], out["face_images"] = self.face.loss, self.face.images
+        return out
+
+    def _give(self, param, g, seen):
+        if id(param) not in seen:
+            seen.add(id(param))
+            param.grad = g
+            return
+        rec = _ops.Recorder(g.device)
+        one = rec.hold(torch.ones((1,), dtype=torch.float32, device=g.device))
+        out = rec.affine_rows(param.grad.reshape(1, -1).contiguous(), one, g.reshape(1, -1).contiguous(), one)
+        rec.run()
+        param.grad = out.view(param.shape)

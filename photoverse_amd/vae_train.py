@@ -101,7 +101,7 @@ def decode_on_tape(tp: Tape, vae, z: torch.Tensor, *, clamp=(-1.0, 1.0)):
         wdg = d.conv_in.weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(lc, -1).to(torch.float16).contiguous()
         g = x.g if x.g.is_contiguous() else rb.add_rows(x.g, torch.zeros_like(x.t))
         dzq = rb.conv_out(g, wdg, None, batch=B, cin=c_in, h=h0, wd=w0, cout=lc)
-        dz.g = rb.pointwise_nchw(dzq, wpq.t().contiguous(), None, batch=B, cin=lc, cout=lc, hw=h0 * w0)
+        dz.g = rb.pointwise_nchw(dzq, wpq.t().contiguous(), None, batch=B, cin=lc, cout=lc, hw=h0 * w0).view(B, lc, h0, w0)
     tp.back.append(head_bwd)
     x = _res(tp, vae, d.mid_block.resnets[0], x, B, h, w)
     x = _attn(tp, vae, d.mid_block.attentions[0], x, B, h, w)
