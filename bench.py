@@ -95,7 +95,7 @@ def spawn_ranks(n, argv, dry=False):
     return 0
 
 
-def train_step_leg(unet, B, S, dev, reps=3):
+def train_step_leg(unet, B, S, dev, reps=3, with_face=True):
     """Time one full training iteration at configs[3]'s shape: bs=16, 64x64 latents, 5 image tokens, LoRA (r=8, dropout 0.1) on attn2.to_q/k/v,
     SD-v1.5-sized UNet, 12-layer CLIP text encoder, both adapters; forward + backward + clip + AdamW."""
     import time
@@ -148,14 +148,62 @@ def train_step_leg(unet, B, S, dev, reps=3):
         out = one()
     torch.cuda.synchronize()
     iter_ms = (time.perf_counter() - t1) * 1e3 / reps
+    hip_graph = ts.graph is not None
+    launches = (len(ts.tape.rf), len(ts.tape.rb))
+    act_bytes = ts.tape.rf.bytes_allocated + ts.tape.rb.bytes_allocated
+    loss_last = float(out["loss"])
+    finite = bool(torch.isfinite(out["loss"]).all().item())
+    # the same iteration WITH the identity-loss branch (configs[3] as written: "... with ArcFace identity loss"): 4 of the 16 samples
+    # (face_loss_sample_ratio 0.25) go through run_inference(timesteps=10, guidance 2, training_mode=True) - 9 denoising steps without
+    # gradient, the last one + the VAE decode (512x512) + the IR-ResNet18 inside the differentiated plan
+    face = None
+    if with_face:
+        from photoverse_amd.loss import FaceLoss
+        from photoverse_amd.vae import AutoencoderKL
+        from photoverse_amd.modeling_utils import load_models  # noqa: F401
+        from types import SimpleNamespace
+        from photoverse_amd.scheduler import DPMSolverMultistepScheduler
+        del ts, opt
+        torch.cuda.empty_cache()
+        vae = AutoencoderKL().to(dev)
+        fl = FaceLoss(dev, "arcface")
+        ns = 4
+        ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=S, w=S, n_tokens=5, grad_scale=4096.0, fusion_seed=1,
+                       face_loss=fl, vae=vae, noise_scheduler=SimpleNamespace(config=DPMSolverMultistepScheduler().config), face_samples=ns,
+                       guidance_scale=2.0, infer_steps=10)
+        groups = ts.trainable_parameters()
+        opt = AdamW([p for g_ in groups.values() for p in g_], lr=1e-5, weight_decay=1e-2)
+        fi = dict(pixel_values=(torch.rand(ns, 3, 8 * S, 8 * S, generator=g) * 2 - 1).to(dev), start_latents=torch.randn(ns, 4, S, S, generator=g).to(dev),
+                  image_embeddings=torch.randn(ns, 257, 1024, generator=g).half().to(dev),
+                  uncond_image_embeddings=torch.randn(ns, 257, 1024, generator=g).half().to(dev),
+                  text_input_ids=torch.randint(0, 49000, (ns, 77), generator=g).to(dev), placeholder_idx=torch.full((ns, 1), 4).to(dev),
+                  uncond_input_ids=torch.randint(0, 49000, (ns, 77), generator=g).to(dev))
+
+        def one_face():
+            o = ts.step(**inputs, face_inputs=fi)
+            opt.step(clip_groups=list(groups.values()), max_norm=1.0, grad_scale=ts.grad_scale)
+            return o
+        o = one_face()
+        o = one_face()                                       # second iteration captures the HIP graphs
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            o = one_face()
+        torch.cuda.synchronize()
+        fms = (time.perf_counter() - t1) * 1e3 / 2
+        face = {"ms_per_iteration": round(fms, 2), "face_samples": ns, "infer_steps": 10, "guidance_scale": 2.0,
+                "face_loss": round(float(o["face_loss"]), 5), "loss": round(float(o["loss"]), 5), "finite": bool(torch.isfinite(o["loss"]).all().item()),
+                "launches": {"conditioning": len(ts.face.rec_cond), "no_grad_step": len(ts.face.loop_tape.rf), "last_step_decode_loss": len(ts.face.rec_last),
+                             "backward": len(ts.face.tape.rb)}}
     n_train = sum(p.numel() for g_ in groups.values() for p in g_)
-    return {"workload": "configs[3] without the optional ArcFace term: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 / alpha=1 / dropout=0.1 (the reference defaults) on attn2.to_q/k/v; "
-                        "adapters + 12-layer CLIP text encoder + SD-v1.5 UNet forward, backward through all of them, per-module clip_grad_norm_, AdamW",
+    return {"workload": "configs[3]: bs=16, 64x64 latents, 5 image tokens, LoRA r=8 / alpha=1 / dropout=0.1 (the reference defaults) on attn2.to_q/k/v; "
+                        "adapters + 12-layer CLIP text encoder + SD-v1.5 UNet forward, backward through all of them, per-module clip_grad_norm_, AdamW; "
+                        "ms_per_iteration etc. are WITHOUT the ArcFace term, with_face_loss is the same iteration with it",
             "ms_per_iteration": round(iter_ms, 2), "forward_plan_ms": round(fwd_ms, 2), "backward_plan_ms": round(bwd_ms, 2),
-            "launches_forward": len(ts.tape.rf), "launches_backward": len(ts.tape.rb), "trainable_parameters": n_train,
-            "activation_bytes": ts.tape.rf.bytes_allocated + ts.tape.rb.bytes_allocated, "plan_build_s": round(build_s, 2),
-            "loss_first": round(l0, 5), "loss_last": round(float(out["loss"]), 5), "finite": bool(torch.isfinite(out["loss"]).all().item()),
-            "hip_graph": ts.graph is not None, "samples_per_s": round(B / (iter_ms * 1e-3), 2)}
+            "launches_forward": launches[0], "launches_backward": launches[1], "trainable_parameters": n_train,
+            "activation_bytes": act_bytes, "plan_build_s": round(build_s, 2),
+            "loss_first": round(l0, 5), "loss_last": round(loss_last, 5), "finite": finite,
+            "hip_graph": hip_graph, "samples_per_s": round(B / (iter_ms * 1e-3), 2), "with_face_loss": face}
 
 
 def main():

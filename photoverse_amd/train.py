@@ -671,11 +671,26 @@ class TrainStep:
                 forced.copy_(torch.as_tensor(src, dtype=torch.float32))
         f.tape.load_weights()
         f.loop_tape.load_weights()
-        f.rec_cond.run()
-        for _ in range(f.T - 1):
-            f.loop_tape.rf.run()
-        f.rec_last.run()
-        f.tape.rb.run()
+
+        def replay():
+            f.rec_cond.run()
+            for _ in range(f.T - 1):
+                f.loop_tape.rf.run()
+            f.rec_last.run()
+            f.tape.rb.run()
+        if getattr(f, "graph", None) is not None:
+            f.graph.replay()
+        elif self.use_graph and getattr(f, "warm", False):
+            torch.cuda.synchronize()                      # second iteration on: the whole branch (~13k launches at T = 10) as one HIP graph
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                replay()
+            f.graph = gr
+            f.state.copy_(torch.tensor([0, f.T, 0, 0], dtype=torch.int32))     # capture does not execute: the counter is still at 0
+            gr.replay()
+        else:
+            replay()
+            f.warm = True
 
     # ------------------------------------------------------------------ one iteration
     def trainable_parameters(self) -> Dict[str, List[torch.nn.Parameter]]:
@@ -755,3 +770,59 @@ class TrainStep:
         out = rec.affine_rows(param.grad.reshape(1, -1).contiguous(), one, g.reshape(1, -1).contiguous(), one)
         rec.run()
         param.grad = out.view(param.shape)
+
+
+@torch.no_grad()
+def training_iteration(step: TrainStep, optimizer, batch, tokenizer, image_encoder, vae, noise_scheduler, device, image_encoder_layers_idx,
+                       extra_num_tokens: int, *, generator: Optional[torch.Generator] = None, max_grad_norm: float = 1.0):
+    """The body of the reference's training loop (``train.py:464-549``) on top of ``TrainStep``: the frozen, gradient-free part with this
+    package's inference modules - VAE encode + posterior sample (``:471-472``), noise / per-sample timesteps / add_noise (``:475-484``), CLIP
+    image features (``:487-492``) and, with a face loss, the inputs of ``run_inference(sliced_batch, ...)`` (``:522-530``, ``infer.py:42-84``:
+    the "a photo of *" prompt, a random subset of the batch, its latents noised to the first inference timestep, the zero-image features) -
+    then the forward + backward plans and the clipped AdamW update (``:536-547``).  Returns the loss terms of the step."""
+    device = torch.device(device)
+    pixel_values = batch["pixel_values"].to(device, dtype=torch.float32)
+    pixel_values_clip = batch["pixel_values_clip"].to(device, dtype=torch.float32)
+    bsz = pixel_values.shape[0]
+    cpu_gen = dict(generator=generator) if generator is not None else {}
+    rec = Recorder(device)
+    dist = vae.encode(pixel_values).latent_dist
+    eps = torch.randn(dist.mean.shape, **cpu_gen).to(device, torch.float32)
+    sf = torch.full((bsz,), float(vae.config.scaling_factor), dtype=torch.float32, device=device)
+    latents = rec.affine_rows(rec.posterior_sample(dist.parameters.contiguous(), eps.contiguous()), sf)
+    rec.run()
+    noise = torch.randn(latents.shape, **cpu_gen).to(device, torch.float32)
+    n_train = noise_scheduler.config["num_train_timesteps"] if isinstance(noise_scheduler.config, dict) else noise_scheduler.config.num_train_timesteps
+    timesteps = torch.randint(0, n_train, (bsz,), **cpu_gen).long()
+    from .scheduler import DPMSolverMultistepScheduler
+    sch = noise_scheduler if hasattr(noise_scheduler, "add_noise") else DPMSolverMultistepScheduler.from_config(noise_scheduler.config)
+    noisy_latents = sch.add_noise(latents, noise, timesteps)
+    feats = image_encoder(pixel_values_clip, output_hidden_states=True)
+    image_embeddings = [feats[0]] + [feats[2][i] for i in image_encoder_layers_idx if i < len(feats[2])]
+    assert len(image_embeddings) == extra_num_tokens + 1, "Entered indices are out of range for image_encoder layers."
+    face_inputs = None
+    if step.face is not None:
+        f = step.face
+        idx = torch.randperm(bsz, **cpu_gen)[:f.ns]                                              # random_batch_slicing (datasets/utils.py:223-234)
+        text = "a photo of {}".format("*")                                                       # prepare_prompt (train.py:523)
+        ids = tokenizer([text] * f.ns, padding="max_length", max_length=tokenizer.model_max_length, return_tensors="pt").input_ids
+        uids = tokenizer([""] * f.ns, padding="max_length", max_length=tokenizer.model_max_length, return_tensors="pt").input_ids
+        pidx = torch.full((f.ns, 1), text.split().index("*") + 1, dtype=torch.int64)
+        sub = pixel_values[idx.to(device)]
+        d2 = vae.encode(sub).latent_dist                                                         # infer.py:62-65 (a fresh posterior sample)
+        rec = Recorder(device)
+        e2 = torch.randn(d2.mean.shape, **cpu_gen).to(device, torch.float32)
+        lat = rec.affine_rows(rec.posterior_sample(d2.parameters.contiguous(), e2.contiguous()), sf[:f.ns].contiguous())
+        rec.run()
+        n2 = torch.randn(lat.shape, **cpu_gen).to(device, torch.float32)
+        start = f.scheduler.add_noise(lat, n2, f.scheduler.timesteps[:1].repeat(f.ns)) * f.scheduler.init_noise_sigma
+        ufeats = image_encoder(torch.zeros_like(pixel_values_clip[:f.ns]), output_hidden_states=True)
+        face_inputs = dict(pixel_values=sub, start_latents=start, image_embeddings=image_embeddings[0][idx.to(device)],
+                           uncond_image_embeddings=ufeats[0], text_input_ids=ids.to(device), placeholder_idx=pidx.to(device),
+                           uncond_input_ids=uids.to(device))
+    out = step.step(noisy_latents=noisy_latents, noise=noise, timesteps=timesteps, text_input_ids=batch["text_input_ids"].to(device),
+                    placeholder_idx=batch["concept_placeholder_idx"].to(device), image_embeddings=image_embeddings, face_inputs=face_inputs)
+    groups = step.trainable_parameters()
+    out["grad_norms"] = optimizer.step(clip_groups=list(groups.values()), max_norm=max_grad_norm, grad_scale=step.grad_scale)
+    optimizer.zero_grad()
+    return out
