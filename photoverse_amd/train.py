@@ -547,7 +547,7 @@ class TrainStep:
         (infer.py:7-123) + face_loss(pixel_values, gen_images, normalize=False) (loss.py:64-78) for ``ns`` samples:
 
             A  conditioning WITH gradient: text_adapter / image_adapter token 0, injected text encoder         (one recorder)
-            L  one denoising step without gradient: uncond + cond UNet forward, CFG + DPM-Solver++ update       (replayed T - 1 times)
+            L  one denoising step without gradient: uncond + cond UNet forward (one stacked pass), CFG + DPM-Solver++ update   (replayed T - 1 times)
             B  the last step with gradient: both forwards (per-layer fusion drawn on the device), the update,
                latents / scaling_factor -> VAE decode -> clamp -> ArcFace loss                                   (one recorder)
             backward of B and A in one plan.
@@ -600,14 +600,28 @@ class TrainStep:
         text_u = Var(f.text_u, False)
 
         # ---- L: one denoising step without gradient, replayed T - 1 times (infer.py:98-119 under set_grad_enabled(False))
+        # Without gradient both forwards use the (1, 1) fusion, so the uncond and the cond forward are ONE pass over the stacked batch
+        # [uncond; cond] (same weights, per-sample conditioning): 2 ns rows fill the chip better than two passes of ns.
         tl = f.loop_tape = Tape(dev, 1.0)
-        self._enter(tape=tl, t_state=(f.ts, f.state), fusion_names=[], site_base=2000)
-        eps_u, _ = self._unet_pass(f.lat, text_u, Var(ip_u.t, False))
-        self._enter(fusion_names=[], site_base=2500, vnorms={})
-        eps_c, _ = self._unet_pass(f.lat, Var(text_c.t, False), Var(ip_c.t, False))
-        tl.rf.cfg_dpm_step(eps_u, eps_c, f.lat, f.x0_prev, f.coef, f.state, guidance)
-        tl.rf.step_advance(f.state)
+        lrf = tl.rf
+        one = lrf.hold(torch.ones((1,), dtype=torch.float32, device=dev))
+        lat2 = lrf.hold(torch.zeros((2 * ns, cfg.in_channels, h, w), dtype=torch.float32, device=dev))
+        text2 = lrf.hold(torch.zeros((2 * ns * seq, cfg.cross_attention_dim), dtype=torch.float16, device=dev))
+        ip2 = lrf.hold(torch.zeros((2 * ns, cfg.cross_attention_dim), dtype=torch.float16, device=dev))
+        zt = lrf.hold(torch.zeros((ns * seq, cfg.cross_attention_dim), dtype=torch.float16, device=dev))
+        f.rec_stack = Recorder(dev)                       # once per iteration, after the conditioning: stack the two conditionings
+        f.rec_stack.add_rows(f.text_u, zt, out=text2[:ns * seq])
+        f.rec_stack.add_rows(text_c.t, zt, out=text2[ns * seq:])
+        f.rec_stack.add_rows(ip_u.t, zt[:ns], out=ip2[:ns])
+        f.rec_stack.add_rows(ip_c.t, zt[:ns], out=ip2[ns:])
+        for half in (lat2[:ns], lat2[ns:]):               # every step: both halves read the current latents
+            lrf.affine_rows(f.lat.view(1, -1), one, out=half.view(1, -1))
+        self._enter(tape=tl, B=2 * ns, t_state=(f.ts, f.state), fusion_names=[], site_base=2000)
+        eps2, _ = self._unet_pass(lat2, Var(text2, False), Var(ip2, False))
+        lrf.cfg_dpm_step(eps2[:ns], eps2[ns:], f.lat, f.x0_prev, f.coef, f.state, guidance)
+        lrf.step_advance(f.state)
         tl.back = []
+        self._enter(B=ns)
 
         # ---- B: the last step, in grad mode (infer.py:99), decode, loss
         f.rec_last = ft.rf = Recorder(dev)
@@ -674,6 +688,7 @@ class TrainStep:
 
         def replay():
             f.rec_cond.run()
+            f.rec_stack.run()
             for _ in range(f.T - 1):
                 f.loop_tape.rf.run()
             f.rec_last.run()
