@@ -26,6 +26,37 @@ class AdamW:
         self.step_count = 0
         self.state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.params}
 
+    # ---- torch.optim.AdamW's checkpoint format (modeling_utils.save_progress stores optimizer.state_dict(), modeling_utils.py:43-44) ----
+    def state_dict(self):
+        state = {}
+        if self.step_count:
+            for i, p in enumerate(self.params):
+                m, v = self.state[id(p)]
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True,     # torch >= 2.6: AdamW is Adam with this flag; a group without it loads as coupled L2 decay
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        self.lr, self.betas, self.eps, self.weight_decay = group["lr"], tuple(group["betas"]), group["eps"], group["weight_decay"]
+        steps = set()
+        for i, p in enumerate(self.params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            m, v = self.state[id(p)]
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: this optimizer keeps one step counter")
+        self.step_count = steps.pop() if steps else 0
+
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None

@@ -776,3 +776,33 @@ def test_training_iteration_loop_body(need_gpu, with_face):
         moved = sum(float((p.detach() - b).abs().sum()) for p, b in zip(ps, before[k]))
         assert moved > 0, k
     assert losses[-1] < losses[0]              # same batch, same draws (generator re-seeded): three AdamW steps lower its loss
+
+
+def test_adamw_state_dict_is_interchangeable_with_torch(need_gpu):
+    """save_progress stores optimizer.state_dict() (modeling_utils.py:43-44): the HIP optimizer writes / reads torch.optim.AdamW's format -
+    one step here, state moved into torch.optim.AdamW (and back), a second step on both sides gives the same parameters."""
+    from photoverse_amd.optim import AdamW
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.nn.Parameter(torch.randn(s_, generator=g).cuda()) for s_ in ((64, 32), (32,), (5, 7))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    o1 = AdamW(ps, lr=1e-3, weight_decay=1e-2)
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).cuda()
+    o1.step()
+    for p, q in zip(ps, qs):
+        q.data.copy_(p.data)
+    o2 = torch.optim.AdamW(qs, lr=5e-2)
+    import copy
+    o2.load_state_dict(copy.deepcopy(o1.state_dict()))    # (a file round trip; torch keeps same-device tensors by reference) - also carries lr / betas / ...
+    assert o2.param_groups[0]["lr"] == 1e-3
+    for p, q in zip(ps, qs):
+        gr = torch.randn(p.shape, generator=g).cuda()
+        p.grad, q.grad = gr.clone(), gr.clone()
+    o1.step()
+    o2.step()
+    for p, q in zip(ps, qs):
+        assert rel_l2(p.detach(), q.detach()) < 1e-6
+    o3 = AdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1.0)
+    o3.load_state_dict(copy.deepcopy(o2.state_dict()))
+    assert o3.step_count == 2 and o3.lr == 1e-3
+    assert torch.equal(o3.state[id(o3.params[0])][0], o2.state[qs[0]]["exp_avg"])
