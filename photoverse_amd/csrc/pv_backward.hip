@@ -87,6 +87,76 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
     }
 }
 
+// data-gradient-only LayerNorm backward (the frozen LayerNorms of the UNet / text encoder): one wave per row, 16-byte loads, the row and
+// its gradient live in registers between the three passes (statistics, the two projections, the result)
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layernorm_bwd_params p) {
+    constexpr int NCH = 4;                                   // 16-byte chunks per lane: cols <= 2048
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nchunk = p.cols >> 3;
+    const half_t* x = reinterpret_cast<const half_t*>(p.x) + (size_t)row * p.ldx;
+    const int grp = p.dy_group > 1 ? p.dy_group : 1;
+    const int drow = row / grp;
+    const float dys = (p.dy_group > 1 && (row - drow * grp) < p.dy_skip) ? 0.f : p.dy_scale;
+    const half_t* dy = reinterpret_cast<const half_t*>(p.dy) + (size_t)drow * p.lddy;
+    float xv[NCH][8], gv[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(x + ch * 8), g = *reinterpret_cast<const half8_t*>(dy + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xv[i][j] = (float)a[j]; gv[i][j] = (float)g[j] * dys; sum += xv[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[i][j] = gv[i][j] = 0.f;
+        }
+    }
+    const float mean = pv_wave_sum(sum) / (float)p.cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + i * 64 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(pv_wave_sum(sq) / (float)p.cols + p.eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gam = p.gamma[ch * 8 + j];
+                const float xh = (xv[i][j] - mean) * rstd;
+                float g = gv[i][j];
+                if (p.act == PV_ACT_LEAKY_RELU && gam * xh + p.beta[ch * 8 + j] < 0.f) g *= 0.01f;
+                const float dxh = g * gam;
+                xv[i][j] = xh;
+                gv[i][j] = dxh;
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        }
+    }
+    s1 = pv_wave_sum(s1) / (float)p.cols;
+    s2 = pv_wave_sum(s2) / (float)p.cols;
+    half_t* dx = reinterpret_cast<half_t*>(p.dx) + (size_t)row * p.lddx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(rstd * (gv[i][j] - s1 - xv[i][j] * s2));
+            *reinterpret_cast<half8_t*>(dx + ch * 8) = o;
+        }
+    }
+}
+
 // out[k][c] = scale * sum_i x[i][k][c] in i order: column reductions (dgamma / dbeta partials, bias gradients), deterministic
 __global__ void reduce_blocks_kernel(const float* x, int nblk, long inner, float scale, float* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +227,10 @@ extern "C" int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_
 
 extern "C" int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream) {
     if (!p->x || !p->dy || !p->dx || !p->gamma || !p->beta || p->rows <= 0 || p->cols <= 0 || p->cols > 2048) return (int)hipErrorInvalidValue;
+    if (!p->dgb_partial && p->cols % 8 == 0 && (p->ldx | p->lddy | p->lddx) % 8 == 0) {
+        hipLaunchKernelGGL(layernorm_bwd_vec_kernel, dim3((unsigned)((p->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p);
+        return PV_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((p->rows + 4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1) - 1) / (4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1)))), dim3(256), 8 * p->cols * sizeof(float), (hipStream_t)stream, *p);
     return PV_CHECK_LAUNCH();
 }

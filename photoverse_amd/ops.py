@@ -467,7 +467,12 @@ class Recorder:
         K must be a multiple of 128 (or 160)."""
         a = self.transpose(dy16)          # [N, Mp]
         w = self.transpose(x16)           # [K, Mp]
-        return self.gemm(a, w, out_f32=True, splitk=0)
+        # the output is tiny and the contraction is the row count: split it over workgroups (fixed-order slab reduce, deterministic) -
+        # a 320 x 320 gradient over 65536 rows is 6 tiles; unsplit it took 781 us
+        bn = 160 if w.shape[0] % 160 == 0 else 128
+        tiles = ((a.shape[0] + 127) // 128) * (w.shape[0] // bn)
+        sk = max(1, min(16, 256 // tiles, a.shape[1] // 512))
+        return self.gemm(a, w, out_f32=True, splitk=sk if sk > 1 else 0)
 
     def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0):
         """dx fp16 [rows, cols] and (dgamma, dbeta) fp32 [2, cols].  ``dy_group`` > 1: dy has rows / dy_group rows, row r uses

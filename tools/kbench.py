@@ -143,6 +143,77 @@ def conv_out(name, cin, cout, hw, b=B):
     cases.append((name, f))
 
 
+
+# ---- backward kernels of the training step (pv_train.hip / pv_backward.hip) ----
+def attn_bwd(name, d, n, causal=False, heads=8, b=B):
+    def f():
+        rec = Recorder(dev)
+        C = heads * d
+        qkv, do = h16(b * n, 3 * C), h16(b * n, C)
+        lse = torch.empty((b, heads, n), dtype=torch.float32, device=dev)
+        pre = Recorder(dev)
+        o = pre.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=b, heads=heads, nq=n, nk=n, d=d, causal=causal, lse=lse)
+        pre.run()
+        rec.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, do, lse, batch=b, heads=heads, nq=n, nk=n, d=d, causal=causal)
+        rec.keep.append(pre)
+        return rec, 10.0 * b * n * n * C * (0.5 if causal else 1.0), 0        # five N x N x d products (S and dP twice, dV, dK, dQ)
+    cases.append((name, f))
+
+
+def xattn_bwd(name, d, n, p=5):
+    def f():
+        rec = Recorder(dev)
+        C = 8 * d
+        q, kvt, kvi, do = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C), h16(B * n, C)
+        rec.cross_attention_backward(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], do, batch=B, heads=8, nq=n, nt=77, nip=p, d=d)
+        return rec, 14.0 * B * n * (77 + p) * C, 2.0 * 3 * B * n * C         # pass 1: S, dP, dQ; pass 2: S, dP, dK, dV
+    cases.append((name, f))
+
+
+def gn_bwd(name, c, hw):
+    def f():
+        pre, rec = Recorder(dev), Recorder(dev)
+        x, dy = h16(B * hw * hw, c), h16(B * hw * hw, c)
+        g, bt = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        _, stats = pre.groupnorm(x, g, bt, batch=B, hw=hw * hw, act=1, return_stats=True)
+        pre.run()
+        rec.groupnorm_backward(x, dy, stats, g, bt, batch=B, hw=hw * hw, act=1)
+        rec.keep.append(pre)
+        return rec, 0, 2.0 * B * hw * hw * c * 5                              # x and dy twice (two passes) + dx
+    cases.append((name, f))
+
+
+def ln_bwd(name, c, rows):
+    def f():
+        rec = Recorder(dev)
+        x, dy = h16(rows, c), h16(rows, c)
+        rec.layernorm_backward(x, dy, torch.ones(c, device=dev), torch.zeros(c, device=dev), want_affine=False)
+        return rec, 0, 2.0 * rows * c * 3
+    cases.append((name, f))
+
+
+def conv_dgrad(name, cin, cout, hw, stride=1):
+    def f():
+        from photoverse_amd.tape import conv3_dgrad_weight
+        rec = Recorder(dev)
+        ho = hw // stride
+        dy = h16(B * ho * ho, cout)
+        wd = conv3_dgrad_weight(torch.randn(cout, cin, 3, 3, device=dev) * 0.02)
+        if stride == 2:
+            dy = rec.dilate2x(dy, batch=B, h=ho, w=ho)
+        rec.gemm(dy, wd, conv=dict(batch=B, hin=hw, win=hw, hout=hw, wout=hw))
+        return rec, 2.0 * B * hw * hw * cin * 9 * cout, 0
+    cases.append((name, f))
+
+
+def wgrad(name, M, K, N):
+    def f():
+        rec = Recorder(dev)
+        rec.wgrad(h16(M, N), h16(M, K))
+        return rec, 2.0 * M * N * K, 2.0 * M * (N + K) * 2
+    cases.append((name, f))
+
+
 conv("conv3 320->320 @64", 320, 320, 64)
 conv("conv3 640+320->320 @64 (dual)", 640, 320, 64, c1=320)
 conv("conv3 320->320 @64 s2", 320, 320, 64, stride=2)
@@ -181,14 +252,27 @@ gn_cs("gn(colstats)+silu 640 @32", 640, 32)
 ln("ln 320 x65536", 320, 65536)
 ln("ln 640 x16384", 640, 16384)
 ln("ln 1280 x4096", 1280, 4096)
+attn_bwd("attn BWD d40 n4096", 40, 4096)
+attn_bwd("attn BWD d80 n1024", 80, 1024)
+attn_bwd("attn BWD d160 n256", 160, 256)
+attn_bwd("attn BWD d64 n77 causal (CLIP text, 12 heads)", 64, 77, causal=True, heads=12)
+xattn_bwd("xattn BWD d40 n4096 P5", 40, 4096)
+xattn_bwd("xattn BWD d80 n1024 P5", 80, 1024)
+gn_bwd("gn+silu BWD 320 @64", 320, 64)
+gn_bwd("gn+silu BWD 1280 @16", 1280, 16)
+ln_bwd("ln BWD 320 x65536", 320, 65536)
+conv_dgrad("conv3 dgrad 320->320 @64", 320, 320, 64)
+conv_dgrad("conv3 dgrad 320->320 @64 s2 (dilate + conv)", 320, 320, 64, stride=2)
+wgrad("wgrad 65536: dW[320x320] (attn2.to_q LoRA)", 65536, 320, 320)
+wgrad("wgrad 4112: dW[1024x1024] (adapter Linear)", 4112, 1024, 1024)
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-print(f"{'case':40s} {'us':>10s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+print(f"{'case':52s} {'us':>10s} {'TFLOP/s':>9s} {'GB/s':>9s}")
 for name, f in cases:
     if flt and not any(f_ in name for f_ in flt.split("|")):   # "a|b": either substring
         continue
     rec, flops, byts = f()
     us = timeit(rec)
-    print(f"{name:40s} {us:10.1f} {flops / us / 1e6:9.1f} {byts / us / 1e3:9.1f}")
+    print(f"{name:52s} {us:10.1f} {flops / us / 1e6:9.1f} {byts / us / 1e3:9.1f}")
     del rec
     torch.cuda.empty_cache()
