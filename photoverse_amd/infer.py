@@ -42,11 +42,13 @@ def run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_ad
     ``(B, C, latent, latent)`` replacing the draw of ``infer.py:52-59`` - used by the batch-sharded pipeline, which draws the
     global batch once and hands each rank its slice."""
     if training_mode and torch.is_grad_enabled():
-        # the reference back-propagates through the last denoising step (infer.py:99); the backward kernels are not built (SURVEY 8f-3).
-        # Under torch.no_grad() the FORWARD semantics of that mode are available: the last step's forwards draw the grad-mode branch
-        # fusion of every cross-attention layer (attention_processor.py:413-420), on the device, inside the captured step.
-        raise NotImplementedError("training_mode with autograd needs the backward kernels (SURVEY 8f-3); call under torch.no_grad() for the "
-                                  "forward semantics of the mode (random branch fusion on the last step)")
+        # the reference back-propagates through the last denoising step (infer.py:99).  Here that differentiated call is a static
+        # forward + backward plan, not a dynamic autograd graph: train.TrainStep(face_loss=..., vae=...) replays exactly this function
+        # (conditioning with gradient, T - 1 steps without, the last step + decode inside the plan).  Under torch.no_grad() the FORWARD
+        # semantics of the mode are available from this entry point: the last step's forwards draw the grad-mode branch fusion of every
+        # cross-attention layer (attention_processor.py:413-420), on the device, inside the captured step.
+        raise NotImplementedError("run_inference(training_mode=True) with autograd enabled: use photoverse_amd.train.TrainStep(face_loss=..., vae=...) - "
+                                  "the differentiated form of this call - or call under torch.no_grad() for the forward semantics of the mode")
     device = torch.device(device)
     # infer.py:39-40 - the sampler is rebuilt from the loaded scheduler's config on every call
     sch = DPMSolverMultistepScheduler.from_config(scheduler.config)
