@@ -273,8 +273,8 @@ int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt,
 int pv_xattn_fused_wo_slot(int32_t slot);
 
 /* ------------------------------------------------------------------------------------------
- * BACKWARD of PhotoVerse's own trainable modules (first correct versions; the stock SD-v1.5 / CLIP
- * backward is not built).
+ * BACKWARD of PhotoVerse's own trainable modules (the backward of the stock SD-v1.5 / CLIP blocks the gradient crosses is
+ * declared further up: pv_attention_backward, pv_groupnorm_backward, ...).
  *
  * pv_cross_attention_backward: gradient of the dual-branch SDPA (attention_processor.py:317-322,
  * :392-420) given dout = dL/d(attention output before to_out):

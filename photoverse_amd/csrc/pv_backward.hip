@@ -5,9 +5,10 @@
 //                                 dW = dY^T . X run on pv_gemm_conv)
 //   pv_layernorm_backward         LayerNorm (+ LeakyReLU) backward of the adapter MLPs (adapters.py:15-19)
 //
-// First correct versions: fp32 VALU arithmetic on fp16 operands staged through LDS, fixed-order reductions (deterministic), no MFMA.
-// The cross-attention contraction is 96 keys wide - these kernels are a few percent of a training step's backward; the stock
-// SD-v1.5 / CLIP backward (convs, self-attention, GroupNorm ...) is not built.
+//   pv_adamw_step, pv_clip_coef   the optimizer (train.py:372-377, :538-545)
+//
+// fp32 VALU arithmetic on fp16 operands, fixed-order reductions (deterministic).  The MFMA backward kernels (both attentions) and the
+// backward of the stock SD-v1.5 / CLIP blocks are in pv_train.hip.
 #include "pv_common.h"
 
 namespace {

@@ -24,8 +24,8 @@ class DenoiseLoop:
                  two_streams: bool = True, batch_splits: int = 1, training_mode: bool = False, fusion_seed: int = 0):
         """``training_mode``: the reference enables grad on the LAST denoising step only (infer.py:99), where every cross-attention
         layer of both forwards then draws its branch fusion (attention_processor.py:413-420).  Here the draw runs on the device inside
-        the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps; the backward itself is
-        not built - this is the forward semantics of that mode."""
+        the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps.  This is the forward semantics
+        of that mode; the differentiated last step lives in ``train.TrainStep(face_loss=...)``."""
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")

@@ -12,8 +12,8 @@ on the inference-style engine (fused GEGLU / fused attn2, nothing kept for a bac
 
 ``TrainStep`` (below): the trainable part of the step - adapters, text encoder, UNet, losses - as a forward AND a backward launch plan
 (``tape.py``), leaving gradients on every parameter ``train.py:366-377`` optimises; ``optim.AdamW`` finishes the iteration
-(``:538-545``).  ``lora_dropout > 0`` (the reference default, 0.1) runs the low-rank branches un-merged with a device-side dropout.  The optional ArcFace
-face-loss term (``:521-535``) is not built.
+(``:538-545``).  ``lora_dropout > 0`` (the reference default, 0.1) runs the low-rank branches un-merged with a device-side dropout.  ``face_loss=`` adds
+the ArcFace identity-loss branch (``:521-535``); ``training_iteration`` is the loop body of ``:464-549``.
 """
 from __future__ import annotations
 
@@ -128,8 +128,8 @@ from .unet import ResnetBlock2D, Transformer2DModel, _conv1_w, _conv3_w, _f16, _
 
 
 class TrainStep:
-    """One PhotoVerse training iteration (``/root/reference/train.py:466-545`` without the optional ArcFace term) for a fixed
-    shape, as a forward and a backward launch plan over the HIP kernels.
+    """One PhotoVerse training iteration (``/root/reference/train.py:466-545``; the ArcFace identity-loss term of ``:521-535`` with
+    ``face_loss=``) for a fixed shape, as forward and backward launch plans over the HIP kernels.
 
     Trainable (train.py:366-377): both adapters, ``to_k_ip`` / ``to_v_ip`` of the 16 cross-attention processors and - with
     ``--use_lora`` - the LoRA factors behind ``attn2.to_q / to_k / to_v``.  Everything else is frozen, but the gradient crosses it:
@@ -138,7 +138,8 @@ class TrainStep:
 
     ``step(batch)`` fills the static inputs, replays the two plans and leaves ``.grad`` (times ``grad_scale``, fp32) on every
     trainable parameter; ``optim.AdamW.step(clip_groups=..., grad_scale=...)`` finishes the iteration without a host sync.
-    The LoRA factor gradients dA = s B^T dW, dB = s dW A^T are rank-r products of the merged-weight gradient (library GEMM).
+    With ``lora_dropout == 0`` LoRA runs merged and the factor gradients dA = s B^T dW, dB = s dW A^T are rank-r products of the
+    merged-weight gradient (library GEMM); with dropout the low-rank branches run un-merged on the HIP GEMM (``_lora_branch``).
     """
 
     def __init__(self, unet, text_encoder, text_adapter, image_adapter, *, batch: int, h: int, w: int, n_tokens: int, seq: int = 77,
