@@ -946,3 +946,33 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     errs = {k: group_err(v) for k, v in groups.items()}
     print("full-size training step + face loss, gradient rel-L2 per group:", errs)
     assert max(errs.values()) < 8e-2, errs
+
+
+@pytest.mark.parametrize("face", [False, True])
+def test_train_cli_runs_and_writes_reference_layout_checkpoints(need_gpu, tmp_path, face):
+    """``train.py`` (the counterpart of the reference's training CLI) as a subprocess on the tiny config with synthetic data: three steps
+    with LoRA (reference defaults incl. dropout) and, for ``face``, the ArcFace identity loss; the step and final checkpoints load through
+    ``load_photoverse_model`` (reference layout, modeling_utils.py:13-50) and carry the optimizer state."""
+    import subprocess
+    import sys
+    from photoverse_amd.modeling_utils import load_models, load_photoverse_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train.py"), "--pretrained_model_name_or_path", "random", "--tiny", "--synthetic_data",
+           "--max_train_steps", "3", "--train_batch_size", "2", "--resolution", "128", "--extra_num_tokens", "2", "--image_encoder_layers_idx", "1", "2",
+           "--use_lora", "--checkpoint_save_steps", "2", "--output_dir", str(tmp_path), "--seed", "7", "--lr_scheduler", "constant_with_warmup",
+           "--lr_warmup_steps", "2", "--learning_rate", "1e-4"] + (["--face_loss", "arcface"] if face else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("step ")]
+    assert len(lines) == 3 and "loss_mle=" in lines[0] and ("loss_face=" in lines[0]) == face
+    assert "lr=0," in lines[0].replace(" ", "") or "lr=0" in lines[0]          # warm-up: first step at lr 0, then 5e-5, then 1e-4
+    assert os.path.exists(tmp_path / "photoverse_000002.pt") and os.path.exists(tmp_path / "photoverse.pt")
+    sd = torch.load(tmp_path / "photoverse.pt", map_location="cpu")
+    assert set(sd) >= {"image_adapter", "text_adapter", "cross_attention_adapter", "lora_config", "optimizer"}
+    assert any("lora_A" in k for k in sd["cross_attention_adapter"]) and any("to_k_ip" in k for k in sd["cross_attention_adapter"])
+    assert len(sd["optimizer"]["state"]) > 0 and int(sd["optimizer"]["state"][0]["step"]) == 3
+    from oracle.unet_ref import TINY_CONFIG
+    _, _, _, unet, _, ia, ta, _, _ = load_models(None, 2, unet_config=TINY_CONFIG, vision_config=VIS, text_config=TXT,
+                                                  vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1), seed=1)
+    ia, ta, unet, lcfg = load_photoverse_model(str(tmp_path / "photoverse.pt"), ia, ta, unet)
+    assert lcfg is not None and lcfg.r == 8 and lcfg.lora_dropout == pytest.approx(0.1)
