@@ -326,6 +326,15 @@ int pv_reduce_sumsq(const float* a, int64_t n, float scale, float* partial, int3
  * first - it carries 1/loss_scale and the clip_grad_norm_ coefficient without a host sync */
 int pv_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, const float* gscale, void* stream);
+/* Multi-tensor forms of the three optimizer launches: ONE launch each over every parameter tensor.  entries: int64 [T][6] =
+ * {param, grad, exp_avg, exp_avg_sq, gscale pointer (or 0), n}; workgroup b handles elements [blk_chunk[b] * chunk, + chunk) of tensor
+ * blk_tensor[b].  pv_sumsq_multi: partial[b] = sum of grad^2 of that range; pv_clip_coef_groups: group g owns partial[group_start[g] ..
+ * group_start[g+1]): out[2g] = base * min(1, max_norm / (base * sqrt(sum) + 1e-6)), out[2g+1] = base * sqrt(sum) (base = 1 / loss scale);
+ * pv_adamw_multi: the AdamW update of every range, reading its tensor's gscale. */
+int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float* partial, void* stream);
+int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, void* stream);
+int pv_adamw_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
 /* clip_grad_norm_ (train.py:538-541): out[0] = base * min(1, max_norm / (sqrt(sum_i sumsq[i]) + 1e-6)), out[1] = the norm */
 int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream);
 /* out[c] = sum_r x[r][c] over fp16 rows (bias gradients); partial: nblk*cols floats */

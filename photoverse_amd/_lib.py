@@ -126,6 +126,9 @@ SIGNATURES = {
     "pv_sign_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "pv_gather_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "pv_reduce_sumsq": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "pv_sumsq_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pv_clip_coef_groups": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "pv_adamw_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "pv_clip_coef": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -2,8 +2,8 @@
 ``:538-541`` ``clip_grad_norm_(…, 1)`` per module, ``:545`` ``optimizer.step()``).
 
 Same update rule as ``torch.optim.AdamW`` (decoupled weight decay, bias correction).  The clip coefficient and the loss-scale removal
-are computed ON THE DEVICE (sum of squares by the deterministic reduction kernel -> ``pv_clip_coef`` -> read by ``pv_adamw_step``), so a
-step needs no host synchronisation.  State (exp_avg, exp_avg_sq) is fp32; parameters must be fp32 CUDA tensors.
+are computed ON THE DEVICE (``pv_sumsq_multi`` -> ``pv_clip_coef_groups`` -> read by ``pv_adamw_multi``: three multi-tensor launches over all
+~220 parameter tensors, fixed summation order), so a step needs no host synchronisation.  State (exp_avg, exp_avg_sq) is fp32; parameters must be fp32 CUDA tensors.
 """
 from __future__ import annotations
 
@@ -61,40 +61,59 @@ class AdamW:
         for p in self.params:
             p.grad = None
 
+    CHUNK = 32768      # elements per workgroup of the multi-tensor launches
+
     @torch.no_grad()
     def step(self, clip_groups: Sequence[Sequence[torch.nn.Parameter]] = (), max_norm: float = 1.0, grad_scale: float = 1.0):
         """One AdamW step.  ``clip_groups``: parameter groups each clipped to ``max_norm`` by its own total gradient norm (the
         reference clips text_adapter, image_adapter and unet parameters separately); parameters in no group are not clipped.
-        ``grad_scale``: the loss scale the gradients carry (divided out).  Returns the device tensors of the group norms."""
+        ``grad_scale``: the loss scale the gradients carry (divided out).  Returns the device tensors of the group norms.
+
+        Three launches whatever the number of tensors: the squared gradient norms (``pv_sumsq_multi``), the per-group clip coefficient
+        times 1 / grad_scale (``pv_clip_coef_groups``, device memory) and the update (``pv_adamw_multi``) - no host synchronisation."""
+        import numpy as np
         self.step_count += 1
         dev = self.params[0].device
+        gid = {}
+        for gi, group in enumerate(clip_groups):
+            for p in group:
+                gid[id(p)] = gi
+        n_groups = len(clip_groups)
+        active = [p for p in self.params if p.grad is not None]
+        if not active:
+            return []
+        active.sort(key=lambda p: gid.get(id(p), n_groups))                     # stable: every group's tensors (and blocks) are contiguous
+        grads = [p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.float().contiguous() for p in active]
+        used = sorted({gid[id(p)] for p in active if id(p) in gid})
+        slot = {g: i for i, g in enumerate(used)}                               # groups without gradients are skipped
+        key = (tuple((id(p), g.data_ptr()) for p, g in zip(active, grads)), tuple(gid.get(id(p), -1) for p in active), float(grad_scale))
+        if getattr(self, "_mt_key", None) != key:
+            coef = torch.zeros((max(len(used), 1), 2), dtype=torch.float32, device=dev)
+            plain = torch.full((1,), 1.0 / grad_scale, dtype=torch.float32, device=dev)
+            entries = np.zeros((len(active), 6), dtype=np.int64)
+            blk_t, blk_c, starts = [], [], [0] * (len(used) + 1)
+            n_grouped = 0
+            for t, (p, g) in enumerate(zip(active, grads)):
+                m, v = self.state[id(p)]
+                gs = coef.data_ptr() + 8 * slot[gid[id(p)]] if id(p) in gid else (plain.data_ptr() if grad_scale != 1.0 else 0)
+                entries[t] = (p.data.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), gs, p.numel())
+                nb = (p.numel() + self.CHUNK - 1) // self.CHUNK
+                blk_t += [t] * nb
+                blk_c += list(range(nb))
+                if id(p) in gid:
+                    n_grouped += nb
+                    starts[slot[gid[id(p)]] + 1] = n_grouped
+            self._mt = dict(coef=coef, plain=plain, entries=torch.from_numpy(entries).to(dev), blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev),
+                            blk_c=torch.tensor(blk_c, dtype=torch.int32, device=dev), starts=torch.tensor(starts, dtype=torch.int32, device=dev),
+                            partial=torch.zeros((max(n_grouped, 1),), dtype=torch.float32, device=dev), n_grouped=n_grouped, n_blocks=len(blk_t))
+            self._mt_key = key
+        mt = self._mt
+        mt["grads"] = grads                                                    # keep the gradient buffers alive until the launches ran
         rec = Recorder(dev)
-        coef_of = {}
-        norms = []
-        for group in clip_groups:
-            gs = [p for p in group if p.grad is not None]
-            if not gs:
-                continue
-            sq = rec.empty((len(gs),), torch.float32)
-            for i, p in enumerate(gs):
-                g = p.grad.contiguous().view(-1)
-                rec.hold(g)
-                rec.reduce_sumsq(g, out=sq[i:i + 1], scale=1.0 / (grad_scale * grad_scale))
-            coef = rec.empty((2,), torch.float32)
-            rec._add(rec.lib.pv_clip_coef, _ptr(sq), len(gs), float(max_norm), 1.0 / grad_scale, _ptr(coef))
-            norms.append(coef)
-            for p in gs:
-                coef_of[id(p)] = coef
-        plain = None
-        if grad_scale != 1.0:
-            plain = rec.hold(torch.full((1,), 1.0 / grad_scale, dtype=torch.float32, device=dev))
-        for p in self.params:
-            if p.grad is None:
-                continue
-            m, v = self.state[id(p)]
-            g = rec.hold(p.grad.contiguous())
-            cs = coef_of.get(id(p), plain)
-            rec._add(rec.lib.pv_adamw_step, _ptr(p.data), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(self.lr), float(self.betas[0]),
-                     float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count, _ptr(cs))
+        if used:
+            rec._add(rec.lib.pv_sumsq_multi, _ptr(mt["entries"]), _ptr(mt["blk_t"]), _ptr(mt["blk_c"]), mt["n_grouped"], self.CHUNK, _ptr(mt["partial"]))
+            rec._add(rec.lib.pv_clip_coef_groups, _ptr(mt["partial"]), _ptr(mt["starts"]), len(used), float(max_norm), 1.0 / grad_scale, _ptr(mt["coef"]))
+        rec._add(rec.lib.pv_adamw_multi, _ptr(mt["entries"]), _ptr(mt["blk_t"]), _ptr(mt["blk_c"]), mt["n_blocks"], self.CHUNK, float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count)
         rec.run()
-        return [c[1:2] for c in norms]
+        return [mt["coef"][slot[g], 1:2] for g in used]
