@@ -976,3 +976,48 @@ def test_train_cli_runs_and_writes_reference_layout_checkpoints(need_gpu, tmp_pa
                                                   vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1), seed=1)
     ia, ta, unet, lcfg = load_photoverse_model(str(tmp_path / "photoverse.pt"), ia, ta, unet)
     assert lcfg is not None and lcfg.r == 8 and lcfg.lora_dropout == pytest.approx(0.1)
+
+
+@pytest.mark.parametrize("B,ent,use_lora,face,guidance", [(1, 0, False, False, 2.0), (3, 1, False, True, 1.0), (2, 4, True, True, 7.5)])
+def test_training_step_configurations_run(need_gpu, B, ent, use_lora, face, guidance):
+    """Shapes / options beyond the parity tests: one token (extra_num_tokens = 0), odd batch, no LoRA (only adapters + to_k_ip / to_v_ip
+    train), guidance 1 (the uncond forward of the last step carries no gradient), five tokens with a large guidance: finite losses,
+    a gradient on every trainable parameter, nothing on frozen ones."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.loss import FaceLoss
+    from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.train import TrainStep
+    from oracle.unet_ref import TINY_CONFIG
+    VAE = dict(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
+    vis = dict(VIS, num_hidden_layers=max(ent, 1) + 1)
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, ent, use_lora=use_lora, lora_config=LoraConfig(r=4, lora_alpha=4, lora_dropout=0.1) if use_lora else None, unet_config=TINY_CONFIG,
+        vision_config=vis, text_config=TXT, vae_config=VAE, seed=81)
+    for m in (unet, text_encoder, image_adapter, text_adapter, vae):
+        m.to("cuda")
+    E = ent + 1
+    step = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=16, w=16, n_tokens=E, clip_tokens=17, clip_dim=256, grad_scale=512.0,
+                     face_loss=FaceLoss("cuda", "arcface") if face else None, vae=vae if face else None, noise_scheduler=scheduler, face_samples=1,
+                     guidance_scale=guidance, infer_steps=2, image_size=128)
+    g = torch.Generator().manual_seed(82)
+    fi = None
+    if face:
+        fi = dict(pixel_values=(torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).cuda(), start_latents=torch.randn(1, 4, 16, 16, generator=g).cuda(),
+                  image_embeddings=torch.randn(1, 17, 256, generator=g).half().cuda(), uncond_image_embeddings=torch.randn(1, 17, 256, generator=g).half().cuda(),
+                  text_input_ids=torch.randint(0, 1000, (1, 77), generator=g).cuda(), placeholder_idx=torch.tensor([[4]]).cuda(),
+                  uncond_input_ids=torch.randint(0, 1000, (1, 77), generator=g).cuda())
+    for it in range(2):                                   # second iteration replays the captured graphs
+        out = step.step(noisy_latents=torch.randn(B, 4, 16, 16, generator=g).cuda(), noise=torch.randn(B, 4, 16, 16, generator=g).cuda(),
+                        timesteps=torch.randint(0, 1000, (B,), generator=g), text_input_ids=torch.randint(0, 1000, (B, 77), generator=g).cuda(),
+                        placeholder_idx=torch.randint(1, 70, (B, 1), generator=g).cuda(),
+                        image_embeddings=[torch.randn(B, 17, 256, generator=g).half().cuda() for _ in range(E)], face_inputs=fi)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["loss"]).all()
+    groups = step.trainable_parameters()
+    n_lora = sum(1 for n, _ in unet.named_parameters() if "lora_" in n)
+    assert (n_lora > 0) == use_lora and len(groups["unet"]) == 8 + n_lora
+    for k, ps in groups.items():
+        for p in ps:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    trainable = {id(p) for ps in groups.values() for p in ps}
+    assert all(p.grad is None for p in unet.parameters() if id(p) not in trainable)
