@@ -498,3 +498,21 @@ def test_generate_prepare_example_from_image_file(tmp_path):
     args.synthetic_input = True
     ex2 = gen.prepare_example(args, SyntheticCLIPTokenizer())
     assert ex2["pixel_values"].abs().sum() == 0 and ex2["pixel_values_clip"].shape == (2, 3, 224, 224)
+
+
+def test_train_cli_rejects_what_it_does_not_support_and_fails_loudly_without_a_gpu():
+    """train.py (the training CLI): flags of the reference that this build cannot honour are rejected by the parser, not ignored; without a
+    HIP device the run stops with a message (no CPU fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(root, "train.py"), *a], capture_output=True, text=True, timeout=300)
+    for bad, msg in ((["--synthetic_data", "--mask_subfolder", "masks"], "masked dataset"), (["--synthetic_data", "--face_loss", "facenet"], "facenet"),
+                     (["--synthetic_data", "--gradient_accumulation_steps", "2"], "gradient_accumulation_steps"),
+                     (["--synthetic_data", "--push_to_hub"], "network"), ([], "--data_root_path"),
+                     (["--synthetic_data", "--extra_num_tokens", "2"], "image_encoder_layers_idx")):
+        r = run(*bad)
+        assert r.returncode == 2 and msg in r.stderr, (bad, r.stderr[-300:])
+    if not torch.cuda.is_available():
+        r = run("--synthetic_data", "--tiny", "--max_train_steps", "1")
+        assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
