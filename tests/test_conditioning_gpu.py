@@ -1021,3 +1021,42 @@ def test_training_step_configurations_run(need_gpu, B, ent, use_lora, face, guid
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
     trainable = {id(p) for ps in groups.values() for p in ps}
     assert all(p.grad is None for p in unet.parameters() if id(p) not in trainable)
+
+
+def test_training_step_is_bit_reproducible(need_gpu):
+    """No atomics and fixed-order reductions everywhere (split-K slabs, GroupNorm / LayerNorm partials, attention backward, weight-gradient
+    split-K, the optimizer's norms): the same inputs with the same forced fusion draws give bit-identical losses and gradients - eager
+    first iteration vs the HIP-graph replays of the next two - with the identity-loss branch switched on."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.loss import FaceLoss
+    from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.train import TrainStep
+    from oracle.unet_ref import TINY_CONFIG
+    VAE = dict(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, 2, use_lora=True, lora_config=LoraConfig(r=4, lora_alpha=4, lora_dropout=0.0), unet_config=TINY_CONFIG, vision_config=VIS,
+        text_config=TXT, vae_config=VAE, seed=91)
+    for m in (unet, text_encoder, image_adapter, text_adapter, vae):
+        m.to("cuda")
+    B, E = 2, 3
+    step = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=16, w=16, n_tokens=E, clip_tokens=17, clip_dim=256, grad_scale=512.0,
+                     face_loss=FaceLoss("cuda", "arcface"), vae=vae, noise_scheduler=scheduler, face_samples=1, infer_steps=3, image_size=128)
+    g = torch.Generator().manual_seed(92)
+    fi = dict(pixel_values=(torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).cuda(), start_latents=torch.randn(1, 4, 16, 16, generator=g).cuda(),
+              image_embeddings=torch.randn(1, 17, 256, generator=g).half().cuda(), uncond_image_embeddings=torch.randn(1, 17, 256, generator=g).half().cuda(),
+              text_input_ids=torch.randint(0, 1000, (1, 77), generator=g).cuda(), placeholder_idx=torch.tensor([[4]]).cuda(),
+              uncond_input_ids=torch.randint(0, 1000, (1, 77), generator=g).cuda(), forced_fusion=([0.5, 0.1, 0.9, 0.5], [0.9, 0.5, 0.5, 0.1]))
+    kw = dict(noisy_latents=torch.randn(B, 4, 16, 16, generator=g).cuda(), noise=torch.randn(B, 4, 16, 16, generator=g).cuda(),
+              timesteps=torch.tensor([5, 900]), text_input_ids=torch.randint(0, 1000, (B, 77), generator=g).cuda(),
+              placeholder_idx=torch.tensor([[2], [9]]).cuda(), image_embeddings=[torch.randn(B, 17, 256, generator=g).half().cuda() for _ in range(E)],
+              forced_fusion=[0.1, 0.5, 0.9, 0.5], face_inputs=fi)
+    params = [p for ps in step.trainable_parameters().values() for p in ps]
+    runs = []
+    for it in range(3):
+        out = step.step(**kw)
+        torch.cuda.synchronize()
+        runs.append((out["loss"].clone(), out["face_loss"].clone(), [p.grad.detach().clone() for p in params]))
+    assert step.graph is not None and step.face.graph is not None
+    for it in (1, 2):
+        assert torch.equal(runs[it][0], runs[0][0]) and torch.equal(runs[it][1], runs[0][1])
+        assert all(torch.equal(a, b) for a, b in zip(runs[it][2], runs[0][2])), it
