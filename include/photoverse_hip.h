@@ -138,7 +138,7 @@ typedef struct pv_attn_params {
 int pv_attention(const pv_attn_params* p, void* stream);
 
 /* Backward of pv_attention (the [EXT] AttnProcessor2_0 SDPA of attn1, models/unet.py:20-24, and the CLIP text layers the gradient
- * of text_adapter crosses, train.py:498-500).  Probabilities are recomputed from lse; delta: fp32 workspace [B][heads][nq].
+ * of text_adapter crosses, train.py:498-500).  Probabilities are recomputed from lse; delta: fp32 workspace [B][heads][nq]; qs: fp16 workspace like q.
  * dq / dk / dv: fp16 rows (may be column slices of one [dq | dk | dv] buffer).  d in {40, 64, 80, 160}.  Deterministic. */
 typedef struct pv_attn_bwd_params {
     const void* q; const void* k; const void* v;
@@ -147,6 +147,7 @@ typedef struct pv_attn_bwd_params {
     const void* dout; int32_t lddo;
     const float* lse;
     float* delta;
+    void* qs; int32_t ldqs;          /* fp16 workspace [B*nq][heads*d]: the scaled queries, written by the call */
     void* dq; void* dk; void* dv;
     int32_t lddq, lddk, lddv;
     int32_t batch, heads, nq, nk, d;

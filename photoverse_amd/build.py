@@ -19,7 +19,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 #: per-source extra flags.  The attention kernels keep MFMA results in VGPRs (the softmax VALU work reads them directly;
 #: AGPR-form costs ~200 v_accvgpr moves per tile); the 256-row GEMM variant needs the AGPR half for its accumulators.
 EXTRA_FLAGS = {"pv_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
-               "pv_xfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+               "pv_xfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+               "pv_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}   # attention backward: 136 accvgpr moves per tile otherwise
 
 
 def _hipcc() -> str:

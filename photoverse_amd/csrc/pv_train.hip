@@ -35,12 +35,17 @@ struct TileRegs {
     static constexpr int CHP = BCfg<D>::DK / 8;
     static constexpr int NI = (64 * CHP + NT - 1) / NT;
     half8_t v[NI];
+    // branch-free: always load from a clamped (valid) address, select zero afterwards - per-item exec-mask branches in the tile loop cost
+    // more than the wasted loads of the pad chunks
     __device__ __forceinline__ void gload(const half_t* g, int ld, int row0, int nrows) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int idx = threadIdx.x + i * NT;
             const int r = idx / CHP, c = idx - r * CHP;
-            v[i] = (idx < 64 * CHP && c < BCfg<D>::CH && row0 + r < nrows) ? *reinterpret_cast<const half8_t*>(g + (size_t)(row0 + r) * ld + c * 8) : tz8();
+            const bool ok = c < BCfg<D>::CH && row0 + r < nrows && (((64 * CHP) % NT == 0) || idx < 64 * CHP);
+            const int rr = min(row0 + r, nrows - 1), cc = c < BCfg<D>::CH ? c : 0;
+            const half8_t x = *reinterpret_cast<const half8_t*>(g + (size_t)rr * ld + cc * 8);
+            v[i] = ok ? x : tz8();
         }
     }
     __device__ __forceinline__ void swrite(half_t* sR, float mul) const {
@@ -48,7 +53,7 @@ struct TileRegs {
         for (int i = 0; i < NI; ++i) {
             const int idx = threadIdx.x + i * NT;
             const int r = idx / CHP, c = idx - r * CHP;
-            if (idx < 64 * CHP) {
+            if (((64 * CHP) % NT == 0) || idx < 64 * CHP) {
                 half8_t x = v[i];
                 if (mul != 1.0f) {
 #pragma unroll
@@ -68,16 +73,12 @@ __device__ __forceinline__ half8_t tfrag(const half_t* sR, int f, int s2, int fr
     const half_t* a = sR + (s2 * 32 + fq * 4 + (fr >> 2)) * C::RS + f * 16 + (fr & 3) * 4;
     const fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
     const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * C::RS));
-    half8_t r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[j] = (half_t)t1[j];
-        r[j + 4] = (half_t)t2[j];
-    }
-    return r;
+    const half4_t h1 = __builtin_bit_cast(half4_t, t1), h2 = __builtin_bit_cast(half4_t, t2);      // same bits: no per-element conversion
+    return __builtin_shufflevector(h1, h2, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// delta[b][h][q] = sum_c dO[q][c] * O[q][c]
+// delta[b][h][q] = sum_c dO[q][c] * O[q][c]; also qs = fp16(q * softmax_scale * log2 e) - the forward kernel's rounding of the scaled
+// query, written once so that the dK / dV kernel stages it without a per-tile multiply
 __global__ void attn_bwd_delta_kernel(const pv_attn_bwd_params p) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.batch * p.heads * p.nq;
@@ -85,56 +86,76 @@ __global__ void attn_bwd_delta_kernel(const pv_attn_bwd_params p) {
     const int q = (int)(idx % p.nq), h = (int)((idx / p.nq) % p.heads), b = (int)(idx / ((long)p.nq * p.heads));
     const half_t* o = reinterpret_cast<const half_t*>(p.out) + ((size_t)b * p.nq + q) * p.ldo + h * p.d;
     const half_t* g = reinterpret_cast<const half_t*>(p.dout) + ((size_t)b * p.nq + q) * p.lddo + h * p.d;
+    const half_t* qr = reinterpret_cast<const half_t*>(p.q) + ((size_t)b * p.nq + q) * p.ldq + h * p.d;
+    half_t* qs = reinterpret_cast<half_t*>(p.qs) + ((size_t)b * p.nq + q) * p.ldqs + h * p.d;
+    const float qscale = rsqrtf((float)p.d) * 1.4426950408889634f;
     float a = 0.f;
     for (int c = 0; c < p.d; c += 8) {
         const half8_t x = *reinterpret_cast<const half8_t*>(o + c), y = *reinterpret_cast<const half8_t*>(g + c);
+        const half8_t qv = *reinterpret_cast<const half8_t*>(qr + c);
+        half8_t sv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
+        for (int j = 0; j < 8; ++j) {
+            a += (float)x[j] * (float)y[j];
+            sv[j] = (half_t)((float)qv[j] * qscale);
+        }
+        *reinterpret_cast<half8_t*>(qs + c) = sv;
     }
     p.delta[idx] = a;
 }
 
-// dQ: one workgroup = 64 queries of one (sample, head) (wave w: queries 16w..16w+15 as the MFMA column), keys walked in tiles of 64.
+// dQ: one workgroup = 64 * NF queries of one (sample, head) (wave w: NF fragments of 16 queries, each the MFMA column of its own
+// products), keys walked in tiles of 64.  The K / V / K^T operand fragments read from LDS are shared by the NF query fragments - with one
+// fragment per wave the kernels are LDS-read bound (1 MFMA per KB read), two halve that.
 //   S'^T = K (q qscale)^T - lse  (log2 units)     P^T = exp2(S'^T)        dP^T = V dO^T        dS^T = P^T (dP^T - delta)
 //   dQ^T += K^T dS^T   (contraction over the 64 keys, order permuted identically on both operands)
-template <int D>
+template <int D, int NF>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_params p) {
     using C = BCfg<D>;
+    constexpr int QW = 64 * NF;                              // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sK = reinterpret_cast<half_t*>(smem);
     half_t* sV = sK + C::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int nqt = (p.nq + 63) / 64;
-    const int qt = blockIdx.x % nqt, h = (blockIdx.x / nqt) % p.heads, b = blockIdx.x / (nqt * p.heads);
+    const int nqt = (p.nq + QW - 1) / QW;
+    // XCD-aware: the query tiles of one (sample, head) get consecutive remapped ids = one XCD, whose L2 then holds that head's K / V once
+    // (spread round-robin, every XCD streams every active head: the working set of ~16 heads does not fit a 4 MB L2)
+    const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
     const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
     const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
     const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
     const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
     const float scale = rsqrtf((float)D), qscale = scale * 1.4426950408889634f;
-
-    const int qrow = qt * 64 + wave * 16 + fr;
-    const bool qok = qrow < p.nq;
-    const int qc = qok ? qrow : p.nq - 1;
-    half8_t qf[C::KSTEPS], dof[C::KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const int c = ks * 4 + fq;
-        qf[ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)qc * p.ldq + c * 8) : tz8();
-        dof[ks] = (c < C::CH && qok) ? *reinterpret_cast<const half8_t*>(DO + (size_t)qc * p.lddo + c * 8) : tz8();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * qscale);    // same fp16 rounding as the forward kernel
-    }
     const size_t bh = ((size_t)b * p.heads + h) * p.nq;
-    const float nlse = qok ? -p.lse[bh + qc] : -INFINITY;
-    const float delta = qok ? p.delta[bh + qc] : 0.f;
 
-    float4_t acc[C::DT];
+    int qrow[NF];
+    bool qok[NF];
+    half8_t qf[NF][C::KSTEPS], dof[NF][C::KSTEPS];
+    float nlse[NF], delta[NF];
+    float4_t acc[NF][C::DT];
 #pragma unroll
-    for (int f = 0; f < C::DT; ++f) acc[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int qi = 0; qi < NF; ++qi) {
+        qrow[qi] = qt * QW + (wave * NF + qi) * 16 + fr;
+        qok[qi] = qrow[qi] < p.nq;
+        const int qc = qok[qi] ? qrow[qi] : p.nq - 1;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)qc * p.ldq + c * 8) : tz8();
+            dof[qi][ks] = (c < C::CH && qok[qi]) ? *reinterpret_cast<const half8_t*>(DO + (size_t)qc * p.lddo + c * 8) : tz8();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qi][ks][j] = (half_t)((float)qf[qi][ks][j] * qscale);    // same fp16 rounding as the forward kernel
+        }
+        nlse[qi] = qok[qi] ? -p.lse[bh + qc] : -INFINITY;
+        delta[qi] = qok[qi] ? p.delta[bh + qc] : 0.f;
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) acc[qi][f] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     int ntiles = (p.nk + 63) / 64;
-    if (p.causal) ntiles = min(ntiles, min(qt * 64 + 63, p.nq - 1) / 64 + 1);
+    if (p.causal) ntiles = min(ntiles, min(qt * QW + QW - 1, p.nq - 1) / 64 + 1);
     TileRegs<D> rk, rv;
     rk.gload(Kg, p.ldk, 0, p.nk);
     rv.gload(Vg, p.ldv, 0, p.nk);
@@ -148,60 +169,77 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
             rv.gload(Vg, p.ldv, (t + 1) * 64, p.nk);
         }
         const bool masked = p.causal || (t + 1) * 64 > p.nk;
-        float4_t ds[4];
+        float4_t ds[NF][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            float4_t s = float4_t{nlse, nlse, nlse, nlse}, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+            half8_t ka[C::KSTEPS], va[C::KSTEPS];
 #pragma unroll
             for (int ks = 0; ks < C::KSTEPS; ++ks) {
-                const half8_t ka = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
-                const half8_t va = *reinterpret_cast<const half8_t*>(sV + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, dof[ks], dp, 0, 0, 0);
+                ka[ks] = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                va[ks] = *reinterpret_cast<const half8_t*>(sV + (kb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pr = PV_EXP2(s[r]);
-                if (masked) {
-                    const int key = t * 64 + kb * 16 + fq * 4 + r;
-                    if (key >= p.nk || (p.causal && key > qrow)) pr = 0.f;
+            for (int qi = 0; qi < NF; ++qi) {
+                float4_t s = float4_t{nlse[qi], nlse[qi], nlse[qi], nlse[qi]}, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[ks], qf[qi][ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[ks], dof[qi][ks], dp, 0, 0, 0);
                 }
-                ds[kb][r] = pr * (dp[r] - delta);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = PV_EXP2(s[r]);
+                    if (masked) {
+                        const int key = t * 64 + kb * 16 + fq * 4 + r;
+                        if (key >= p.nk || (p.causal && key > qrow[qi])) pr = 0.f;
+                    }
+                    ds[qi][kb][r] = pr * (dp[r] - delta[qi]);
+                }
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            half8_t bsl;
+            half8_t bsl[NF];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bsl[r] = (half_t)ds[2 * s2][r];
-                bsl[r + 4] = (half_t)ds[2 * s2 + 1][r];
-            }
+            for (int qi = 0; qi < NF; ++qi)
 #pragma unroll
-            for (int f = 0; f < C::DT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sK, f, s2, fr, fq), bsl, acc[f], 0, 0, 0);
-        }
-    }
-    if (qok) {
-        half_t* dQ = reinterpret_cast<half_t*>(p.dq) + ((size_t)b * p.nq + qrow) * p.lddq + h * D;
+                for (int r = 0; r < 4; ++r) {
+                    bsl[qi][r] = (half_t)ds[qi][2 * s2][r];
+                    bsl[qi][r + 4] = (half_t)ds[qi][2 * s2 + 1][r];
+                }
 #pragma unroll
-        for (int f = 0; f < C::DT; ++f) {
-            const int dv = f * 16 + fq * 4;
-            if (dv < D) {
-                half4_t o;
+            for (int f = 0; f < C::DT; ++f) {
+                const half8_t tk = tfrag<D>(sK, f, s2, fr, fq);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[f][r] * scale);
-                *reinterpret_cast<half4_t*>(dQ + dv) = o;
+                for (int qi = 0; qi < NF; ++qi) acc[qi][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk, bsl[qi], acc[qi][f], 0, 0, 0);
             }
         }
     }
+#pragma unroll
+    for (int qi = 0; qi < NF; ++qi)
+        if (qok[qi]) {
+            half_t* dQ = reinterpret_cast<half_t*>(p.dq) + ((size_t)b * p.nq + qrow[qi]) * p.lddq + h * D;
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) {
+                const int dv = f * 16 + fq * 4;
+                if (dv < D) {
+                    half4_t o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[qi][f][r] * scale);
+                    *reinterpret_cast<half4_t*>(dQ + dv) = o;
+                }
+            }
+        }
 }
 
-// dK, dV: one workgroup = 64 keys of one (sample, head) (wave w: keys 16w..16w+15 as the MFMA column), queries walked in tiles of 64.
+// dK, dV: one workgroup = 64 * NF keys of one (sample, head) (wave w: NF fragments of 16 keys as MFMA columns), queries walked in tiles
+// of 64; the Q / dO / Q^T / dO^T fragments read from LDS are shared by the NF key fragments.
 //   S' = (q qscale) K^T - lse      P = exp2(S')      dP = dO V^T      dS = P (dP - delta)
 //   dV^T += dO^T P      dK^T += (q qscale)^T dS / log2(e)
-template <int D>
+template <int D, int NF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_params p) {
     using C = BCfg<D>;
+    constexpr int KW = 64 * NF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sQ = reinterpret_cast<half_t*>(smem);
     half_t* sDO = sQ + C::TILE;
@@ -209,48 +247,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
     float* sDl = sL + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int nkt = (p.nk + 63) / 64;
-    const int kt = blockIdx.x % nkt, h = (blockIdx.x / nkt) % p.heads, b = blockIdx.x / (nkt * p.heads);
-    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const int nkt = (p.nk + KW - 1) / KW;
+    const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);      // one (sample, head) per XCD at a time: its Q / dO stay in that L2
+    const int kt = rid % nkt, h = (rid / nkt) % p.heads, b = rid / (nkt * p.heads);
+    const half_t* Q = reinterpret_cast<const half_t*>(p.qs) + (size_t)b * p.nq * p.ldqs + h * D;       // pre-scaled queries
     const half_t* DO = reinterpret_cast<const half_t*>(p.dout) + (size_t)b * p.nq * p.lddo + h * D;
     const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
     const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
-    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
     const size_t bh = ((size_t)b * p.heads + h) * p.nq;
+    const bool masked = p.causal || (kt + 1) * KW > p.nk;      // workgroup-uniform: some key of this workgroup needs the mask
 
-    const int key = kt * 64 + wave * 16 + fr;
-    const bool kok = key < p.nk;
-    const int kc = kok ? key : p.nk - 1;
-    half8_t kf[C::KSTEPS], vf[C::KSTEPS];
+    int key[NF];
+    bool kok[NF];
+    half8_t kf[NF][C::KSTEPS], vf[NF][C::KSTEPS];
+    float4_t accK[NF][C::DT], accV[NF][C::DT];
 #pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const int c = ks * 4 + fq;
-        kf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Kg + (size_t)kc * p.ldk + c * 8) : tz8();
-        vf[ks] = (c < C::CH && kok) ? *reinterpret_cast<const half8_t*>(Vg + (size_t)kc * p.ldv + c * 8) : tz8();
+    for (int ki = 0; ki < NF; ++ki) {
+        key[ki] = kt * KW + (wave * NF + ki) * 16 + fr;
+        kok[ki] = key[ki] < p.nk;
+        const int kc = kok[ki] ? key[ki] : p.nk - 1;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int c = ks * 4 + fq;
+            kf[ki][ks] = (c < C::CH && kok[ki]) ? *reinterpret_cast<const half8_t*>(Kg + (size_t)kc * p.ldk + c * 8) : tz8();
+            vf[ki][ks] = (c < C::CH && kok[ki]) ? *reinterpret_cast<const half8_t*>(Vg + (size_t)kc * p.ldv + c * 8) : tz8();
+        }
+#pragma unroll
+        for (int f = 0; f < C::DT; ++f) accK[ki][f] = accV[ki][f] = float4_t{0.f, 0.f, 0.f, 0.f};
     }
-    float4_t accK[C::DT], accV[C::DT];
-#pragma unroll
-    for (int f = 0; f < C::DT; ++f) accK[f] = accV[f] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nqt = (p.nq + 63) / 64;
-    const int t0 = p.causal ? (kt * 64) / 64 : 0;          // causal: queries before this key tile never see it
+    const int t0 = p.causal ? (kt * KW) / 64 : 0;          // causal: queries before this workgroup's first key never see it
     TileRegs<D> rq, rdo;
     float pl = -INFINITY, pd = 0.f;
-    auto gload_stats = [&](int t) {
-        if (tid < 64) {
-            const int qr = t * 64 + tid;
-            pl = qr < p.nq ? -p.lse[bh + qr] : -INFINITY;
-            pd = qr < p.nq ? p.delta[bh + qr] : 0.f;
-        }
+    auto gload_stats = [&](int t) {                        // every thread loads (clamped address): no exec branch in the loop
+        const int qr = t * 64 + (tid & 63), qc = min(qr, p.nq - 1);
+        const float l = p.lse[bh + qc], dd = p.delta[bh + qc];
+        pl = qr < p.nq ? -l : -INFINITY;
+        pd = qr < p.nq ? dd : 0.f;
     };
     if (t0 < nqt) {
-        rq.gload(Q, p.ldq, t0 * 64, p.nq);
+        rq.gload(Q, p.ldqs, t0 * 64, p.nq);
         rdo.gload(DO, p.lddo, t0 * 64, p.nq);
         gload_stats(t0);
     }
     for (int t = t0; t < nqt; ++t) {
         __syncthreads();
-        rq.swrite(sQ, qscale);
+        rq.swrite(sQ, 1.0f);
         rdo.swrite(sDO, 1.0f);
         if (tid < 64) {
             sL[tid] = pl;
@@ -258,72 +301,91 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
         }
         __syncthreads();
         if (t + 1 < nqt) {
-            rq.gload(Q, p.ldq, (t + 1) * 64, p.nq);
+            rq.gload(Q, p.ldqs, (t + 1) * 64, p.nq);
             rdo.gload(DO, p.lddo, (t + 1) * 64, p.nq);
             gload_stats(t + 1);
         }
-        float4_t pw[4], ds[4];
+        float4_t pw[NF][4], ds[NF][4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            float4_t s = *reinterpret_cast<const float4_t*>(sL + qb * 16 + fq * 4);
+            const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + qb * 16 + fq * 4);
             const float4_t dl = *reinterpret_cast<const float4_t*>(sDl + qb * 16 + fq * 4);
-            float4_t dp = float4_t{0.f, 0.f, 0.f, 0.f};
+            half8_t qa[C::KSTEPS], da[C::KSTEPS];
 #pragma unroll
             for (int ks = 0; ks < C::KSTEPS; ++ks) {
-                const half8_t qa = *reinterpret_cast<const half8_t*>(sQ + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
-                const half8_t da = *reinterpret_cast<const half8_t*>(sDO + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(da, vf[ks], dp, 0, 0, 0);
+                qa[ks] = *reinterpret_cast<const half8_t*>(sQ + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
+                da[ks] = *reinterpret_cast<const half8_t*>(sDO + (qb * 16 + fr) * C::RS + (ks * 4 + fq) * 8);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pr = PV_EXP2(s[r]);
-                const int qr = t * 64 + qb * 16 + fq * 4 + r;
-                if (!kok || (p.causal && key > qr)) pr = 0.f;
-                pw[qb][r] = pr;
-                ds[qb][r] = pr * (dp[r] - dl[r]);
+            for (int ki = 0; ki < NF; ++ki) {
+                float4_t s = l4, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[ks], kf[ki][ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(da[ks], vf[ki][ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = PV_EXP2(s[r]);
+                    if (masked) {
+                        const int qr = t * 64 + qb * 16 + fq * 4 + r;
+                        if (!kok[ki] || (p.causal && key[ki] > qr)) pr = 0.f;
+                    }
+                    pw[ki][qb][r] = pr;
+                    ds[ki][qb][r] = pr * (dp[r] - dl[r]);
+                }
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            half8_t bp, bs;
+            half8_t bp[NF], bs[NF];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bp[r] = (half_t)pw[2 * s2][r];
-                bp[r + 4] = (half_t)pw[2 * s2 + 1][r];
-                bs[r] = (half_t)ds[2 * s2][r];
-                bs[r + 4] = (half_t)ds[2 * s2 + 1][r];
-            }
-#pragma unroll
-            for (int f = 0; f < C::DT; ++f) {
-                accV[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sDO, f, s2, fr, fq), bp, accV[f], 0, 0, 0);
-                accK[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag<D>(sQ, f, s2, fr, fq), bs, accK[f], 0, 0, 0);
-            }
-        }
-    }
-    if (kok) {
-        half_t* dK = reinterpret_cast<half_t*>(p.dk) + ((size_t)b * p.nk + key) * p.lddk + h * D;
-        half_t* dV = reinterpret_cast<half_t*>(p.dv) + ((size_t)b * p.nk + key) * p.lddv + h * D;
-#pragma unroll
-        for (int f = 0; f < C::DT; ++f) {
-            const int dv = f * 16 + fq * 4;
-            if (dv < D) {
-                half4_t ok_, ov;
+            for (int ki = 0; ki < NF; ++ki)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    ok_[r] = (half_t)(accK[f][r] * 0.6931471805599453f);
-                    ov[r] = (half_t)accV[f][r];
+                    bp[ki][r] = (half_t)pw[ki][2 * s2][r];
+                    bp[ki][r + 4] = (half_t)pw[ki][2 * s2 + 1][r];
+                    bs[ki][r] = (half_t)ds[ki][2 * s2][r];
+                    bs[ki][r + 4] = (half_t)ds[ki][2 * s2 + 1][r];
                 }
-                *reinterpret_cast<half4_t*>(dK + dv) = ok_;
-                *reinterpret_cast<half4_t*>(dV + dv) = ov;
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) {
+                const half8_t td = tfrag<D>(sDO, f, s2, fr, fq), tq = tfrag<D>(sQ, f, s2, fr, fq);
+#pragma unroll
+                for (int ki = 0; ki < NF; ++ki) {
+                    accV[ki][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(td, bp[ki], accV[ki][f], 0, 0, 0);
+                    accK[ki][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tq, bs[ki], accK[ki][f], 0, 0, 0);
+                }
             }
         }
     }
+#pragma unroll
+    for (int ki = 0; ki < NF; ++ki)
+        if (kok[ki]) {
+            half_t* dK = reinterpret_cast<half_t*>(p.dk) + ((size_t)b * p.nk + key[ki]) * p.lddk + h * D;
+            half_t* dV = reinterpret_cast<half_t*>(p.dv) + ((size_t)b * p.nk + key[ki]) * p.lddv + h * D;
+#pragma unroll
+            for (int f = 0; f < C::DT; ++f) {
+                const int dv = f * 16 + fq * 4;
+                if (dv < D) {
+                    half4_t ok_, ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ok_[r] = (half_t)(accK[ki][f][r] * 0.6931471805599453f);
+                        ov[r] = (half_t)accV[ki][f][r];
+                    }
+                    *reinterpret_cast<half4_t*>(dK + dv) = ok_;
+                    *reinterpret_cast<half4_t*>(dV + dv) = ov;
+                }
+            }
+        }
 }
 
 template <int D>
 int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
     using C = BCfg<D>;
+    // fragments per wave: 2 where the accumulators fit (d <= 80) and the sequence is long enough to keep >= 2 workgroups per CU busy
+    constexpr int NFMAX = D <= 80 ? 2 : 1;
     constexpr int smem_dq = 2 * C::TILE * 2;
     constexpr int smem_dkv = 2 * C::TILE * 2 + 128 * 4;
     static bool attr_set_dev[64] = {};
@@ -331,16 +393,24 @@ int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
-        if (e != hipSuccess) return (int)e;
+        const void* fns[4] = {reinterpret_cast<const void*>(attn_bwd_dq_kernel<D, 1>), reinterpret_cast<const void*>(attn_bwd_dq_kernel<D, NFMAX>),
+                              reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, 1>), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, NFMAX>)};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? smem_dq : smem_dkv);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     const long rows = (long)p.batch * p.heads * p.nq;
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3((unsigned)(((p.nk + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dkv, s, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)(((p.nq + 63) / 64) * p.heads * p.batch)), dim3(256), smem_dq, s, p);
+    const long bh = (long)p.batch * p.heads;
+    static const int nf_env = getenv("PV_ATTN_BWD_NF") ? atoi(getenv("PV_ATTN_BWD_NF")) : -1;      // experiments: bit 0 = dK/dV, bit 1 = dQ
+    const bool big = NFMAX == 2 && bh * ((p.nk + 127) / 128) >= 1024 && bh * ((p.nq + 127) / 128) >= 1024;
+    const bool two_kv = big && (nf_env < 0 ? D == 40 : (nf_env & 1)), two_q = big && (nf_env < 0 ? D == 40 : (nf_env & 2));
+    if (two_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, NFMAX>), dim3((unsigned)(((p.nk + 127) / 128) * bh)), dim3(256), smem_dkv, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, 1>), dim3((unsigned)(((p.nk + 63) / 64) * bh)), dim3(256), smem_dkv, s, p);
+    if (two_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, NFMAX>), dim3((unsigned)(((p.nq + 127) / 128) * bh)), dim3(256), smem_dq, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, 1>), dim3((unsigned)(((p.nq + 63) / 64) * bh)), dim3(256), smem_dq, s, p);
     return PV_CHECK_LAUNCH();
 }
 
@@ -1216,9 +1286,9 @@ extern "C" int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* s
 }
 
 extern "C" int pv_attention_backward(const pv_attn_bwd_params* p, void* stream) {
-    if (!p || !p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->delta || !p->dq || !p->dk || !p->dv) return (int)hipErrorInvalidValue;
+    if (!p || !p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->delta || !p->qs || !p->dq || !p->dk || !p->dv) return (int)hipErrorInvalidValue;
     if (p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nk <= 0) return (int)hipErrorInvalidValue;
-    if ((p->ldq | p->ldk | p->ldv | p->ldo | p->lddo | p->lddq | p->lddk | p->lddv) % 8) return (int)hipErrorInvalidValue;
+    if ((p->ldq | p->ldk | p->ldv | p->ldo | p->lddo | p->lddq | p->lddk | p->lddv | p->ldqs) % 8) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     switch (p->d) {
         case 40: return launch_attn_bwd<40>(*p, s);

@@ -222,8 +222,9 @@ class Recorder:
         dk = self.empty((batch * nk, C_)) if dk is None else dk
         dv = self.empty((batch * nk, C_)) if dv is None else dv
         delta = self.empty((batch, heads, nq), torch.float32)
+        qs = self.empty((batch * nq, C_))
         p = AttnBwdParams(_ptr(q), _ptr(k), _ptr(v), _rows(q)[0], _rows(k)[0], _rows(v)[0], _ptr(out), _rows(out)[0], _ptr(dout), _rows(dout)[0],
-                          _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
+                          _ptr(lse), _ptr(delta), _ptr(qs), C_, _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
                           int(causal))
         self.keep.extend((q, k, v, out, dout, lse, dq, dk, dv))
         self._add(self.lib.pv_attention_backward, p)
