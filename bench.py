@@ -21,7 +21,7 @@ if ROOT not in sys.path:
 # analytic algorithmic FLOPs of one SD-v1.5 UNet forward per sample at 64x64 latents, P=1
 UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-DOMINANT_KERNEL = "gemm_conv_kernel<5, true, false, true, false>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
+DOMINANT_KERNEL = "gemm_conv_kernel<5, true, false, true, false, 4>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
 
 
 def cpu_baseline(seconds_budget=40.0):

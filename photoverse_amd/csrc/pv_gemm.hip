@@ -32,9 +32,9 @@ struct pv_gemm_params_dev : pv_gemm_params {
 };
 
 // 128-row tile, wave tile 64 x BN/2, 2 LDS stages, 2 workgroups / CU (two waves per SIMD)
-template <int NF>
+template <int NF, int MIV = 4>
 struct TileCfg {
-    static constexpr int MI = 4;                   // 16-row M fragments per wave
+    static constexpr int MI = MIV;                 // 16-row M fragments per wave (4: 128-row tile; 2: 64-row tile for HBM-bound Linear layers)
     static constexpr int BM = 2 * MI * 16;
     static constexpr int BN = NF * 32;
     static constexpr int NWAVES = 4;               // 2 x 2 waves
@@ -79,11 +79,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // CS: instantiation whose epilogue also produces the GroupNorm column statistics (pv_gemm_params.colstats).  Separate from the
 // plain kernel because the extra 40 accumulators cost the launches that do not want them 2-3 %.
-template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false>
-__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
+template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false, int MIV = 4>
+__global__ __launch_bounds__(256, MIV == 4 ? 2 : 3) void gemm_conv_kernel(const pv_gemm_params_dev p, const int tiles_n,
                                                                               const int nblk, const int order, const int tpw_arg) {
     const int tpw = MULTI ? tpw_arg : 1;        // MULTI = false: the straight one-tile kernel (the tile loop folds away)
-    using Cfg = TileCfg<NF>;
+    using Cfg = TileCfg<NF, MIV>;
+    static_assert(MIV == 4 || (!CS && !MULTI && !CONV), "the 64-row tile exists for plain Linear layers only");
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NWAVES;
     constexpr int MI = Cfg::MI;
@@ -520,14 +521,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const pv_gemm_params
     }
 }
 
-template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false>
+template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false, int MIV = 4>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream, int tpw = 1) {
-    using Cfg = TileCfg<NF>;
+    using Cfg = TileCfg<NF, MIV>;
     static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI>;
+    auto kern = gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MIV>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::SMEM_BYTES);
@@ -548,7 +549,8 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream, int tpw = 1) {
     return PV_CHECK_LAUNCH();
 }
 
-// One tile shape (128 x BN x 64, two workgroups per CU) for every layer: larger tiles lost on every UNet shape (see the header).
+// One tile shape (128 x BN x 64, two workgroups per CU) for every layer but the small Linear ones (64 x BN x 64, below): larger tiles lost
+// on every UNet shape (see the header).
 // tiles per workgroup: the shortest-K GEGLU layers (K = 320: five K-steps per tile, 10240 tiles at bs = 16) let one workgroup walk
 // several N-tiles with a continuous K pipeline, as long as the launch keeps >= 1024 workgroups.  Measured (kbench, MI355X): -4 % at
 // K = 320 (181.5 -> 174.6 us), nothing at K = 640, +6 % at K = 1280 - so only nk <= 5 uses it.
@@ -564,7 +566,8 @@ int choose_tpw(const pv_gemm_params_dev& p) {
     return 1;
 }
 
-// One tile shape (128 x BN x 64, two workgroups per CU) for every layer: larger tiles lost on every UNet shape (see the header).
+// One tile shape (128 x BN x 64, two workgroups per CU) for every layer but the small Linear ones (64 x BN x 64, below): larger tiles lost
+// on every UNet shape (see the header).
 template <int NF, bool CONV, bool GEGLU>
 int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
     if constexpr (!CONV && GEGLU) {       // the plain-epilogue instantiations spill with the tile loop (NF = 5: 300+ B of scratch): GEGLU only
@@ -573,6 +576,14 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
     }
     if constexpr (!GEGLU) {
         if (p.colstats && !(p.splitk > 1 && p.splitk_ws)) return launch<NF, CONV, false, true>(p, stream);   // split-K: the reduce launch makes them
+    }
+    if constexpr (!CONV && !GEGLU) {
+        // 64-row tiles for the Linear layers whose 128-row tiling leaves the chip under two workgroups per CU (M = 4096 rows x N = 1280 at
+        // the 16x16 level, the text / image-token K,V projections, CLIP / adapter layers): 4096x1280->1280 30.0 -> 25.8 us, 1232x768->640
+        // 15.8 -> 10.4 us.  With >= 512 tiles the 128-row tile wins (65536x320->960: 70.8 vs 88.1 us).  PV_GEMM_MI2: 0 = never, N = below N tiles.
+        static const int mi2_env = getenv("PV_GEMM_MI2") ? atoi(getenv("PV_GEMM_MI2")) : 512;
+        const long tiles128 = (long)((p.M + 127) / 128) * (p.N / (NF * 32));
+        if (!(p.splitk > 1 && p.splitk_ws) && tiles128 < mi2_env) return launch<NF, false, false, false, false, 2>(p, stream);
     }
     return launch<NF, CONV, GEGLU>(p, stream);
 }

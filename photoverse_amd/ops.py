@@ -159,14 +159,15 @@ class Recorder:
                        _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
-        # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI>
+        # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MI>
         # (MULTI = the tile-loop instantiation pv_gemm.hip's choose_tpw picks for the short-K GEGLU layers with >= 1024 workgroups)
         multi = False
         if geglu and conv is None:
             tiles_n, nblk = N // (nf * 32), ((M + 127) // 128) * (N // (nf * 32))
             multi = any(tiles_n % c == 0 and kdim // 64 <= 5 and nblk // c >= 1024 for c in range(2, 9))
+        mi = 2 if (conv is None and not geglu and cs is None and splitk == 1 and ((M + 127) // 128) * (N // (nf * 32)) < 512) else 4
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
-                f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}>")
+                f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 

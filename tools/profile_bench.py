@@ -13,7 +13,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "prof_bench")
 steps = sys.argv[1] if len(sys.argv) > 1 else "5"
-DOM = "gemm_conv_kernel<5, true, false, true, false>"
+DOM = "gemm_conv_kernel<5, true, false, true, false, 4>"
 env = dict(os.environ, TMPDIR="/tmp")
 base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "2", "--no-cpu-baseline", "--no-train-forward"]
 
