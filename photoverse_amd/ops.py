@@ -23,7 +23,7 @@ ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
 import os as _os
 #: split-K heuristic: split until about SPLITK_TARGET workgroups exist (2 per CU), at most SPLITK_MAX ways
-SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "8"))
+SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "4"))      # same-box sweep (bench, two branches): 4 -> 28.09, 8 -> 27.76, 3 -> 27.91, 2 -> 27.41 steps/s
 SPLITK_TARGET = int(_os.environ.get("PV_SPLITK_TARGET", "512"))
 
 
