@@ -504,9 +504,9 @@ class TrainStep:
         ip_rows = Var(ip.t.view(B * self.E, -1), True)
 
         def ip_rows_bwd():
-            if ip_rows.g is not None:
-                g = ip_rows.g if ip_rows.g.is_contiguous() else rb.add_rows(ip_rows.g, torch.zeros_like(ip_rows.t))
-                tp._accum(ip, g.view(B, -1))
+            if ip_rows.g is not None:                         # the sum of the 16 layers' K / V projection data gradients: a GEMM output
+                assert ip_rows.g.is_contiguous()
+                tp._accum(ip, ip_rows.g.view(B, -1))
         tp.back.append(ip_rows_bwd)
         self.text_states, self.ip_states = text, ip_rows
 
