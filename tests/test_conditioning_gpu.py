@@ -345,15 +345,17 @@ def test_adamw_and_clip_match_torch(grad_scale):
             assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
 
 
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop):
+@pytest.mark.parametrize("p_drop,hw", [(0.0, 16), (0.1, 16), (0.0, 20)])
+def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     """The whole backward of a training step (train.py:495-536 without the optional face loss) on the HIP plans: gradient of
     mse + 0.01 |concept| + 0.001 ||V_ip|| w.r.t. every trainable parameter - both adapters (through the UNet's cross-attention layers;
     the text adapter additionally through the CLIP text encoder), to_k_ip / to_v_ip of every processor and the LoRA factors behind
     attn2.to_q / to_k / to_v - against torch autograd over the fp32 oracle composition with the same forced fusion draws.  Then one
     AdamW step with the reference's per-module gradient clipping, against torch.optim.AdamW on the oracle.
     p_drop = 0.1: the reference's default lora_dropout (train.py:265) - the low-rank branches run un-merged with the device-side dropout;
-    the oracle applies the SAME keep masks (rebuilt from the counter-based generator after the step)."""
+    the oracle applies the SAME keep masks (rebuilt from the counter-based generator after the step).
+    hw = 20: ragged everything - 400 / 100 tokens (attention tiles of 64 / 128 with tails, GroupNorm statistics without the 64-row column
+    statistics, conv / GEMM row tails)."""
     import torch.nn.functional as F
     from oracle.adapters_ref import PhotoVerseAdapterRef
     from oracle.clip_ref import CLIPTextModelRef
@@ -387,15 +389,15 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop):
     for n in train_names:
         r_params[n].requires_grad_(True)
 
-    noisy = torch.randn(B, 4, 16, 16, generator=g)
-    noise = torch.randn(B, 4, 16, 16, generator=g)
+    noisy = torch.randn(B, 4, hw, hw, generator=g)
+    noise = torch.randn(B, 4, hw, hw, generator=g)
     timesteps = torch.tensor([731, 42])
     ids = torch.randint(0, 1000, (B, 77), generator=g)
     pidx = torch.tensor([[5], [3]])
     embs = [(torch.randn(B, T, D, generator=g)).half() for _ in range(ENT + 1)]
     forced = [0.1, 0.5, 0.9, 0.4]
 
-    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=16, w=16, n_tokens=ENT + 1, clip_tokens=T, clip_dim=D,
+    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=hw, w=hw, n_tokens=ENT + 1, clip_tokens=T, clip_dim=D,
                    grad_scale=1024.0, fusion_seed=3)
     out = ts.step(noisy_latents=noisy.cuda(), noise=noise.cuda(), timesteps=timesteps, text_input_ids=ids.cuda(), placeholder_idx=pidx.cuda(),
                   image_embeddings=[e.cuda() for e in embs], forced_fusion=forced)
@@ -410,7 +412,7 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop):
         rec = Recorder("cuda")
         got = []
         for site, copies, cols, p in ts.dropout_sites:
-            rows = B * 77 if copies == 2 else {320: B * 256, 640: B * 64}[cols]
+            rows = B * 77 if copies == 2 else {320: B * hw * hw, 640: B * hw * hw // 4}[cols]
             got.append((site, copies, cols, rec.dropout(torch.ones(rows, cols, dtype=torch.float16, device="cuda"), p=p, rng=ts.fusion_rng, site=site,
                                                         copies=copies)))
         rec.run()
