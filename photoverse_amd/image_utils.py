@@ -72,3 +72,36 @@ def to_pil(image: torch.Tensor):
     from PIL import Image
     arr = image.detach().float().cpu().permute(1, 2, 0).numpy()
     return Image.fromarray((arr * 255).round().astype("uint8"))
+
+
+def denormalize_clip(image: torch.Tensor, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """CLIP-normalised pixels -> [0, 1] (``utils/image_utils.py:14-21``)."""
+    m = torch.tensor(mean, dtype=image.dtype, device=image.device)[:, None, None]
+    s = torch.tensor(std, dtype=image.dtype, device=image.device)[:, None, None]
+    return (image * s + m).clamp(0, 1)
+
+
+def save_images_grid(grid_data, img_grid_file, header: int = 50):
+    """``grid_data``: [(column title, [PIL images])], one column per entry, one row per sample; a white header strip carries the titles
+    (``{}`` in a title becomes ``S*``).  The layout of ``utils/image_utils.py:32-69`` (train.py:549-596 writes one per sample step)."""
+    from PIL import Image, ImageDraw, ImageFont
+    titles = [t for t, _ in grid_data]
+    columns = [imgs for _, imgs in grid_data]
+    rows = [np.concatenate([np.asarray(im.convert("RGB")) for im in row], axis=1) for row in zip(*columns)]
+    arr = np.pad(np.concatenate(rows, axis=0), ((header, 0), (0, 0), (0, 0)), mode="constant", constant_values=255)
+    grid = Image.fromarray(arr.astype("uint8"), "RGB")
+    draw = ImageDraw.Draw(grid)
+    try:
+        font = ImageFont.truetype("arial.ttf", 36)
+    except IOError:
+        try:
+            font = ImageFont.load_default(size=36)
+        except TypeError:                                   # older Pillow: fixed-size bitmap font
+            font = ImageFont.load_default()
+    width = columns[0][0].width
+    for i, text in enumerate(titles):
+        text = text.format("S*")
+        x1, y1, x2, y2 = font.getbbox(text)
+        draw.text(((width - (x2 - x1)) // 2 + i * width, (header - (y2 - y1)) // 2), text, font=font, fill="black")
+    grid.save(img_grid_file)
+    return grid

@@ -961,14 +961,19 @@ def test_train_cli_runs_and_writes_reference_layout_checkpoints(need_gpu, tmp_pa
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "train.py"), "--pretrained_model_name_or_path", "random", "--tiny", "--synthetic_data",
            "--max_train_steps", "3", "--train_batch_size", "2", "--resolution", "128", "--extra_num_tokens", "2", "--image_encoder_layers_idx", "1", "2",
-           "--use_lora", "--checkpoint_save_steps", "2", "--output_dir", str(tmp_path), "--seed", "7", "--lr_scheduler", "constant_with_warmup",
+           "--use_lora", "--checkpoint_save_steps", "2", "--samples_save_steps", "2", "--denoise_timesteps", "3", "--num_of_samples_to_save", "2",
+           "--output_dir", str(tmp_path), "--seed", "7", "--lr_scheduler", "constant_with_warmup",
            "--lr_warmup_steps", "2", "--learning_rate", "1e-4"] + (["--face_loss", "arcface"] if face else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("step ")]
-    assert len(lines) == 3 and "loss_mle=" in lines[0] and ("loss_face=" in lines[0]) == face
+    lines = [l for l in r.stdout.splitlines() if l.startswith("step ") and "loss_mle=" in l]
+    assert len(lines) == 3 and ("loss_face=" in lines[0]) == face
     assert "lr=0," in lines[0].replace(" ", "") or "lr=0" in lines[0]          # warm-up: first step at lr 0, then 5e-5, then 1e-4
     assert os.path.exists(tmp_path / "photoverse_000002.pt") and os.path.exists(tmp_path / "photoverse.pt")
+    from PIL import Image
+    grid = Image.open(tmp_path / "00002.jpg")               # input | condition | generated, two samples, 50-pixel title strip
+    assert grid.size == (3 * 128, 2 * 128 + 50)
+    assert ("face_similarity=" in r.stdout) == face
     sd = torch.load(tmp_path / "photoverse.pt", map_location="cpu")
     assert set(sd) >= {"image_adapter", "text_adapter", "cross_attention_adapter", "lora_config", "optimizer"}
     assert any("lora_A" in k for k in sd["cross_attention_adapter"]) and any("to_k_ip" in k for k in sd["cross_attention_adapter"])

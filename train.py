@@ -4,7 +4,8 @@
 Same flags and defaults for everything the hot path consumes (``train.py:37-285`` of the reference): model / checkpoint paths, AdamW
 hyper-parameters, LoRA (``--use_lora --lora_rank --lora_alpha --lora_dropout``), ``--extra_num_tokens`` / ``--image_encoder_layers_idx``,
 ``--face_loss arcface --face_loss_sample_ratio``, ``--guidance_scale``, ``--lr_scheduler`` / ``--lr_warmup_steps``,
-``--checkpoint_save_steps``, ``--max_train_steps``.  One iteration = ``photoverse_amd.train.training_iteration`` (``train.py:464-549``):
+``--checkpoint_save_steps``, ``--samples_save_steps`` / ``--denoise_timesteps`` / ``--num_of_samples_to_save`` (sample grids through
+``run_inference``, ``train.py:549-596``), ``--max_train_steps``.  One iteration = ``photoverse_amd.train.training_iteration`` (``train.py:464-549``):
 forward + backward launch plans on the HIP kernels, per-module gradient clipping and AdamW on the device; checkpoints in the reference's
 ``photoverse_XXXXXX.pt`` layout (``models/modeling_utils.py:29-50``), loadable by both code bases.
 
@@ -57,6 +58,9 @@ def parse_args():
     p.add_argument("--train_batch_size", type=int, default=4)
     p.add_argument("--dataloader_num_workers", type=int, default=4)
     p.add_argument("--checkpoint_save_steps", type=int, default=2000)
+    p.add_argument("--samples_save_steps", type=int, default=500, help="write a sample grid (input | condition | generated) every N steps; 0 = never")
+    p.add_argument("--denoise_timesteps", type=int, default=25)
+    p.add_argument("--num_of_samples_to_save", type=int, default=5)
     p.add_argument("--mixed_precision", type=str, default=None)
     p.add_argument("--gradient_accumulation_steps", type=int, default=1)
     p.add_argument("--extra_num_tokens", type=int, default=4)
@@ -157,6 +161,26 @@ def collate(examples):                                      # datasets/utils.py 
     return {k: torch.stack([e[k] for e in examples]) for k in examples[0]}
 
 
+def save_samples(args, global_step, batch, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, noise_scheduler, device, face):
+    """A grid of input / condition / generated images for the current batch with the weights as they are now (train.py:555-596)."""
+    from photoverse_amd.image_utils import denormalize, denormalize_clip, save_images_grid, to_pil
+    from photoverse_amd.infer import run_inference
+    n = min(args.num_of_samples_to_save, batch["pixel_values"].shape[0])
+    unet.repack()                                           # the inference engines bake fp16 copies of the weights: rebuild from the trained ones
+    example = {k: (v[:n] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        gen = run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, noise_scheduler, device,
+                            args.image_encoder_layers_idx, latent_size=args.resolution // 8, guidance_scale=args.guidance_scale,
+                            timesteps=args.denoise_timesteps, token_index=0, disable_tqdm=True)
+    if face is not None:
+        sim = float(face(example["pixel_values"].to(device, torch.float32), gen.float(), normalize=False, maximize=False))
+        print(f"step {global_step}: face_similarity={sim:.4f}", flush=True)
+    grid = [("Input Images", [to_pil(denormalize(i)) for i in example["pixel_values"]]),
+            ("Condition Images", [to_pil(denormalize_clip(i)).resize((args.resolution, args.resolution)) for i in example["pixel_values_clip"]]),
+            ("a photo of {}", [to_pil(denormalize(i)) for i in gen.float().cpu()])]
+    save_images_grid(grid, os.path.join(args.output_dir, f"{str(global_step).zfill(5)}.jpg"))
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -224,6 +248,9 @@ def main():
             if face is not None:
                 logs["loss_face"] = float(out["face_loss"])
             print(f"step {global_step}: " + ", ".join(f"{k}={v:.6g}" for k, v in logs.items()), flush=True)
+            if args.samples_save_steps and global_step % args.samples_save_steps == 0:                                            # train.py:555-596
+                save_samples(args, global_step, batch, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae,
+                             noise_scheduler, device, face)
             if global_step % args.checkpoint_save_steps == 0:
                 save_progress(image_adapter, text_adapter, unet, None, args.output_dir, step=global_step, lora_config=lora_config, optimizer=optimizer)
             if global_step >= args.max_train_steps:
