@@ -722,9 +722,12 @@ class TrainStep:
         return {"text_adapter": list(self.text_adapter.parameters()), "image_adapter": list(self.image_adapter.parameters()), "unet": un}
 
     @torch.no_grad()
-    def step(self, *, noisy_latents, noise, timesteps, text_input_ids, placeholder_idx, image_embeddings, forced_fusion=None, face_inputs=None):
+    def step(self, *, noisy_latents, noise, timesteps, text_input_ids, placeholder_idx, image_embeddings, forced_fusion=None, face_inputs=None,
+             accumulate: bool = False):
         """Fill the static inputs, replay forward + backward, set ``.grad`` (= gradient x ``grad_scale``).  Returns the loss terms.
-        ``face_inputs`` (see ``_run_face``): required when the step was built with a face loss."""
+        ``face_inputs`` (see ``_run_face``): required when the step was built with a face loss.  ``accumulate``: ADD this micro-batch's
+        gradients to the ones of the previous calls (``accelerator.accumulate``, train.py:464) in persistent fp32 accumulators; the first
+        micro-batch of an update is a call with ``accumulate=False``; divide by the count through the optimizer's ``grad_scale``."""
         if (self.face is None) != (face_inputs is None):
             raise ValueError("face_inputs must be given exactly when the TrainStep was built with face_loss")
         self.noisy.copy_(noisy_latents)
@@ -758,12 +761,24 @@ class TrainStep:
         if self.face is not None:
             self._run_face(face_inputs)
         seen = set()
+        if accumulate:                                          # keep the running sums: the plan buffers are rewritten by the next replay
+            if not hasattr(self, "_accum"):
+                raise RuntimeError("accumulate=True needs a preceding step(accumulate=False) of the same update")
+            seen = set(self._accum)                              # every parameter already has a gradient: _give adds
+            for pid, acc in self._accum.items():
+                self._accum_params[pid].grad = acc
         for param, buf in self.pgrads:                          # a parameter used by several passes has several buffers: summed here
             self._give(param, buf() if callable(buf) else buf.view(param.shape), seen)
         for mod, dW in self.lora_pending:                       # rank-r factor gradients from the merged-weight gradient
             A, Bm = mod.lora_A["default"].weight, mod.lora_B["default"].weight
             self._give(A, mod.scaling * (Bm.detach().t() @ dW), seen)
             self._give(Bm, mod.scaling * (dW @ A.detach().t()), seen)
+        # gradients that may be needed after the next replay (accumulation) live in buffers of their own
+        self._accum, self._accum_params = {}, {}
+        for ps in self.trainable_parameters().values():
+            for prm in ps:
+                if prm.grad is not None:
+                    self._accum[id(prm)], self._accum_params[id(prm)] = prm.grad, prm
         out = {"loss": self.loss, "diffusion_loss": self.terms[0:1], "concept_text_loss": self.terms[1:2],
                "cross_attn_visual_loss": self.terms[2:3], "noise_pred": self.noise_pred, "fusion_table": self.fusion_tab}
         if self.face is not None:
@@ -790,12 +805,15 @@ class TrainStep:
 
 @torch.no_grad()
 def training_iteration(step: TrainStep, optimizer, batch, tokenizer, image_encoder, vae, noise_scheduler, device, image_encoder_layers_idx,
-                       extra_num_tokens: int, *, generator: Optional[torch.Generator] = None, max_grad_norm: float = 1.0):
+                       extra_num_tokens: int, *, generator: Optional[torch.Generator] = None, max_grad_norm: float = 1.0, micro_step: int = 0,
+                       accumulation_steps: int = 1):
     """The body of the reference's training loop (``train.py:464-549``) on top of ``TrainStep``: the frozen, gradient-free part with this
     package's inference modules - VAE encode + posterior sample (``:471-472``), noise / per-sample timesteps / add_noise (``:475-484``), CLIP
     image features (``:487-492``) and, with a face loss, the inputs of ``run_inference(sliced_batch, ...)`` (``:522-530``, ``infer.py:42-84``:
     the "a photo of *" prompt, a random subset of the batch, its latents noised to the first inference timestep, the zero-image features) -
-    then the forward + backward plans and the clipped AdamW update (``:536-547``).  Returns the loss terms of the step."""
+    then the forward + backward plans and the clipped AdamW update (``:536-547``).  Returns the loss terms of the step.
+    ``accumulation_steps`` > 1 (``--gradient_accumulation_steps``): micro-batch ``micro_step`` of that many; gradients are summed, the optimizer
+    runs after the last one on their mean (accelerate scales each micro-batch's loss by 1 / steps)."""
     device = torch.device(device)
     pixel_values = batch["pixel_values"].to(device, dtype=torch.float32)
     pixel_values_clip = batch["pixel_values_clip"].to(device, dtype=torch.float32)
@@ -837,8 +855,26 @@ def training_iteration(step: TrainStep, optimizer, batch, tokenizer, image_encod
                            uncond_image_embeddings=ufeats[0], text_input_ids=ids.to(device), placeholder_idx=pidx.to(device),
                            uncond_input_ids=uids.to(device))
     out = step.step(noisy_latents=noisy_latents, noise=noise, timesteps=timesteps, text_input_ids=batch["text_input_ids"].to(device),
-                    placeholder_idx=batch["concept_placeholder_idx"].to(device), image_embeddings=image_embeddings, face_inputs=face_inputs)
+                    placeholder_idx=batch["concept_placeholder_idx"].to(device), image_embeddings=image_embeddings, face_inputs=face_inputs,
+                    accumulate=micro_step > 0)
+    if micro_step + 1 < accumulation_steps:
+        if micro_step == 0 and accumulation_steps > 1:
+            _detach_grads(step)                              # the first micro-batch's gradients alias plan buffers the next replay rewrites
+        return out
     groups = step.trainable_parameters()
-    out["grad_norms"] = optimizer.step(clip_groups=list(groups.values()), max_norm=max_grad_norm, grad_scale=step.grad_scale)
+    out["grad_norms"] = optimizer.step(clip_groups=list(groups.values()), max_norm=max_grad_norm, grad_scale=step.grad_scale * accumulation_steps)
     optimizer.zero_grad()
     return out
+
+
+def _detach_grads(step: TrainStep):
+    """Copy every gradient out of the plan's buffers (fp32 row-affine kernel as the copy) so that it survives the next replay."""
+    rec = Recorder(step.noisy.device)
+    one = rec.hold(torch.ones((1,), dtype=torch.float32, device=step.noisy.device))
+    new = {}
+    for pid, g in step._accum.items():
+        new[pid] = rec.affine_rows(g.reshape(1, -1).contiguous(), one).view(g.shape)
+    rec.run()
+    for pid, g in new.items():
+        step._accum[pid] = g
+        step._accum_params[pid].grad = g

@@ -963,7 +963,7 @@ def test_train_cli_runs_and_writes_reference_layout_checkpoints(need_gpu, tmp_pa
            "--max_train_steps", "3", "--train_batch_size", "2", "--resolution", "128", "--extra_num_tokens", "2", "--image_encoder_layers_idx", "1", "2",
            "--use_lora", "--checkpoint_save_steps", "2", "--samples_save_steps", "2", "--denoise_timesteps", "3", "--num_of_samples_to_save", "2",
            "--output_dir", str(tmp_path), "--seed", "7", "--lr_scheduler", "constant_with_warmup",
-           "--lr_warmup_steps", "2", "--learning_rate", "1e-4"] + (["--face_loss", "arcface"] if face else [])
+           "--lr_warmup_steps", "2", "--learning_rate", "1e-4"] + (["--face_loss", "arcface"] if face else ["--gradient_accumulation_steps", "2"])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("step ") and "loss_mle=" in l]
@@ -1067,3 +1067,36 @@ def test_training_step_is_bit_reproducible(need_gpu):
     for it in (1, 2):
         assert torch.equal(runs[it][0], runs[0][0]) and torch.equal(runs[it][1], runs[0][1])
         assert all(torch.equal(a, b) for a, b in zip(runs[it][2], runs[0][2])), it
+
+
+def test_gradient_accumulation_sums_micro_batches(need_gpu):
+    """accelerator.accumulate (train.py:464, --gradient_accumulation_steps): two micro-batches through step(accumulate=...) leave the SUM of
+    their gradients (the optimizer divides by the count through grad_scale); compared with the two gradients taken separately."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_models
+    from photoverse_amd.train import TrainStep, _detach_grads
+    from oracle.unet_ref import TINY_CONFIG
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, 1, use_lora=True, lora_config=LoraConfig(r=4, lora_alpha=4, lora_dropout=0.0), unet_config=TINY_CONFIG, vision_config=VIS,
+        text_config=TXT, vae_config=dict(block_out_channels=(128, 128, 128, 128), layers_per_block=1), seed=95)
+    for m in (unet, text_encoder, image_adapter, text_adapter):
+        m.to("cuda")
+    B, E = 2, 2
+    step = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=16, w=16, n_tokens=E, clip_tokens=17, clip_dim=256, grad_scale=512.0)
+    g = torch.Generator().manual_seed(96)
+    mk = lambda: dict(noisy_latents=torch.randn(B, 4, 16, 16, generator=g).cuda(), noise=torch.randn(B, 4, 16, 16, generator=g).cuda(),
+                      timesteps=torch.randint(0, 1000, (B,), generator=g), text_input_ids=torch.randint(0, 1000, (B, 77), generator=g).cuda(),
+                      placeholder_idx=torch.randint(1, 70, (B, 1), generator=g).cuda(),
+                      image_embeddings=[torch.randn(B, 17, 256, generator=g).half().cuda() for _ in range(E)], forced_fusion=[0.5, 0.1, 0.9, 0.5])
+    a, b = mk(), mk()
+    params = [p for ps in step.trainable_parameters().values() for p in ps]
+    step.step(**a)
+    ga = [p.grad.detach().clone() for p in params]
+    step.step(**b)
+    gb = [p.grad.detach().clone() for p in params]
+    step.step(**a)                                         # first micro-batch of an update ...
+    _detach_grads(step)
+    step.step(**b, accumulate=True)                        # ... second one adds
+    torch.cuda.synchronize()
+    for p, x, y in zip(params, ga, gb):
+        assert rel_l2(p.grad, x + y) < 1e-6

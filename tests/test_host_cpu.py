@@ -508,7 +508,7 @@ def test_train_cli_rejects_what_it_does_not_support_and_fails_loudly_without_a_g
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = lambda *a: subprocess.run([sys.executable, os.path.join(root, "train.py"), *a], capture_output=True, text=True, timeout=300)
     for bad, msg in ((["--synthetic_data", "--mask_subfolder", "masks"], "masked dataset"), (["--synthetic_data", "--face_loss", "facenet"], "facenet"),
-                     (["--synthetic_data", "--gradient_accumulation_steps", "2"], "gradient_accumulation_steps"),
+                     (["--synthetic_data", "--gradient_accumulation_steps", "0"], "gradient_accumulation_steps"),
                      (["--synthetic_data", "--push_to_hub"], "network"), ([], "--data_root_path"),
                      (["--synthetic_data", "--extra_num_tokens", "2"], "image_encoder_layers_idx")):
         r = run(*bad)

@@ -14,7 +14,7 @@ sizes for a smoke run), ``--synthetic_data`` (random images instead of a dataset
 network; the reference downloads it), ``--image_encoder_path``, ``--grad_scale``.
 
 Not supported (rejected with a message, not ignored): ``--mask_subfolder`` (the masked CelebA-HQ dataset needs cv2), ``--face_loss facenet``
-([EXT] facenet_pytorch), ``--gradient_accumulation_steps`` > 1, ``--report_to`` / ``--push_to_hub`` (no network), multi-process launch
+([EXT] facenet_pytorch), ``--report_to`` / ``--push_to_hub`` (no network), multi-process launch
 (the reference's accelerate config is single-GPU too, ``single_gpu.json:3``).  ``--mixed_precision`` is accepted and ignored: activations are
 fp16-stored with fp32 accumulation and fp32 master weights always.  An incomplete last batch of an epoch is dropped (the plans have a
 fixed batch size).
@@ -88,8 +88,8 @@ def parse_args():
         p.error("--mask_subfolder: the masked dataset (datasets/custom.py:97-189, cv2) is not part of this build")
     if args.face_loss == "facenet":
         p.error("--face_loss facenet needs [EXT] facenet_pytorch; only arcface is built")
-    if args.gradient_accumulation_steps != 1:
-        p.error("--gradient_accumulation_steps > 1 is not supported")
+    if args.gradient_accumulation_steps < 1:
+        p.error("--gradient_accumulation_steps must be >= 1")
     if args.report_to or args.push_to_hub:
         p.error("--report_to / --push_to_hub need network access")
     if not args.synthetic_data and not args.data_root_path:
@@ -236,12 +236,16 @@ def main():
     loader = torch.utils.data.DataLoader(dataset, shuffle=True, collate_fn=collate, batch_size=B, drop_last=True,
                                          num_workers=0 if args.synthetic_data else args.dataloader_num_workers)
     gen = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
-    global_step = 0
+    global_step, micro = 0, 0
+    acc_n = args.gradient_accumulation_steps
     for epoch in range(args.num_train_epochs):
         for batch in loader:
             optimizer.lr = args.learning_rate * sched(global_step)
             out = training_iteration(step, optimizer, batch, tokenizer, image_encoder, vae, noise_scheduler, device, args.image_encoder_layers_idx,
-                                     args.extra_num_tokens, generator=gen)
+                                     args.extra_num_tokens, generator=gen, micro_step=micro, accumulation_steps=acc_n)
+            micro = (micro + 1) % acc_n
+            if micro:                                        # accelerator.accumulate: no optimizer step, no logging yet (train.py:464, :551)
+                continue
             global_step += 1
             logs = {"loss_mle": float(out["diffusion_loss"]), "loss_reg_concept_text": float(out["concept_text_loss"]),
                     "loss_reg_cross_attn_visual": float(out["cross_attn_visual_loss"]), "lr": optimizer.lr}                    # train.py:612-617
