@@ -507,7 +507,7 @@ def test_train_cli_rejects_what_it_does_not_support_and_fails_loudly_without_a_g
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = lambda *a: subprocess.run([sys.executable, os.path.join(root, "train.py"), *a], capture_output=True, text=True, timeout=300)
-    for bad, msg in ((["--synthetic_data", "--mask_subfolder", "masks"], "masked dataset"), (["--synthetic_data", "--face_loss", "facenet"], "facenet"),
+    for bad, msg in ((["--synthetic_data", "--face_loss", "facenet"], "facenet"),
                      (["--synthetic_data", "--gradient_accumulation_steps", "0"], "gradient_accumulation_steps"),
                      (["--synthetic_data", "--push_to_hub"], "network"), ([], "--data_root_path"),
                      (["--synthetic_data", "--extra_num_tokens", "2"], "image_encoder_layers_idx")):
@@ -516,3 +516,40 @@ def test_train_cli_rejects_what_it_does_not_support_and_fails_loudly_without_a_g
     if not torch.cuda.is_available():
         r = run("--synthetic_data", "--tiny", "--max_train_steps", "1")
         assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
+
+
+def test_train_cli_datasets(tmp_path):
+    """The image-folder datasets of the training CLI (datasets/custom.py:44-171): numbered files in order, prompt + placeholder index,
+    [-1, 1] VAE pixels and CLIP pixels; with masks the CLIP image is the masked photo cropped to the reference's enlarged, squared box."""
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    from photoverse_amd.tokenizer import SyntheticCLIPTokenizer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pv_train_cli", os.path.join(root, "train.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    os.makedirs(tmp_path / "images"); os.makedirs(tmp_path / "masks")
+    rng = np.random.RandomState(0)
+    for i in (2, 10, 1):                                   # numeric order, not lexicographic
+        Image.fromarray(rng.randint(0, 255, (96, 128, 3), dtype=np.uint8)).save(tmp_path / "images" / f"{i}.png")
+        m = np.zeros((48, 64), dtype=np.uint8)
+        m[10:30, 20:28] = 255                              # tall box: 20 x 8 (bbox ymax - ymin = 19, xmax - xmin = 7)
+        Image.fromarray(m).save(tmp_path / "masks" / f"{i}.png")
+    tok = SyntheticCLIPTokenizer()
+    ds = cli.ImageFolderDataset(str(tmp_path), tok, size=64)
+    assert [os.path.basename(p) for p in ds.image_paths] == ["1.png", "2.png", "10.png"] and len(ds) == 3
+    ex = ds[0]
+    assert ex["pixel_values"].shape == (3, 64, 64) and ex["pixel_values_clip"].shape == (3, 224, 224) and -1 <= ex["pixel_values"].min() and ex["pixel_values"].max() <= 1
+    assert ex["text_input_ids"].shape == (77,) and int(ex["concept_placeholder_idx"]) == 4          # "a photo of *": BOS + 3 words
+    # the reference's box: bbox rows 10..29, cols 20..27 -> +-15 %: rows 7..31, cols 18..28 -> taller than wide (24 > 10): cols widened by 12 each side
+    m = np.zeros((48, 64), dtype=np.uint8); m[10:30, 20:28] = 255
+    assert cli.crop_box_of_mask(m) == (7, 31, 6, 40)
+    wide = np.zeros((48, 64), dtype=np.uint8); wide[20:24, 2:60] = 1
+    assert cli.crop_box_of_mask(wide) == (0, 48, 0, 64)                                            # clipped to the image on every side
+    dm = cli.MaskedImageFolderDataset(str(tmp_path), tok, size=64)
+    exm = dm[1]
+    assert exm["pixel_values_clip"].shape == (3, 224, 224) and torch.equal(exm["pixel_values"], ds[1]["pixel_values"])
+    assert not torch.equal(exm["pixel_values_clip"], ds[1]["pixel_values_clip"])
+    batch = cli.collate([ds[0], ds[1]])
+    assert batch["pixel_values"].shape == (2, 3, 64, 64) and batch["concept_placeholder_idx"].shape == (2, 1)

@@ -4,6 +4,7 @@
 Same flags and defaults for everything the hot path consumes (``train.py:37-285`` of the reference): model / checkpoint paths, AdamW
 hyper-parameters, LoRA (``--use_lora --lora_rank --lora_alpha --lora_dropout``), ``--extra_num_tokens`` / ``--image_encoder_layers_idx``,
 ``--face_loss arcface --face_loss_sample_ratio``, ``--guidance_scale``, ``--lr_scheduler`` / ``--lr_warmup_steps``,
+``--data_root_path`` / ``--img_subfolder`` / ``--mask_subfolder`` (the image-folder datasets of ``datasets/custom.py``, with and without masks),
 ``--checkpoint_save_steps``, ``--samples_save_steps`` / ``--denoise_timesteps`` / ``--num_of_samples_to_save`` (sample grids through
 ``run_inference``, ``train.py:549-596``), ``--max_train_steps``.  One iteration = ``photoverse_amd.train.training_iteration`` (``train.py:464-549``):
 forward + backward launch plans on the HIP kernels, per-module gradient clipping and AdamW on the device; checkpoints in the reference's
@@ -13,7 +14,7 @@ Build-side additions: ``--pretrained_model_name_or_path random`` (seeded random-
 sizes for a smoke run), ``--synthetic_data`` (random images instead of a dataset), ``--arcface_weights`` (local state dict of the ArcFace
 network; the reference downloads it), ``--image_encoder_path``, ``--grad_scale``.
 
-Not supported (rejected with a message, not ignored): ``--mask_subfolder`` (the masked CelebA-HQ dataset needs cv2), ``--face_loss facenet``
+Not supported (rejected with a message, not ignored): ``--face_loss facenet``
 ([EXT] facenet_pytorch), ``--report_to`` / ``--push_to_hub`` (no network), multi-process launch
 (the reference's accelerate config is single-GPU too, ``single_gpu.json:3``).  ``--mixed_precision`` is accepted and ignored: activations are
 fp16-stored with fp32 accumulation and fp32 master weights always.  An incomplete last batch of an epoch is dropped (the plans have a
@@ -84,8 +85,6 @@ def parse_args():
     args = p.parse_args()
     if len(args.image_encoder_layers_idx) != args.extra_num_tokens:           # train.py:291-292
         p.error("--image_encoder_layers_idx must have --extra_num_tokens entries")
-    if args.mask_subfolder is not None:
-        p.error("--mask_subfolder: the masked dataset (datasets/custom.py:97-189, cv2) is not part of this build")
     if args.face_loss == "facenet":
         p.error("--face_loss facenet needs [EXT] facenet_pytorch; only arcface is built")
     if args.gradient_accumulation_steps < 1:
@@ -133,6 +132,56 @@ class ImageFolderDataset(torch.utils.data.Dataset):
             raw = raw.convert("RGB")
         ex["pixel_values"] = preprocess_image(raw, size=self.size, interpolation="bicubic")
         ex["pixel_values_clip"] = clip_image_processor(raw)
+        return ex
+
+
+def crop_box_of_mask(mask, grow=0.15):
+    """The crop ``CustomDatasetWithMasks._crop_to_mask_and_scale`` takes (datasets/custom.py:143-171): bounding box of the non-zero mask,
+    each side moved out by ``grow`` x the box size (clipped to the image), then the SHORTER side widened by half of the longer side's
+    length on both of its ends (clipped) - the reference's way of getting a roughly square, generously padded crop.  (ymin, ymax, xmin, xmax)."""
+    import numpy as np
+    ys, xs = np.where(np.asarray(mask) > 0)
+    H, W = np.asarray(mask).shape[:2]
+    ymin, ymax, xmin, xmax = int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max())
+    bh, bw = ymax - ymin, xmax - xmin
+    ymin, ymax = max(0, int(ymin - bh * grow)), min(H, int(ymax + bh * grow))
+    xmin, xmax = max(0, int(xmin - bw * grow)), min(W, int(xmax + bw * grow))
+    cw, ch = xmax - xmin, ymax - ymin
+    if cw > ch:
+        ymax, ymin = min(H, ymax + cw // 2), max(0, ymin - cw // 2)
+    elif ch > cw:
+        xmax, xmin = min(W, xmax + ch // 2), max(0, xmin - ch // 2)
+    return ymin, ymax, xmin, xmax
+
+
+class MaskedImageFolderDataset(ImageFolderDataset):
+    """datasets/custom.py:97-141 (``CustomDatasetWithMasks``): the CLIP-side image is the photo resized to the mask's size, blacked out
+    outside the mask and cropped around it; the VAE-side pixels are the full photo."""
+
+    def __init__(self, data_root, tokenizer, img_subfolder="images", mask_subfolder="masks", **kw):
+        super().__init__(data_root, tokenizer, img_subfolder, **kw)
+        mask_dir = os.path.join(data_root, mask_subfolder)
+        paths = [os.path.join(mask_dir, f) for f in os.listdir(mask_dir) if any(e in f.lower() for e in ("jpg", "png", "jpeg"))]
+        self.mask_paths = sorted(paths, key=lambda x: int(os.path.basename(x).split(".")[0]))
+        if len(self.mask_paths) != len(self.image_paths):
+            raise ValueError(f"{len(self.image_paths)} images but {len(self.mask_paths)} masks under {data_root}")
+
+    def __getitem__(self, idx):
+        import numpy as np
+        from PIL import Image
+        from photoverse_amd.image_utils import clip_image_processor, preprocess_image
+        template = TEMPLATES[np.random.randint(len(TEMPLATES))] if self.use_random_templates else self.template
+        ex = prompt_example(self.tokenizer, template, self.placeholder_token)
+        raw = Image.open(self.image_paths[idx])
+        mask = Image.open(self.mask_paths[idx])
+        raw = raw if raw.mode == "RGB" else raw.convert("RGB")
+        mask = mask if mask.mode == "L" else mask.convert("L")
+        small = np.array(raw.resize(mask.size))
+        m = np.array(mask)
+        masked = np.where((m > 0)[:, :, None], small, 0).astype(np.uint8)
+        y0, y1, x0, x1 = crop_box_of_mask(m)
+        ex["pixel_values"] = preprocess_image(raw, size=self.size, interpolation="bicubic")
+        ex["pixel_values_clip"] = clip_image_processor(Image.fromarray(masked[y0:y1, x0:x1]))
         return ex
 
 
@@ -232,7 +281,9 @@ def main():
     if args.synthetic_data:
         dataset = SyntheticDataset(tokenizer, args.resolution, clip_size, n=max(B * 4, 16), seed=args.seed or 0)
     else:
-        dataset = ImageFolderDataset(args.data_root_path, tokenizer, args.img_subfolder, size=args.resolution, use_random_templates=args.use_random_prompts)
+        kw = dict(size=args.resolution, use_random_templates=args.use_random_prompts)                                 # train.py:388-396
+        dataset = (ImageFolderDataset(args.data_root_path, tokenizer, args.img_subfolder, **kw) if args.mask_subfolder is None else
+                   MaskedImageFolderDataset(args.data_root_path, tokenizer, args.img_subfolder, args.mask_subfolder, **kw))
     loader = torch.utils.data.DataLoader(dataset, shuffle=True, collate_fn=collate, batch_size=B, drop_last=True,
                                          num_workers=0 if args.synthetic_data else args.dataloader_num_workers)
     gen = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
