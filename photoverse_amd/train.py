@@ -806,14 +806,16 @@ class TrainStep:
 @torch.no_grad()
 def training_iteration(step: TrainStep, optimizer, batch, tokenizer, image_encoder, vae, noise_scheduler, device, image_encoder_layers_idx,
                        extra_num_tokens: int, *, generator: Optional[torch.Generator] = None, max_grad_norm: float = 1.0, micro_step: int = 0,
-                       accumulation_steps: int = 1):
+                       accumulation_steps: int = 1, reducer: Optional["GradientReducer"] = None):
     """The body of the reference's training loop (``train.py:464-549``) on top of ``TrainStep``: the frozen, gradient-free part with this
     package's inference modules - VAE encode + posterior sample (``:471-472``), noise / per-sample timesteps / add_noise (``:475-484``), CLIP
     image features (``:487-492``) and, with a face loss, the inputs of ``run_inference(sliced_batch, ...)`` (``:522-530``, ``infer.py:42-84``:
     the "a photo of *" prompt, a random subset of the batch, its latents noised to the first inference timestep, the zero-image features) -
     then the forward + backward plans and the clipped AdamW update (``:536-547``).  Returns the loss terms of the step.
     ``accumulation_steps`` > 1 (``--gradient_accumulation_steps``): micro-batch ``micro_step`` of that many; gradients are summed, the optimizer
-    runs after the last one on their mean (accelerate scales each micro-batch's loss by 1 / steps)."""
+    runs after the last one on their mean (accelerate scales each micro-batch's loss by 1 / steps).  ``reducer``: a ``GradientReducer`` over the
+    trainable parameters when several ranks train data-parallel - the gradients are summed over the ranks once per optimizer step (not per
+    micro-batch, like DDP under ``accelerator.accumulate``) and the optimizer takes their mean."""
     device = torch.device(device)
     pixel_values = batch["pixel_values"].to(device, dtype=torch.float32)
     pixel_values_clip = batch["pixel_values_clip"].to(device, dtype=torch.float32)
@@ -862,9 +864,54 @@ def training_iteration(step: TrainStep, optimizer, batch, tokenizer, image_encod
             _detach_grads(step)                              # the first micro-batch's gradients alias plan buffers the next replay rewrites
         return out
     groups = step.trainable_parameters()
-    out["grad_norms"] = optimizer.step(clip_groups=list(groups.values()), max_norm=max_grad_norm, grad_scale=step.grad_scale * accumulation_steps)
+    world = reducer() if reducer is not None else 1
+    out["grad_norms"] = optimizer.step(clip_groups=list(groups.values()), max_norm=max_grad_norm,
+                                       grad_scale=step.grad_scale * accumulation_steps * world)
     optimizer.zero_grad()
     return out
+
+
+class GradientReducer:
+    """Data-parallel training: the reference runs its loop under accelerate (``train.py:299-305``, ``accelerator.prepare`` ``:398-400``), i.e.
+    every rank steps its own shard of the batch and DDP averages the gradients of the trainable parameters before ``optimizer.step()``.
+
+    Here: ONE flat fp32 bucket for all trainable gradients (≈ 220 tensors, tens of MB with the reference's LoRA rank - far below the size at
+    which a ring all-reduce over xGMI becomes bandwidth-bound, so splitting it into buckets would only add launches) and ONE
+    ``all_reduce(SUM)`` per optimizer step (RCCL when the process group's backend is ``nccl``).  The division by the world size is not a
+    pass over the bucket: the caller multiplies the optimizer's ``grad_scale`` by the returned world size.  After the call every
+    ``param.grad`` is a view of the bucket, so the multi-tensor optimizer keeps seeing the same addresses from step to step.  The backward
+    plan has fully run when the bucket is filled (the plan is one HIP graph): there is no backward left to overlap the collective with."""
+
+    def __init__(self, params, group=None):
+        import torch.distributed as dist
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.params[0].device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+
+    @torch.no_grad()
+    def __call__(self) -> int:
+        """Sum the gradients over the ranks in place; returns the number of ranks the sum ran over (1: nothing to do)."""
+        if self.world == 1:
+            return 1
+        import torch.distributed as dist
+        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat.zero_()                                # a parameter outside this step's plan contributes nothing on this rank
+        torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = self.flat.cpu()                           # gloo (CPU rendezvous, tests on one device): through host memory
+            dist.all_reduce(host, group=self.group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, group=self.group)
+        for p, v in have:
+            p.grad = v
+        return self.world
 
 
 def _detach_grads(step: TrainStep):

@@ -1100,3 +1100,68 @@ def test_gradient_accumulation_sums_micro_batches(need_gpu):
     torch.cuda.synchronize()
     for p, x, y in zip(params, ga, gb):
         assert rel_l2(p.grad, x + y) < 1e-6
+
+
+def test_data_parallel_training_matches_full_batch(need_gpu, tmp_path):
+    """Data-parallel training (the reference trains under accelerate / DDP, train.py:299-305, :398-400): two ranks (two processes sharing this
+    GPU, gloo rendezvous) each step HALF of a seeded global batch, ``GradientReducer`` sums the gradients, AdamW takes the mean through
+    ``grad_scale``.  Both ranks must end with IDENTICAL gradients and parameters, and these must match one process stepping the whole batch
+    (the losses are batch means, so the mean of the half-batch gradients is the full-batch gradient)."""
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ddp_train_worker as W
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ddp_train_worker.py")
+    B, world = 2, 2
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(B)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    full = W.one_step(W.build(101), W.rows(W.global_batch(B * world, 2, 102), 0, B * world), B * world, lambda params: None)
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    assert r0["world"] == r1["world"] == 2 and full["world"] == 1
+    assert all(torch.equal(a, b) for a, b in zip(r0["grads"], r1["grads"]))               # one sum, the same bits on every rank
+    assert all(torch.equal(a, b) for a, b in zip(r0["params"], r1["params"]))
+    assert not torch.equal(r0["loss"], r1["loss"])                                          # ... from different halves of the batch
+    num = sum(float((a - b).pow(2).sum()) for a, b in zip(r0["grads"], full["grads"]))
+    den = sum(float(b.pow(2).sum()) for b in full["grads"])
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    assert abs(float(0.5 * (r0["loss"] + r1["loss"]) - full["loss"])) < 2e-3 * abs(float(full["loss"]))
+    moved = sum(float((a - b).abs().max()) for a, b in zip(r0["params"], full["params"]))
+    assert moved < 1e-3 * len(full["params"])                                               # the same AdamW update (lr 1e-3, sign-like first step)
+
+
+def test_train_cli_two_ranks(need_gpu, tmp_path):
+    """The training CLI launched as two ranks (both on this GPU, gloo instead of RCCL): every rank runs its own batches, the gradients are
+    all-reduced once per optimizer step, only rank 0 logs and writes the checkpoint, and the run ends cleanly on both."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, os.path.join(root, "train.py"), "--pretrained_model_name_or_path", "random", "--tiny", "--synthetic_data",
+           "--max_train_steps", "2", "--train_batch_size", "2", "--resolution", "128", "--extra_num_tokens", "2", "--image_encoder_layers_idx", "1", "2",
+           "--use_lora", "--checkpoint_save_steps", "100", "--samples_save_steps", "0", "--output_dir", str(tmp_path), "--seed", "7",
+           "--gradient_accumulation_steps", "2"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PV_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, o[-2000:] + e[-2000:]
+        outs.append(o)
+    assert len([l for l in outs[0].splitlines() if l.startswith("step ") and "loss_mle=" in l]) == 2 and "saved " in outs[0]
+    assert "step " not in outs[1] and "saved " not in outs[1]
+    sd = torch.load(tmp_path / "photoverse.pt", map_location="cpu")
+    assert int(sd["optimizer"]["state"][0]["step"]) == 2

@@ -553,3 +553,49 @@ def test_train_cli_datasets(tmp_path):
     assert not torch.equal(exm["pixel_values_clip"], ds[1]["pixel_values_clip"])
     batch = cli.collate([ds[0], ds[1]])
     assert batch["pixel_values"].shape == (2, 3, 64, 64) and batch["concept_placeholder_idx"].shape == (2, 1)
+
+
+def _reducer_rank(rank, world, port, q):
+    import torch.distributed as dist
+    from photoverse_amd.train import GradientReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((3, 4), (7,), (2, 2, 2))] + [torch.nn.Parameter(torch.zeros(5), requires_grad=False)]
+    grads = [[torch.randn(p.shape, generator=g) for p in params[:3]] for _ in range(world)]
+    for p, x in zip(params, grads[rank]):
+        p.grad = x.clone()
+    params[1].grad = None if rank == 1 else params[1].grad                  # a parameter outside one rank's step adds nothing from it
+    red = GradientReducer(params)
+    n = red()
+    ok = n == world and len(red.params) == 3 and red.flat.numel() == 12 + 7 + 8
+    ok &= torch.equal(params[0].grad, grads[0][0] + grads[1][0]) and torch.equal(params[2].grad, grads[0][2] + grads[1][2])
+    ok &= params[0].grad.data_ptr() == red.flat.data_ptr()                  # gradients are views of the one bucket
+    if rank == 0:
+        ok &= torch.equal(params[1].grad, grads[0][1])
+    else:
+        ok &= params[1].grad is None
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_two_ranks_gloo():
+    """World-size-2 gloo run of the data-parallel gradient sum (photoverse_amd.train.GradientReducer): one flat bucket, one all_reduce."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_reducer_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+    from photoverse_amd.train import GradientReducer
+    lone = [torch.nn.Parameter(torch.zeros(3))]
+    lone[0].grad = torch.ones(3)
+    assert GradientReducer(lone)() == 1 and torch.equal(lone[0].grad, torch.ones(3))       # no process group: nothing to do

@@ -15,8 +15,10 @@ sizes for a smoke run), ``--synthetic_data`` (random images instead of a dataset
 network; the reference downloads it), ``--image_encoder_path``, ``--grad_scale``.
 
 Not supported (rejected with a message, not ignored): ``--face_loss facenet``
-([EXT] facenet_pytorch), ``--report_to`` / ``--push_to_hub`` (no network), multi-process launch
-(the reference's accelerate config is single-GPU too, ``single_gpu.json:3``).  ``--mixed_precision`` is accepted and ignored: activations are
+([EXT] facenet_pytorch), ``--report_to`` / ``--push_to_hub`` (no network).  Data-parallel: launched as
+``python -m torch.distributed.run --nproc-per-node N train.py ...`` (the reference: ``accelerate launch``) every rank trains its own batches of
+``--train_batch_size`` on its own GPU, the trainable gradients are summed by one RCCL all-reduce per optimizer step
+(``photoverse_amd.train.GradientReducer``) and rank 0 logs and writes checkpoints.  ``--mixed_precision`` is accepted and ignored: activations are
 fp16-stored with fp32 accumulation and fp32 master weights always.  An incomplete last batch of an epoch is dropped (the plans have a
 fixed batch size).
 """
@@ -238,8 +240,15 @@ def main():
     from photoverse_amd.loss import FaceLoss
     from photoverse_amd.modeling_utils import load_models, save_progress
     from photoverse_amd.optim import AdamW
-    from photoverse_amd.train import TrainStep, training_iteration
-    device = torch.device("cuda")
+    from photoverse_amd.train import GradientReducer, TrainStep, training_iteration
+    # data-parallel: one process per GPU under ``python -m torch.distributed.run --nproc-per-node N train.py ...`` (the reference: ``accelerate launch``)
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    device = torch.device("cuda", local if world > 1 else torch.cuda.current_device())
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend=os.environ.get("PV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    main_process = rank == 0
     if args.seed is not None:
         torch.manual_seed(args.seed)
     cfg, clip_size = {}, 224
@@ -284,16 +293,23 @@ def main():
         kw = dict(size=args.resolution, use_random_templates=args.use_random_prompts)                                 # train.py:388-396
         dataset = (ImageFolderDataset(args.data_root_path, tokenizer, args.img_subfolder, **kw) if args.mask_subfolder is None else
                    MaskedImageFolderDataset(args.data_root_path, tokenizer, args.img_subfolder, args.mask_subfolder, **kw))
-    loader = torch.utils.data.DataLoader(dataset, shuffle=True, collate_fn=collate, batch_size=B, drop_last=True,
+    sampler = None
+    if world > 1:                                            # accelerator.prepare(train_dataloader): every rank draws its own batches of B
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=args.seed or 0, drop_last=True)
+    loader = torch.utils.data.DataLoader(dataset, shuffle=sampler is None, sampler=sampler, collate_fn=collate, batch_size=B, drop_last=True,
                                          num_workers=0 if args.synthetic_data else args.dataloader_num_workers)
-    gen = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
+    reducer = GradientReducer([p for g in groups.values() for p in g]) if world > 1 else None
+    # noise / timestep draws: one stream per rank (weights and the fusion-draw seed are the same on every rank, the data and the noise are not)
+    gen = torch.Generator().manual_seed(args.seed + rank) if args.seed is not None else None
     global_step, micro = 0, 0
     acc_n = args.gradient_accumulation_steps
     for epoch in range(args.num_train_epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         for batch in loader:
             optimizer.lr = args.learning_rate * sched(global_step)
             out = training_iteration(step, optimizer, batch, tokenizer, image_encoder, vae, noise_scheduler, device, args.image_encoder_layers_idx,
-                                     args.extra_num_tokens, generator=gen, micro_step=micro, accumulation_steps=acc_n)
+                                     args.extra_num_tokens, generator=gen, micro_step=micro, accumulation_steps=acc_n, reducer=reducer)
             micro = (micro + 1) % acc_n
             if micro:                                        # accelerator.accumulate: no optimizer step, no logging yet (train.py:464, :551)
                 continue
@@ -302,18 +318,25 @@ def main():
                     "loss_reg_cross_attn_visual": float(out["cross_attn_visual_loss"]), "lr": optimizer.lr}                    # train.py:612-617
             if face is not None:
                 logs["loss_face"] = float(out["face_loss"])
-            print(f"step {global_step}: " + ", ".join(f"{k}={v:.6g}" for k, v in logs.items()), flush=True)
-            if args.samples_save_steps and global_step % args.samples_save_steps == 0:                                            # train.py:555-596
+            if main_process:
+                print(f"step {global_step}: " + ", ".join(f"{k}={v:.6g}" for k, v in logs.items()), flush=True)
+            if main_process and args.samples_save_steps and global_step % args.samples_save_steps == 0:                            # train.py:555-596
                 save_samples(args, global_step, batch, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae,
                              noise_scheduler, device, face)
-            if global_step % args.checkpoint_save_steps == 0:
+            if main_process and global_step % args.checkpoint_save_steps == 0:
                 save_progress(image_adapter, text_adapter, unet, None, args.output_dir, step=global_step, lora_config=lora_config, optimizer=optimizer)
             if global_step >= args.max_train_steps:
                 break
         if global_step >= args.max_train_steps:
             break
-    save_progress(image_adapter, text_adapter, unet, None, args.output_dir, lora_config=lora_config, optimizer=optimizer)       # train.py:627-629
-    print(f"saved {os.path.join(args.output_dir, 'photoverse.pt')} after {global_step} steps")
+    if main_process:
+        save_progress(image_adapter, text_adapter, unet, None, args.output_dir, lora_config=lora_config, optimizer=optimizer)   # train.py:627-629
+        print(f"saved {os.path.join(args.output_dir, 'photoverse.pt')} after {global_step} steps")
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
