@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 5
+#define PV_ABI_VERSION 6
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -336,6 +336,13 @@ int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor, const int3
 int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, void* stream);
 int pv_adamw_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* The fp16 working copies of the trainable weights, re-made from their fp32 masters after every optimizer step (the reference's autocast does
+ * the same cast inside every Linear, train.py:464-470) - ONE launch over all of them.  entries: int64 [E][9] = {src (fp32), ld_src, rows, cols,
+ * scale (float bits in the low word), dst (fp16), ld_dst, dstT (fp16 or 0), ld_dstT}: dst[r][c] = fp16(scale * src[r][c]) and, when given,
+ * dstT[c][r] = the same value (the transposed operand of the data-gradient GEMM).  Workgroup b handles the 32 x 32 tile blk_tile[b] (row-major
+ * over ceil(rows/32) x ceil(cols/32)) of entry blk_entry[b].  A destination may be a block of a larger zero-padded matrix (block-diagonal LoRA
+ * factors, stacked k / v projections). */
+int pv_pack_weights(const int64_t* entries, const int32_t* blk_entry, const int32_t* blk_tile, int32_t n_blocks, void* stream);
 /* clip_grad_norm_ (train.py:538-541): out[0] = base * min(1, max_norm / (sqrt(sum_i sumsq[i]) + 1e-6)), out[1] = the norm */
 int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream);
 /* out[c] = sum_r x[r][c] over fp16 rows (bias gradients); partial: nblk*cols floats */

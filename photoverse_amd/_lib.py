@@ -126,6 +126,7 @@ SIGNATURES = {
     "pv_sign_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "pv_gather_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "pv_reduce_sumsq": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "pv_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pv_sumsq_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pv_clip_coef_groups": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pv_adamw_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
@@ -151,7 +152,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

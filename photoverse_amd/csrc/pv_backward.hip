@@ -246,7 +246,44 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const MtEntry* e, cons
     }
 }
 
+// ---- multi-tensor weight packing: every trainable weight's fp16 copy (+ transposed twin) re-made from its fp32 master in ONE launch ----
+// entry = 9 x int64 {src, ld_src, rows, cols, scale (float bits), dst, ld_dst, dstT (or 0), ld_dstT}; workgroup b = 32 x 32 tile blk_tile[b]
+// (row-major over the entry's tiles) of entry blk_entry[b]: dst[r][c] = fp16(scale * src[r][c]), dstT[c][r] = the same value
+struct PackEntry { const float* src; long ld_src, rows, cols, scale_bits; half_t* dst; long ld_dst; half_t* dstT; long ld_dstT; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* e, const int* blk_entry, const int* blk_tile) {
+    __shared__ float tile[32][33];
+    const PackEntry t = e[blk_entry[blockIdx.x]];
+    const int tiles_c = (int)((t.cols + 31) / 32);
+    const long r0 = (long)(blk_tile[blockIdx.x] / tiles_c) * 32, c0 = (long)(blk_tile[blockIdx.x] % tiles_c) * 32;
+    const float sc = __int_as_float((int)t.scale_bits);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long row = r0 + r, col = c0 + tx;
+        float v = 0.f;
+        if (row < t.rows && col < t.cols) {
+            v = sc * t.src[row * t.ld_src + col];
+            t.dst[row * t.ld_dst + col] = (half_t)v;
+        }
+        tile[r][tx] = v;
+    }
+    if (!t.dstT) return;                                                  // uniform over the workgroup
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long col = c0 + r, row = r0 + tx;
+        if (row < t.rows && col < t.cols) t.dstT[col * t.ld_dstT + row] = (half_t)tile[tx][r];
+    }
+}
+
 }  // namespace
+
+extern "C" int pv_pack_weights(const int64_t* entries, const int32_t* blk_entry, const int32_t* blk_tile, int32_t n_blocks, void* stream) {
+    if (!entries || !blk_entry || !blk_tile || n_blocks <= 0) return (int)hipErrorInvalidValue;
+    static_assert(sizeof(PackEntry) == 9 * sizeof(int64_t), "PackEntry is the int64 [9] row the header documents");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackEntry*>(entries), blk_entry,
+                       blk_tile);
+    return PV_CHECK_LAUNCH();
+}
 
 extern "C" int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float* partial,
                               void* stream) {

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from .ops import ACT_NONE, Recorder
+from .ops import ACT_NONE, Recorder, _ptr
 
 
 class Var:
@@ -47,6 +47,8 @@ class Tape:
         self.back: List[Callable[[], None]] = []
         self.refresh: List[tuple] = []          # (fp16 destination, fn() -> current fp32 / fp16 source): trainable weights, re-packed per step
         self.finalize: List[Callable[[], None]] = []   # after rb.run(): hand parameter gradients to the nn.Parameters
+        self.packed: List[tuple] = []           # (fp32 master parameter, scale, fp16 block, transposed fp16 block): one pv_pack_weights launch per step
+        self._pack_key = None
 
     # ------------------------------------------------------------------ weights
     def frozen(self, w: torch.Tensor) -> tuple:
@@ -61,9 +63,47 @@ class Tape:
         self.refresh.append((w16, wT, fn))
         return w16, wT
 
+    def trainable_blocks(self, rows: int, cols: int, blocks) -> tuple:
+        """(w16, wT16) of a [rows, cols] weight assembled from fp32 master PARAMETERS: ``blocks`` = [(param [r, c], row0, col0, scale)], zero
+        elsewhere (block-diagonal LoRA factors, stacked projections, a single Linear weight).  All blocks of all such weights are re-made
+        from the masters by ONE ``pv_pack_weights`` launch in ``load_weights`` - no per-tensor cast / transpose launches."""
+        w16 = torch.zeros(rows, cols, dtype=torch.float16, device=self.device)
+        wT = torch.zeros(cols, rows, dtype=torch.float16, device=self.device)
+        for prm, r0, c0, scale in blocks:
+            if prm.dim() != 2 or prm.dtype != torch.float32 or not prm.is_contiguous():
+                raise TypeError("trainable_blocks takes contiguous fp32 [rows, cols] master weights")
+            pr, pc = prm.shape
+            if r0 + pr > rows or c0 + pc > cols:
+                raise ValueError("block outside the weight")
+            self.packed.append((prm, float(scale), w16[r0:r0 + pr, c0:c0 + pc], wT[c0:c0 + pc, r0:r0 + pr]))
+        self._pack_key = None
+        return w16, wT
+
+    def _pack_table(self):
+        import numpy as np
+        key = tuple(prm.data_ptr() for prm, _, _, _ in self.packed)
+        if key == self._pack_key:
+            return
+        ent = np.zeros((len(self.packed), 9), dtype=np.int64)
+        blk_e, blk_t = [], []
+        for i, (prm, scale, d, dT) in enumerate(self.packed):
+            pr, pc = prm.shape
+            ent[i] = (prm.data_ptr(), pc, pr, pc, int(np.float32(scale).view(np.int32)) & 0xFFFFFFFF, d.data_ptr(), d.stride(0), dT.data_ptr(), dT.stride(0))
+            nt = ((pr + 31) // 32) * ((pc + 31) // 32)
+            blk_e += [i] * nt
+            blk_t += list(range(nt))
+        dev = self.device
+        self._pack = (torch.from_numpy(ent).to(dev), torch.tensor(blk_e, dtype=torch.int32, device=dev), torch.tensor(blk_t, dtype=torch.int32, device=dev))
+        self.rw = Recorder(dev)
+        self.rw._add(self.rw.lib.pv_pack_weights, _ptr(self._pack[0]), _ptr(self._pack[1]), _ptr(self._pack[2]), len(blk_e))
+        self._pack_key = key
+
     @torch.no_grad()
     def load_weights(self):
-        for w16, wT, fn in self.refresh:
+        if self.packed:
+            self._pack_table()                               # rebuilt only when a master moved (``.to()``, a replaced ``.data``)
+            self.rw.run()
+        for w16, wT, fn in self.refresh:                     # weights computed on the host side (merged LoRA: W + s B A)
             src = fn().detach()
             w16.copy_(src)
             wT.copy_(src.t())

@@ -196,7 +196,7 @@ class TrainStep:
 
         def lin(i, xin):
             L = seq[i]
-            w16, wT = tp.trainable(lambda L=L: L.weight)
+            w16, wT = tp.trainable_blocks(L.out_features, L.in_features, [(L.weight, 0, 0, 1.0)])
             return tp.linear(xin, w16, wT, bias=L.bias.data, on_wgrad=self._to(L.weight), on_bgrad=self._to(L.bias))
         h0 = lin(0, x)
         a1 = tp.layernorm(h0, seq[1].weight.data, seq[1].bias.data, eps=seq[1].eps, act=_ops.ACT_LEAKY_RELU, on_affine=self._affine_to(seq[1]))
@@ -290,21 +290,9 @@ class TrainStep:
         xd = tp.dropout(x, p=p, rng=self.fusion_rng, site=site, copies=n)                       # [M, n * cin]
         self.dropout_sites.append((site, n, cin, p))
 
-        def a_bd():
-            w = torch.zeros(n * RP, n * cin, dtype=torch.float32, device=tp.device)
-            for i, m in enumerate(mods):
-                A = m.lora_A["default"].weight
-                w[i * RP:i * RP + A.shape[0], i * cin:(i + 1) * cin] = A.detach()
-            return w
-
-        def b_bd():
-            w = torch.zeros(sum(couts), n * RP, dtype=torch.float32, device=tp.device)
-            r0 = 0
-            for i, m in enumerate(mods):
-                Bm = m.lora_B["default"].weight
-                w[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]] = m.scaling * Bm.detach()
-                r0 += couts[i]
-            return w
+        # block-diagonal stacks, re-made from the fp32 factors every step: A_i at (i * 128, i * cin), s_i * B_i at (row offset of i, i * 128)
+        a_bd = tp.trainable_blocks(n * RP, n * cin, [(m.lora_A["default"].weight, i * RP, i * cin, 1.0) for i, m in enumerate(mods)])
+        b_bd = tp.trainable_blocks(sum(couts), n * RP, [(m.lora_B["default"].weight, sum(couts[:i]), i * RP, m.scaling) for i, m in enumerate(mods)])
 
         def sink_a(dW):                                   # [n * 128, n * cin]
             for i, m in enumerate(mods):
@@ -317,8 +305,8 @@ class TrainStep:
                 Bm = m.lora_B["default"].weight
                 self.pgrads.append((Bm, lambda dW=dW, i=i, r0=r0, m=m, Bm=Bm: m.scaling * dW[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]]))
                 r0 += couts[i]
-        u = tp.linear(xd, *tp.trainable(a_bd), rows_per_image=rows_per_image, on_wgrad=sink_a)   # [M, n * 128]
-        return tp.linear(u, *tp.trainable(b_bd), residual=base, rows_per_image=rows_per_image, on_wgrad=sink_b)
+        u = tp.linear(xd, *a_bd, rows_per_image=rows_per_image, on_wgrad=sink_a)                 # [M, n * 128]
+        return tp.linear(u, *b_bd, residual=base, rows_per_image=rows_per_image, on_wgrad=sink_b)
 
     def _lora_sink(self, mods_rows):
         """mods_rows: [(LoRALinear or None, row0, row1)] - slices of a stacked merged-weight gradient."""
@@ -366,7 +354,8 @@ class TrainStep:
             kvt = tp.linear(text, wkv, wkvT, rows_per_image=self.S_len,
                             on_wgrad=self._lora_sink([(lk, 0, C), (lv, C, 2 * C)]) if (lk is not None or lv is not None) else None)
         kip, vip = proc.to_k_ip[0], proc.to_v_ip[0]
-        wkvip, wkvipT = tp.trainable(lambda kip=kip, vip=vip: torch.cat([kip.weight, vip.weight], 0))
+        wkvip, wkvipT = tp.trainable_blocks(kip.out_features + vip.out_features, kip.in_features,
+                                            [(kip.weight, 0, 0, 1.0), (vip.weight, kip.out_features, 0, 1.0)])
 
         def ip_sink(dW, kip=kip, vip=vip, C=C):
             self.pgrads.append((kip.weight, dW[:C]))

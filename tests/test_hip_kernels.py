@@ -607,3 +607,26 @@ def test_arcface_loss_pieces(rec_cls):
     Pf, dPf = P.float(), dP.float()
     assert rel_l2(dS, 0.3 * Pf * (dPf - (Pf * dPf).sum(-1, keepdim=True))) < 2e-3
     assert torch.equal(cm.cpu(), torch.where((yv > -1) & (yv < 1), dyv, torch.zeros(())))
+
+
+@pytest.mark.gpu
+def test_pack_weights_multi():
+    """pv_pack_weights: fp16 copies + transposed twins of several fp32 masters in one launch, blocks of larger zero-padded matrices, a scale."""
+    from photoverse_amd.tape import Tape
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    a, b, c = (torch.randn(s, generator=g).to(dev) for s in ((8, 320), (77, 45), (640, 8)))
+    tp = Tape(dev)
+    w1, w1T = tp.trainable_blocks(256, 640, [(a, 0, 0, 1.0), (a, 128, 320, 1.0)])
+    w2, w2T = tp.trainable_blocks(77, 45, [(b, 0, 0, 1.0)])
+    w3, w3T = tp.trainable_blocks(700, 136, [(c, 60, 128, -0.125)])
+    for it in range(2):
+        tp.load_weights()
+        torch.cuda.synchronize()
+        e1 = torch.zeros(256, 640, device=dev)
+        e1[:8, :320], e1[128:136, 320:] = a, a
+        e3 = torch.zeros(700, 136, device=dev)
+        e3[60:700, 128:136] = -0.125 * c
+        for w, wT, e in ((w1, w1T, e1), (w2, w2T, b), (w3, w3T, e3)):
+            assert torch.equal(w, e.half()) and torch.equal(wT, e.half().t())
+        a.mul_(2.0); b.add_(1.0); c.sub_(0.5)                 # the masters move in place (an optimizer step): the next launch picks them up

@@ -1,0 +1,87 @@
+// Does the MFMA SHAPE change the energy per flop?  MFMA-only loops on random fp16 operands (power-capped regime, see
+// profiles/r01_mfma_power_probe.txt): 16x16x32 (what every kernel here uses) against 32x32x16 (half the operand-register reads per flop).
+// Same flops per loop step per wave (40 x 16384 = 20 x 32768), independent accumulator chains, 2 workgroups per CU x 4 waves.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ half8 rnd8(unsigned i, float seed) {
+  half8 r;
+  for (int j = 0; j < 8; ++j) { unsigned h = (i * 8 + j) * 2654435761u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    const float u = (float)(h & 0xffff) / 65536.0f - 0.5f, v = (float)(h >> 16) / 65536.0f - 0.5f;
+    r[j] = (_Float16)(seed * (u + v) * 2.0f); }
+  return r;
+}
+
+template <int SHAPE>   // 0: 16x16x32, 4 W-frags x 5 A-frags (the GEMM's wave tile)   1: 32x32x16, 2 x 2 frags, two k-halves   2: 32x32x16, 2 x 3 frags (96 x 64 tile)
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+  const unsigned t = threadIdx.x + blockIdx.x * 256;
+  half8 a[6], b[6];
+  for (int i = 0; i < 6; ++i) { a[i] = rnd8(t * 16 + i, seed); b[i] = rnd8(t * 16 + 8 + i, seed); }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  if (SHAPE == 0) {
+    f4 c[20]; for (auto& x : c) x = f4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) c[i * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], c[i * 5 + j], 0, 0, 0);
+      asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    for (auto& x : c) s += x[0] + x[3];
+  } else if (SHAPE == 1) {
+    f16v c[4]; for (auto& x : c) for (int e = 0; e < 16; ++e) x[e] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 5; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i + 2 * (h & 1)], b[j + 2 * (h & 1)], c[i * 2 + j], 0, 0, 0);
+      asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    for (auto& x : c) s += x[0] + x[15];
+  } else {
+    f16v c[6]; for (auto& x : c) for (int e = 0; e < 16; ++e) x[e] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) c[i * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i + 2 * (h & 1)], b[j + 3 * (h & 1)], c[i * 3 + j], 0, 0, 0);
+      asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    for (auto& x : c) s += x[0] + x[15];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[2] = (float)(t1 - t0); out[3] = (float)(r1 - r0); }
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int SHAPE> void run(const char* name, float* d, float seed, double mfma_per_iter, double flop_per_mfma) {
+  const int iters = 40000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k<SHAPE><<<512, 256>>>(d, iters, seed); hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k<SHAPE><<<512, 256>>>(d, iters, seed);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  float h[4]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  const double fl = mfma_per_iter * flop_per_mfma * iters * 4.0 * 512.0;
+  printf("%-34s seed %.1f: %7.2f ms  %5.2f PFLOP/s  clock %.2f GHz  %.1f cycles/MFMA\n", name, seed, ms, fl / (ms * 1e-3) / 1e15, h[2] / h[3] * 0.1,
+         h[2] / (mfma_per_iter * iters) / 2.0 /* two waves per SIMD share the pipe */);
+}
+int main() { float* d; hipMalloc(&d, 64);
+  for (int rep = 0; rep < 2; ++rep)
+    for (float seed : {0.f, 1.5f}) {
+      run<0>("16x16x32 f16, 4x5 frags", d, seed, 40, 16384);
+      run<1>("32x32x16 f16, 2x2 frags", d, seed, 20, 32768);
+      run<2>("32x32x16 f16, 2x3 frags", d, seed, 18, 32768);
+    }
+  return 0; }
