@@ -159,12 +159,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
 }
 
 // out[k][c] = scale * sum_i x[i][k][c] in i order: column reductions (dgamma / dbeta partials, bias gradients), deterministic
-__global__ void reduce_blocks_kernel(const float* x, int nblk, long inner, float scale, float* out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= inner) return;
-    float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += x[(size_t)b * inner + i];
-    out[i] = a * scale;
+// 32 columns x 8 block-groups per workgroup: group g sums blocks g, g + 8, ... (four loads in flight), the 8 group sums are added in g order -
+// a fixed order, and 8 x more workgroups with 8 x shorter serial chains than one thread per column (514 blocks x 2048 columns: 64 -> 9 us)
+__global__ __launch_bounds__(256) void reduce_blocks_kernel(const float* x, int nblk, long inner, float scale, float* out) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < inner) {
+        int b = g;
+        for (; b + 24 < nblk; b += 32) {
+            a0 += x[(size_t)b * inner + i];
+            a1 += x[(size_t)(b + 8) * inner + i];
+            a2 += x[(size_t)(b + 16) * inner + i];
+            a3 += x[(size_t)(b + 24) * inner + i];
+        }
+        for (; b < nblk; b += 8) a0 += x[(size_t)b * inner + i];
+    }
+    part[g][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && i < inner) {
+        float a = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) a += part[k][c];
+        out[i] = a * scale;
+    }
 }
 
 // column sums of fp16 rows (bias gradient db = sum_m dy[m][:]) in two deterministic stages
@@ -343,7 +362,7 @@ extern "C" int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* str
 
 extern "C" int pv_reduce_blocks(const float* x, int32_t nblk, int64_t inner, float scale, float* out, void* stream) {
     if (!x || !out || nblk <= 0 || inner <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(reduce_blocks_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, nblk, (long)inner, scale, out);
+    hipLaunchKernelGGL(reduce_blocks_kernel, dim3((unsigned)((inner + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, nblk, (long)inner, scale, out);
     return PV_CHECK_LAUNCH();
 }
 
@@ -352,6 +371,6 @@ extern "C" int pv_colsum_f16(const void* x, int32_t ldx, int32_t rows, int32_t c
     const int rpb = (rows + nblk - 1) / nblk;
     hipLaunchKernelGGL(colsum_f16_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const half_t*>(x), ldx, rows, cols, rpb, partial);
-    hipLaunchKernelGGL(reduce_blocks_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nblk, (long)cols, 1.0f, out);
+    hipLaunchKernelGGL(reduce_blocks_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, (long)cols, 1.0f, out);
     return PV_CHECK_LAUNCH();
 }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
             for (int j = 0; j < 8; ++j) qf[qi][ks][j] = (half_t)((float)qf[qi][ks][j] * qscale);    // same fp16 rounding as the forward kernel
         }
         nlse[qi] = qok[qi] ? -p.lse[bh + qc] : -INFINITY;
-        delta[qi] = qok[qi] ? p.delta[bh + qc] : 0.f;
+        delta[qi] = qok[qi] ? -p.delta[bh + qc] : 0.f;     // -delta: the initial value of the dP accumulators (dS = P (dP - delta) needs no subtraction)
 #pragma unroll
         for (int f = 0; f < C::DT; ++f) acc[qi][f] = float4_t{0.f, 0.f, 0.f, 0.f};
     }
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
             rk.gload(Kg, p.ldk, (t + 1) * 64, p.nk);
             rv.gload(Vg, p.ldv, (t + 1) * 64, p.nk);
         }
-        const bool masked = p.causal || (t + 1) * 64 > p.nk;
+        // the tile body exists twice: the unmasked copy (every tile but a ragged last one, nothing causal) is one straight-line block the
+        // scheduler can interleave freely; with a run-time flag inside it every score carried its own branch around the mask
+        auto tile_body = [&](auto mask_tag) {
+        constexpr bool masked = decltype(mask_tag)::value;
         float4_t ds[NF][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
             }
 #pragma unroll
             for (int qi = 0; qi < NF; ++qi) {
-                float4_t s = float4_t{nlse[qi], nlse[qi], nlse[qi], nlse[qi]}, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+                float4_t s = float4_t{nlse[qi], nlse[qi], nlse[qi], nlse[qi]}, dp = float4_t{delta[qi], delta[qi], delta[qi], delta[qi]};
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
                     s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[ks], qf[qi][ks], s, 0, 0, 0);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
                         const int key = t * 64 + kb * 16 + fq * 4 + r;
                         if (key >= p.nk || (p.causal && key > qrow[qi])) pr = 0.f;
                     }
-                    ds[qi][kb][r] = pr * (dp[r] - delta[qi]);
+                    ds[qi][kb][r] = pr * dp[r];
                 }
             }
         }
@@ -214,6 +217,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pv_attn_bwd_para
                 for (int qi = 0; qi < NF; ++qi) acc[qi][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk, bsl[qi], acc[qi][f], 0, 0, 0);
             }
         }
+        };
+        if (p.causal || (t + 1) * 64 > p.nk) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
     }
 #pragma unroll
     for (int qi = 0; qi < NF; ++qi)
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
     half_t* sQ = reinterpret_cast<half_t*>(smem);
     half_t* sDO = sQ + C::TILE;
     float* sL = reinterpret_cast<float*>(sDO + C::TILE);       // -lse of the 64 staged queries (-inf beyond nq)
-    float* sDl = sL + 64;
+    float* sDl = sL + 64;                                      // -delta of the same queries
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
     const int nkt = (p.nk + KW - 1) / KW;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
     const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
     const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
     const size_t bh = ((size_t)b * p.heads + h) * p.nq;
-    const bool masked = p.causal || (kt + 1) * KW > p.nk;      // workgroup-uniform: some key of this workgroup needs the mask
+    const bool wg_masked = p.causal || (kt + 1) * KW > p.nk;   // workgroup-uniform: some key of this workgroup needs the mask
 
     int key[NF];
     bool kok[NF];
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
         const int qr = t * 64 + (tid & 63), qc = min(qr, p.nq - 1);
         const float l = p.lse[bh + qc], dd = p.delta[bh + qc];
         pl = qr < p.nq ? -l : -INFINITY;
-        pd = qr < p.nq ? dd : 0.f;
+        pd = qr < p.nq ? -dd : 0.f;                        // staged negated: the dP accumulators start from -delta
     };
     if (t0 < nqt) {
         rq.gload(Q, p.ldqs, t0 * 64, p.nq);
@@ -305,6 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
             rdo.gload(DO, p.lddo, (t + 1) * 64, p.nq);
             gload_stats(t + 1);
         }
+        auto tile_body = [&](auto mask_tag) {                   // two copies, see the dQ kernel
+        constexpr bool masked = decltype(mask_tag)::value;
         float4_t pw[NF][4], ds[NF][4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
             }
 #pragma unroll
             for (int ki = 0; ki < NF; ++ki) {
-                float4_t s = l4, dp = float4_t{0.f, 0.f, 0.f, 0.f};
+                float4_t s = l4, dp = dl;
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
                     s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[ks], kf[ki][ks], s, 0, 0, 0);
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
                         if (!kok[ki] || (p.causal && key[ki] > qr)) pr = 0.f;
                     }
                     pw[ki][qb][r] = pr;
-                    ds[ki][qb][r] = pr * (dp[r] - dl[r]);
+                    ds[ki][qb][r] = pr * dp[r];
                 }
             }
         }
@@ -358,6 +366,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pv_attn_bwd_par
                 }
             }
         }
+        };
+        if (wg_masked) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
     }
 #pragma unroll
     for (int ki = 0; ki < NF; ++ki)
