@@ -56,7 +56,9 @@ __device__ __forceinline__ half8_t vt_frag(const half_t* sV, int VS, int key0, i
 template <int D>
 constexpr int attn_min_waves() { return 1; }
 
-template <int D>
+// NQ: 16-query fragments per wave (a workgroup owns 64 * NQ queries): every K / V fragment read from LDS and every staged tile (two
+// barriers) serves NQ fragments
+template <int D, int NQ>
 __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv_attn_params p) {
     using C = ACfg<D>;
     constexpr int KB = 64;
@@ -69,11 +71,8 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 #else
     constexpr bool ONES = (D % 16) != 0;
 #endif
-#ifdef PV_ATTN_DBUF
-    constexpr bool DBUF = D <= 80;                       // two K/V LDS stages -> one barrier per tile (measured slower: off)
-#else
+    // two K/V LDS stages -> one barrier per tile: measured slower in round 1 and again with NQ = 4 (666 vs 660 us at d = 40, N = 4096): off
     constexpr bool DBUF = false;
-#endif
     constexpr int STAGE = KB * (C::KS + C::VS);          // halfs per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sbase = reinterpret_cast<half_t*>(smem);
@@ -82,7 +81,8 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
     const int fr = lane & 15, fq = lane >> 4;
     // 1-D grid, XCD-aware: the q-tiles of one (batch, head) get consecutive remapped ids, i.e. run on ONE XCD, so its K/V
     // (655 KB at N = 4096) are fetched into one L2 instead of all eight (FETCH_SIZE was 8x the K/V bytes)
-    const int nqt = (p.nq + 127) / 128;
+    constexpr int QW = 64 * NQ;
+    const int nqt = (p.nq + QW - 1) / QW;
     const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
     const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
     }
 
     const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
-    half8_t qf[2][C::KSTEPS];
-    int qrow[2];
+    half8_t qf[NQ][C::KSTEPS];
+    int qrow[NQ];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrow[qi] = qt * QW + (wave * NQ + qi) * 16 + fr;
         const int rc = min(qrow[qi], p.nq - 1);
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
@@ -155,20 +155,22 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
         }
     };
 
-    float4_t o[C::DVF][2];
+    float4_t o[C::DVF][NQ];
 #pragma unroll
     for (int f = 0; f < C::DVF; ++f)
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};     // m_run is meaningful from the first tile on (FIRST path)
+        for (int qi = 0; qi < NQ; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[NQ], l_run[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) m_run[qi] = l_run[qi] = 0.f;     // m_run is meaningful from the first tile on (FIRST path)
 
     // one 64-key tile: S'^T = K.Q'^T - m_run (log2 units, relative to the running maximum), online softmax, O^T += V^T.P^T
     auto tile = [&](int t, int st, const bool MASKED, const bool FIRST) {
         const half_t* sK = sbase + st * STAGE;
         const half_t* sV = sK + KB * C::KS;
-        float4_t s[4][2];
+        float4_t s[4][NQ];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
             const float init = FIRST ? 0.f : -m_run[qi];      // the row constant rides in the MFMA accumulator
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) s[kb][qi] = float4_t{init, init, init, init};
@@ -182,12 +184,12 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 #if PV_ATTN_ABLATE == 2
                 asm volatile("" ::"v"(a));
 #else
-                for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+                for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
 #endif
             }
-        half8_t pb[2][2];
+        half8_t pb[2][NQ];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
             if (MASKED) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -250,13 +252,13 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
                 asm volatile("" ::"v"(a), "v"(pb[s2][0]), "v"(pb[s2][1]));
 #else
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
+                for (int qi = 0; qi < NQ; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
 #endif
             }
     };
 
     int ntiles = (p.nk + KB - 1) / KB;
-    if (p.causal) ntiles = min(ntiles, (min(qt * 128 + 127, p.nq - 1)) / KB + 1);
+    if (p.causal) ntiles = min(ntiles, (min(qt * QW + QW - 1, p.nq - 1)) / KB + 1);
     gload(0);
     if (DBUF) {
         swrite(0);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 
     half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < NQ; ++qi) {
         float l;
         if (ONES) {
             // denominator lives in output column D: fragment D/16, lanes with fq == (D%16)/4, register (D%4)
@@ -495,12 +497,13 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p, con
 template <int D>
 int launch_attn(const pv_attn_params& p, hipStream_t s) {
     using C = ACfg<D>;
-#ifdef PV_ATTN_DBUF
-    constexpr int smem = 64 * (C::KS + C::VS) * 2 * (D <= 80 ? 2 : 1);
-#else
-    constexpr int smem = 64 * (C::KS + C::VS) * 2;
-#endif
-    hipLaunchKernelGGL(attn_kernel<D>, dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem, s, p);
+    constexpr int smem1 = 64 * (C::KS + C::VS) * 2;
+    // four query fragments per wave where the accumulators fit two waves per SIMD (d = 40) and the launch still fills the chip
+    static const int nq_env = getenv("PV_ATTN_NQ") ? atoi(getenv("PV_ATTN_NQ")) : 0;
+    const long wg256 = (long)((p.nq + 255) / 256) * p.heads * p.batch;
+    const bool four = D == 40 && (nq_env ? nq_env == 4 : wg256 >= 1024);
+    if (four) hipLaunchKernelGGL((attn_kernel<D, D == 40 ? 4 : 2>), dim3((unsigned)wg256), dim3(256), smem1, s, p);
+    else hipLaunchKernelGGL((attn_kernel<D, 2>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem1, s, p);
     return PV_CHECK_LAUNCH();
 }
 
