@@ -88,13 +88,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
     }
 }
 
-// data-gradient-only LayerNorm backward (the frozen LayerNorms of the UNet / text encoder): one wave per row, 16-byte loads, the row and
-// its gradient live in registers between the three passes (statistics, the two projections, the result)
+// data-gradient-only LayerNorm backward (the frozen LayerNorms of the UNet / text encoder): LPR lanes per row (64 / LPR rows per wave, so
+// that every lane loads: at 320 columns one wave per row left 24 of 64 lanes idle - 58 us at 65536 rows), 16-byte loads, the row and its
+// gradient live in registers between the three passes (statistics, the two projections, the result)
+template <int LPR>
+__device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layernorm_bwd_params p) {
-    constexpr int NCH = 4;                                   // 16-byte chunks per lane: cols <= 2048
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
+    constexpr int RPW = 64 / LPR;                            // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int row_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row_raw < p.rows;                      // dead rows compute on a clamped row (the shuffles need every lane) and store nothing
+    const int row = live ? row_raw : p.rows - 1;
     const int nchunk = p.cols >> 3;
     const half_t* x = reinterpret_cast<const half_t*>(p.x) + (size_t)row * p.ldx;
     const int grp = p.dy_group > 1 ? p.dy_group : 1;
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + i * 64;
+        const int ch = sub + i * LPR;
         if (ch < nchunk) {
             const half8_t a = *reinterpret_cast<const half8_t*>(x + ch * 8), g = *reinterpret_cast<const half8_t*>(dy + ch * 8);
 #pragma unroll
@@ -115,23 +125,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
             for (int j = 0; j < 8; ++j) xv[i][j] = gv[i][j] = 0.f;
         }
     }
-    const float mean = pv_wave_sum(sum) / (float)p.cols;
+    const float mean = sub_sum<LPR>(sum) / (float)p.cols;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-        if (lane + i * 64 < nchunk) {
+        if (sub + i * LPR < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
         }
-    const float rstd = rsqrtf(pv_wave_sum(sq) / (float)p.cols + p.eps);
+    const float rstd = rsqrtf(sub_sum<LPR>(sq) / (float)p.cols + p.eps);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + i * 64;
+        const int ch = sub + i * LPR;
         if (ch < nchunk) {
+            const float4_t g0 = *reinterpret_cast<const float4_t*>(p.gamma + ch * 8), g1 = *reinterpret_cast<const float4_t*>(p.gamma + ch * 8 + 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float gam = p.gamma[ch * 8 + j];
+                const float gam = j < 4 ? g0[j] : g1[j - 4];
                 const float xh = (xv[i][j] - mean) * rstd;
                 float g = gv[i][j];
                 if (p.act == PV_ACT_LEAKY_RELU && gam * xh + p.beta[ch * 8 + j] < 0.f) g *= 0.01f;
@@ -143,12 +154,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
             }
         }
     }
-    s1 = pv_wave_sum(s1) / (float)p.cols;
-    s2 = pv_wave_sum(s2) / (float)p.cols;
+    s1 = sub_sum<LPR>(s1) / (float)p.cols;
+    s2 = sub_sum<LPR>(s2) / (float)p.cols;
+    if (!live) return;
     half_t* dx = reinterpret_cast<half_t*>(p.dx) + (size_t)row * p.lddx;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + i * 64;
+        const int ch = sub + i * LPR;
         if (ch < nchunk) {
             half8_t o;
 #pragma unroll
@@ -156,6 +168,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
             *reinterpret_cast<half8_t*>(dx + ch * 8) = o;
         }
     }
+}
+
+template <int LPR, int NCH>
+void launch_ln_bwd_vec(const pv_layernorm_bwd_params& p, hipStream_t s) {
+    constexpr int rows_per_wg = 4 * (64 / LPR);
+    hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR, NCH>), dim3((unsigned)((p.rows + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0, s, p);
 }
 
 // out[k][c] = scale * sum_i x[i][k][c] in i order: column reductions (dgamma / dbeta partials, bias gradients), deterministic
@@ -353,7 +371,14 @@ extern "C" int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_
 extern "C" int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream) {
     if (!p->x || !p->dy || !p->dx || !p->gamma || !p->beta || p->rows <= 0 || p->cols <= 0 || p->cols > 2048) return (int)hipErrorInvalidValue;
     if (!p->dgb_partial && p->cols % 8 == 0 && (p->ldx | p->lddy | p->lddx) % 8 == 0) {
-        hipLaunchKernelGGL(layernorm_bwd_vec_kernel, dim3((unsigned)((p->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p);
+        const int nchunk = p->cols / 8;                      // fewest lanes per row whose (lanes x chunks) cover the row
+        hipStream_t st = (hipStream_t)stream;
+        if (nchunk <= 40) launch_ln_bwd_vec<8, 5>(*p, st);          // 320 columns
+        else if (nchunk <= 80) launch_ln_bwd_vec<16, 5>(*p, st);    // 640
+        else if (nchunk <= 96) launch_ln_bwd_vec<16, 6>(*p, st);    // 768
+        else if (nchunk <= 128) launch_ln_bwd_vec<32, 4>(*p, st);   // 1024
+        else if (nchunk <= 160) launch_ln_bwd_vec<32, 5>(*p, st);   // 1280
+        else launch_ln_bwd_vec<64, 4>(*p, st);
         return PV_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((p->rows + 4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1) - 1) / (4 * (p->rows_per_wave > 0 ? p->rows_per_wave : 1)))), dim3(256), 8 * p->cols * sizeof(float), (hipStream_t)stream, *p);
