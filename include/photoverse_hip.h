@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 6
+#define PV_ABI_VERSION 7
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -204,6 +204,13 @@ int pv_gray_resize_backward(const float* dy, int64_t dy_image_stride, float* dx,
 int pv_cosine_embedding_loss(const void* e1, const void* e2, int32_t batch, int32_t dim, float target, float gscale, float* per_sample, void* de2,
                              void* stream);
 /* in-place backward of pv_softmax_rows: dp <- scale * p * (dp - sum_j p_j dp_j) per row */
+/* Weight gradient of a Linear layer (loss.backward() reaching a trainable weight, train.py:536): partial slabs
+ * out[s][n][k] (fp32, s < nsplit) = sum over rows m in [s * rows_per_split, min(m, (s + 1) * rows_per_split)) of dy[m][n] * x[m][k] -
+ * both operands fp16 row matrices as the forward / data-gradient chain leaves them (no transposed copies; the MFMA operands are read with the
+ * transposing LDS load).  n, k, lddy, ldx multiples of 8; rows_per_split a multiple of 64.  Sum the slabs in s order with pv_reduce_blocks
+ * (nblk = nsplit, inner = n * k): deterministic. */
+int pv_wgrad_tn(const void* dy, int32_t lddy, const void* x, int32_t ldx, int32_t m, int32_t n, int32_t k, float* out, int32_t nsplit,
+                int32_t rows_per_split, void* stream);
 int pv_softmax_rows_backward(const void* p, int32_t ldp, void* dp, int32_t lddp, int32_t rows, int32_t cols, float scale, void* stream);
 /* out = dy where lo < y < hi else 0: gradient of images.clamp(-1, 1) (infer.py:122) */
 int pv_clamp_mask_f32(const float* y, const float* dy, float lo, float hi, float* out, int64_t n, void* stream);

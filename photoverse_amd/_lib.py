@@ -120,6 +120,7 @@ SIGNATURES = {
     "pv_gray_resize": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "pv_gray_resize_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "pv_cosine_embedding_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pv_wgrad_tn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "pv_softmax_rows_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "pv_clamp_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "pv_act_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -152,7 +153,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -1279,6 +1279,91 @@ __global__ void gather_rows_kernel(const half_t* x, int ldx, const int32_t* idx,
     out[i] = (row >= 0 && row < seq) ? scale * (float)x[((size_t)b * seq + row) * ldx + c] : 0.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient dW[n][k] = sum_m dY[m][n] X[m][k] (both operands are ROW matrices over the m the sum runs over - the layout the forward
+// and the data-gradient chain leave them in).  The contraction index is the slow one of both operands, so the MFMA operands are read from
+// row-major LDS tiles with the transposing LDS read (ds_read_b64_tr_b16, as the attention backward does) - no transposed copies of dY / X in
+// HBM (the first version ran pv_transpose_f16 on both and then the forward GEMM: 280 extra launches per training step).
+// One workgroup = a 128 (n) x 128 (k) tile of dW over a slab of rows [split * rows_per_split, ...): 64 rows per step, next step's global
+// loads in flight while the current one multiplies; 4 waves as 2 x 2, 64 x 64 per wave.  Partial slabs fp32 [nsplit][n][k], summed in split
+// order by the caller's reduce launch (deterministic).
+struct WgradArgs { const half_t* dy; int lddy; const half_t* x; int ldx; int m, n, k; float* out; int rows_per_split; };
+
+constexpr int WG_RS = 136;                                  // LDS row stride (halfs) of the 64 x 128 tiles
+
+__device__ __forceinline__ half8_t wg_tfrag(const half_t* sR, int f, int s2, int fr, int fq) {
+    const half_t* a = sR + (s2 * 32 + fq * 4 + (fr >> 2)) * WG_RS + f * 16 + (fr & 3) * 4;
+    const fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
+    const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * WG_RS));
+    const half4_t h1 = __builtin_bit_cast(half4_t, t1), h2 = __builtin_bit_cast(half4_t, t2);
+    return __builtin_shufflevector(h1, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) half_t sA[64 * WG_RS];
+    __shared__ __attribute__((aligned(16))) half_t sB[64 * WG_RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, split = blockIdx.z;
+    const int m0 = split * p.rows_per_split, m1 = min(p.m, m0 + p.rows_per_split);
+    half8_t ra[4], rb[4];
+    auto gload = [&](int mb) {                               // 64 rows x 16 chunks per tile: 4 chunks per thread and tile, zero beyond m1 / n / k
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 8;
+            const int row = mb + r, rc = min(row, p.m - 1);
+            const bool okr = row < m1;
+            const half8_t va = *reinterpret_cast<const half8_t*>(p.dy + (size_t)rc * p.lddy + min(n0 + c, p.n - 8));
+            const half8_t vb = *reinterpret_cast<const half8_t*>(p.x + (size_t)rc * p.ldx + min(k0 + c, p.k - 8));
+            ra[i] = (okr && n0 + c < p.n) ? va : tz8();
+            rb[i] = (okr && k0 + c < p.k) ? vb : tz8();
+        }
+    };
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    if (m0 < m1) gload(m0);
+    for (int mb = m0; mb < m1; mb += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 8;
+            *reinterpret_cast<half8_t*>(sA + r * WG_RS + c) = ra[i];
+            *reinterpret_cast<half8_t*>(sB + r * WG_RS + c) = rb[i];
+        }
+        __syncthreads();
+        if (mb + 64 < m1) gload(mb + 64);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = wg_tfrag(sA, wm * 4 + i, s2, fr, fq);
+                fb[i] = wg_tfrag(sB, wn * 4 + i, s2, fr, fq);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = p.out + (size_t)split * p.n * p.k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + (wn * 4 + j) * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n0 + (wm * 4 + i) * 16 + fq * 4 + r;
+                if (nn < p.n && kk < p.k) out[(size_t)nn * p.k + kk] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int pv_cross_attention_backward(const pv_xattn_bwd_params* p, void* stream) {
@@ -1407,6 +1492,16 @@ extern "C" int pv_cosine_embedding_loss(const void* e1, const void* e2, int32_t 
     if (!e1 || !e2 || !per_sample || batch <= 0 || dim <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(cosine_loss_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, (const half_t*)e1, (const half_t*)e2, dim, target, gscale, batch,
                        per_sample, (half_t*)de2);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_wgrad_tn(const void* dy, int32_t lddy, const void* x, int32_t ldx, int32_t m, int32_t n, int32_t k, float* out, int32_t nsplit,
+                           int32_t rows_per_split, void* stream) {
+    if (!dy || !x || !out || m <= 0 || n < 8 || k < 8 || (n | k | lddy | ldx) % 8 || nsplit <= 0 || rows_per_split <= 0 || rows_per_split % 64 ||
+        (long)nsplit * rows_per_split < m)
+        return (int)hipErrorInvalidValue;
+    const WgradArgs a{reinterpret_cast<const half_t*>(dy), lddy, reinterpret_cast<const half_t*>(x), ldx, m, n, k, out, rows_per_split};
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)((k + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, a);
     return PV_CHECK_LAUNCH();
 }
 

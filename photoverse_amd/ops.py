@@ -465,16 +465,26 @@ class Recorder:
         return out
 
     def wgrad(self, dy16, x16, scale=None):
-        """dW [N, K] fp32 = dy16[M, N]^T . x16[M, K] on the MFMA GEMM (both operands transposed, M zero-padded to 64).
-        K must be a multiple of 128 (or 160)."""
-        a = self.transpose(dy16)          # [N, Mp]
-        w = self.transpose(x16)           # [K, Mp]
-        # the output is tiny and the contraction is the row count: split it over workgroups (fixed-order slab reduce, deterministic) -
-        # a 320 x 320 gradient over 65536 rows is 6 tiles; unsplit it took 781 us
-        bn = 160 if w.shape[0] % 160 == 0 else 128
-        tiles = ((a.shape[0] + 127) // 128) * (w.shape[0] // bn)
-        sk = max(1, min(16, 256 // tiles, a.shape[1] // 512))
-        return self.gemm(a, w, out_f32=True, splitk=sk if sk > 1 else 0)
+        """dW [N, K] fp32 = dy16[M, N]^T . x16[M, K]: ``pv_wgrad_tn`` (MFMA, operands read transposed from LDS - no transposed copies) over
+        row slabs + the fixed-order slab sum.  N, K multiples of 8."""
+        (lddy, n), (ldx, k) = _rows(dy16), _rows(x16)
+        m = dy16.shape[0]
+        assert x16.shape[0] == m
+        # the output is tiny and the contraction is the row count: split the rows over workgroups (a 320 x 320 gradient over 65536 rows is
+        # 9 tiles) - about 512 workgroups, at least 8 steps of 64 rows each, slabs summed in order
+        tiles = ((n + 127) // 128) * ((k + 127) // 128)
+        steps = (m + 63) // 64
+        nsplit = max(1, min(steps // 8, 512 // tiles, 128))
+        rps = ((steps + nsplit - 1) // nsplit) * 64
+        nsplit = (m + rps - 1) // rps
+        out = self.empty((n, k), torch.float32)
+        part = out if nsplit == 1 else self.empty((nsplit, n, k), torch.float32)
+        self.keep.extend((dy16, x16))
+        self._add(self.lib.pv_wgrad_tn, _ptr(dy16), lddy, _ptr(x16), ldx, m, n, k, _ptr(part), nsplit, rps,
+                  tag=("pv_wgrad_tn", 2.0 * m * n * k, 2.0 * m * (n + k) + 4.0 * nsplit * n * k))
+        if nsplit > 1:
+            self._add(self.lib.pv_reduce_blocks, _ptr(part), nsplit, n * k, 1.0, _ptr(out))
+        return out
 
     def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0):
         """dx fp16 [rows, cols] and (dgamma, dbeta) fp32 [2, cols].  ``dy_group`` > 1: dy has rows / dy_group rows, row r uses

@@ -630,3 +630,27 @@ def test_pack_weights_multi():
         for w, wT, e in ((w1, w1T, e1), (w2, w2T, b), (w3, w3T, e3)):
             assert torch.equal(w, e.half()) and torch.equal(wT, e.half().t())
         a.mul_(2.0); b.add_(1.0); c.sub_(0.5)                 # the masters move in place (an optimizer step): the next launch picks them up
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(1000, 136, 200), (65536, 128, 320), (80, 640, 768), (4112, 1024, 1024), (7, 8, 8)])
+def test_wgrad_tn(m, n, k):
+    """pv_wgrad_tn + slab sum: dW = dY^T X with both operands as row matrices (strided views included), ragged row / column tails,
+    against fp32 matmul of the same fp16 inputs; two runs are bit-identical (fixed-order slab sum)."""
+    from photoverse_amd.ops import Recorder
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(m + n + k)
+    big = torch.randn(m, n + 16, generator=g).half().to(dev)
+    dy = big[:, 8:8 + n]                                       # a column slice: ld != n
+    x = torch.randn(m, k, generator=g).half().to(dev)
+    rec = Recorder(dev)
+    dw = rec.wgrad(dy, x)
+    rec.run()
+    torch.cuda.synchronize()
+    first = dw.clone()
+    ref = dy.float().t() @ x.float()
+    assert dw.shape == (n, k)
+    assert (dw - ref).norm() / ref.norm() < 2e-6 * max(1.0, (m / 64) ** 0.5)
+    rec.run()
+    torch.cuda.synchronize()
+    assert torch.equal(dw, first)
