@@ -46,6 +46,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
       asm volatile("" : "+v"(a[0]), "+v"(b[0]));
     }
     for (auto& x : c) s += x[0] + x[15];
+  } else if (SHAPE == 3) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    f4 c[20]; for (auto& x : c) x = f4{0, 0, 0, 0};
+    half4 a4[4], b4[5];
+    for (int i = 0; i < 4; ++i) a4[i] = half4{a[i][0], a[i][1], a[i][2], a[i][3]};
+    for (int i = 0; i < 5; ++i) b4[i] = half4{b[i][0], b[i][1], b[i][2], b[i][3]};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) c[i * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[i], b4[j], c[i * 5 + j], 0, 0, 0);
+      asm volatile("" : "+v"(a4[0]), "+v"(b4[0]));
+    }
+    for (auto& x : c) s += x[0] + x[3];
   } else {
     f16v c[6]; for (auto& x : c) for (int e = 0; e < 16; ++e) x[e] = 0;
     for (int it = 0; it < iters; ++it) {
@@ -83,5 +99,6 @@ int main() { float* d; hipMalloc(&d, 64);
       run<0>("16x16x32 f16, 4x5 frags", d, seed, 40, 16384);
       run<1>("32x32x16 f16, 2x2 frags", d, seed, 20, 32768);
       run<2>("32x32x16 f16, 2x3 frags", d, seed, 18, 32768);
+      run<3>("16x16x16 f16, 4x5 frags", d, seed, 40, 8192);
     }
   return 0; }
