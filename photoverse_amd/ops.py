@@ -466,7 +466,7 @@ class Recorder:
 
     def wgrad(self, dy16, x16, scale=None):
         """dW [N, K] fp32 = dy16[M, N]^T . x16[M, K]: ``pv_wgrad_tn`` (MFMA, operands read transposed from LDS - no transposed copies) over
-        row slabs + the fixed-order slab sum.  N, K multiples of 8."""
+        row slabs + the fixed-order slab sum (which also applies ``scale``).  N, K multiples of 8."""
         (lddy, n), (ldx, k) = _rows(dy16), _rows(x16)
         m = dy16.shape[0]
         assert x16.shape[0] == m
@@ -478,12 +478,13 @@ class Recorder:
         rps = ((steps + nsplit - 1) // nsplit) * 64
         nsplit = (m + rps - 1) // rps
         out = self.empty((n, k), torch.float32)
-        part = out if nsplit == 1 else self.empty((nsplit, n, k), torch.float32)
+        sc = 1.0 if scale is None else float(scale)          # applied by the slab sum (a one-slab sum when the rows were not split)
+        part = out if (nsplit == 1 and sc == 1.0) else self.empty((nsplit, n, k), torch.float32)
         self.keep.extend((dy16, x16))
         self._add(self.lib.pv_wgrad_tn, _ptr(dy16), lddy, _ptr(x16), ldx, m, n, k, _ptr(part), nsplit, rps,
                   tag=("pv_wgrad_tn", 2.0 * m * n * k, 2.0 * m * (n + k) + 4.0 * nsplit * n * k))
-        if nsplit > 1:
-            self._add(self.lib.pv_reduce_blocks, _ptr(part), nsplit, n * k, 1.0, _ptr(out))
+        if part is not out:
+            self._add(self.lib.pv_reduce_blocks, _ptr(part), nsplit, n * k, sc, _ptr(out))
         return out
 
     def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0):

@@ -121,7 +121,7 @@ class Tape:
 
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, w16, wT16, *, bias=None, x1: Optional[Var] = None, residual: Optional[Var] = None, rows_per_image=None,
-               colstats=False, on_wgrad=None, on_bgrad=None) -> Var:
+               colstats=False, on_wgrad=None, on_bgrad=None, wgrad_scale=None) -> Var:
         y = self.rf.gemm(x.t, w16, a1=None if x1 is None else x1.t, bias=bias, residual=None if residual is None else residual.t,
                          rows_per_image=rows_per_image, colstats=colstats)
         out = Var(y, x.needs or (x1 is not None and x1.needs) or (residual is not None and residual.needs) or on_wgrad is not None
@@ -135,7 +135,7 @@ class Tape:
                 self._accum(residual, dy)
             if on_wgrad is not None:
                 assert x1 is None
-                on_wgrad(self.rb.wgrad(dy, x.t))
+                on_wgrad(self.rb.wgrad(dy, x.t, scale=wgrad_scale))
             if on_bgrad is not None:
                 on_bgrad(self.rb.colsum(dy))
             if x1 is None:

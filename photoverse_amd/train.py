@@ -299,14 +299,16 @@ class TrainStep:
                 A = m.lora_A["default"].weight
                 self.pgrads.append((A, lambda dW=dW, i=i, A=A: dW[i * RP:i * RP + A.shape[0], i * cin:(i + 1) * cin].contiguous()))
 
-        def sink_b(dW):                                   # [sum couts, n * 128]; B_pad = s * B -> dB = s * dB_pad
+        def sink_b(dW):                                   # [sum couts, n * 128]; B_pad = s * B -> dB = s * dB_pad (s applied by the slab sum: wgrad_scale)
             r0 = 0
             for i, m in enumerate(mods):
                 Bm = m.lora_B["default"].weight
-                self.pgrads.append((Bm, lambda dW=dW, i=i, r0=r0, m=m, Bm=Bm: m.scaling * dW[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]]))
+                self.pgrads.append((Bm, lambda dW=dW, i=i, r0=r0, Bm=Bm: dW[r0:r0 + couts[i], i * RP:i * RP + Bm.shape[1]].contiguous()))
                 r0 += couts[i]
         u = tp.linear(xd, *a_bd, rows_per_image=rows_per_image, on_wgrad=sink_a)                 # [M, n * 128]
-        return tp.linear(u, *b_bd, residual=base, rows_per_image=rows_per_image, on_wgrad=sink_b)
+        if len({float(m.scaling) for m in mods}) != 1:
+            raise NotImplementedError("LoRA branches of one site with different scalings")
+        return tp.linear(u, *b_bd, residual=base, rows_per_image=rows_per_image, on_wgrad=sink_b, wgrad_scale=float(mods[0].scaling))
 
     def _lora_sink(self, mods_rows):
         """mods_rows: [(LoRALinear or None, row0, row1)] - slices of a stacked merged-weight gradient."""
