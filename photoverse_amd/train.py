@@ -873,10 +873,12 @@ class GradientReducer:
     ``param.grad`` is a view of the bucket, so the multi-tensor optimizer keeps seeing the same addresses from step to step.  The backward
     plan has fully run when the bucket is filled (the plan is one HIP graph): there is no backward left to overlap the collective with."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, force: bool = False):
+        """``force``: run the collective even in a one-rank group (exercises the RCCL path on a single GPU)."""
         import torch.distributed as dist
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.force = bool(force)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.params[0].device)
         self.views, off = [], 0
@@ -887,7 +889,7 @@ class GradientReducer:
     @torch.no_grad()
     def __call__(self) -> int:
         """Sum the gradients over the ranks in place; returns the number of ranks the sum ran over (1: nothing to do)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return 1
         import torch.distributed as dist
         have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]

@@ -1165,3 +1165,30 @@ def test_train_cli_two_ranks(need_gpu, tmp_path):
     assert "step " not in outs[1] and "saved " not in outs[1]
     sd = torch.load(tmp_path / "photoverse.pt", map_location="cpu")
     assert int(sd["optimizer"]["state"][0]["step"]) == 2
+
+
+def test_gradient_reducer_over_rccl_one_rank(need_gpu):
+    """The flat gradient bucket through RCCL itself (backend "nccl", a one-rank group on this GPU; the two-rank tests above use gloo because two
+    RCCL ranks cannot share a device): the all-reduce runs on device memory, the gradients come back as views of the bucket, unchanged."""
+    import socket
+    import torch.distributed as dist
+    from photoverse_amd.train import GradientReducer
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = torch.Generator().manual_seed(11)
+        params = [torch.nn.Parameter(torch.zeros(s, device="cuda")) for s in ((640, 768), (8, 320), (1024,))]
+        grads = [torch.randn(p.shape, generator=g).cuda() for p in params]
+        for p, x in zip(params, grads):
+            p.grad = x.clone()
+        red = GradientReducer(params, force=True)
+        assert red() == 1
+        torch.cuda.synchronize()
+        for p, x in zip(params, grads):
+            assert torch.equal(p.grad, x) and p.grad.data_ptr() >= red.flat.data_ptr()
+    finally:
+        dist.destroy_process_group()
