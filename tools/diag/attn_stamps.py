@@ -10,12 +10,12 @@ import photoverse_amd.build as b  # noqa: E402
 ABL = os.environ.get("XA_ABLATE", "")
 s = open(os.path.join(b.CSRC, "pv_attn.hip")).read()
 s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long at_stamps[16];\n'
-              '#define STAMP(i) do { if (D == 40 && blockIdx.x == 2000 && threadIdx.x == 0 && t == 20) at_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
+              '#define STAMP(i) do { if (D == 40 && blockIdx.x == 1000 && threadIdx.x == 0 && t == 20) at_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
               % os.path.join(b.CSRC, "pv_common.h"))
 rep = [("        if (!DBUF) {\n            __syncthreads();  // previous tile fully consumed\n            swrite(0);\n            __syncthreads();\n        }",
         "        STAMP(0);\n        if (!DBUF) {\n            %s\n            swrite(0);\n            %s\n        }\n        STAMP(1);" % (("", "") if "nobar" in ABL else ("__syncthreads();", "__syncthreads();"))),
        ("        if (t + 1 < ntiles) gload(t + 1);\n", "        if (t + 1 < ntiles) gload(t + 1);\n        STAMP(2);\n"),
-       ("        half8_t pb[2][2];\n#pragma unroll\n        for (int qi = 0; qi < 2; ++qi) {\n            if (MASKED) {", "        STAMP(3);\n        half8_t pb[2][2];\n#pragma unroll\n        for (int qi = 0; qi < 2; ++qi) {\n            if (MASKED) {"),
+       ("        half8_t pb[2][NQ];\n#pragma unroll\n        for (int qi = 0; qi < NQ; ++qi) {\n            if (MASKED) {", "        STAMP(3);\n        half8_t pb[2][NQ];\n#pragma unroll\n        for (int qi = 0; qi < NQ; ++qi) {\n            if (MASKED) {"),
        ("#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);",
         "        STAMP(4);\n#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);"),
        ("        tile(t, st, need_mask, t == 0);\n", "        tile(t, st, need_mask, t == 0);\n        STAMP(5);\n")]
