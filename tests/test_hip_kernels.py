@@ -654,3 +654,34 @@ def test_wgrad_tn(m, n, k):
     rec.run()
     torch.cuda.synchronize()
     assert torch.equal(dw, first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(77, 200), (1000, 320), (4100, 640), (1232, 768), (130, 1024), (515, 1280), (37, 2048)])
+@pytest.mark.parametrize("affine,act", [(False, "none"), (False, "leaky"), (True, "leaky")])
+def test_layernorm_backward_kernels(rows, cols, affine, act):
+    """pv_layernorm_backward against torch autograd (fp32 math on the same fp16 inputs): the data-only kernel in all its lanes-per-row
+    instantiations (8 x 5, 16 x 5, 16 x 6, 32 x 4, 32 x 5, 64 x 4 chunks) with row counts that leave partial waves, and the kernel that also
+    produces dgamma / dbeta."""
+    from photoverse_amd.ops import ACT_LEAKY_RELU, ACT_NONE, Recorder
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.5 + 0.3).half().to(dev)
+    dy = torch.randn(rows, cols, generator=g).half().to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(cols, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(cols, generator=g)).to(dev)
+    rec = Recorder(dev)
+    dx, dgb = rec.layernorm_backward(x, dy, gamma, beta, eps=1e-5, act=ACT_LEAKY_RELU if act == "leaky" else ACT_NONE, want_affine=affine)
+    rec.run()
+    torch.cuda.synchronize()
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5)
+    if act == "leaky":
+        y = torch.nn.functional.leaky_relu(y, 0.01)
+    y.backward(dy.float())
+    assert rel_l2(dx.float(), xr.grad) < 1.5e-3
+    if affine:
+        assert rel_l2(dgb[0], gr.grad) < 1e-4 and rel_l2(dgb[1], br.grad) < 1e-4
+    else:
+        assert dgb is None
