@@ -685,3 +685,39 @@ def test_layernorm_backward_kernels(rows, cols, affine, act):
         assert rel_l2(dgb[0], gr.grad) < 1e-4 and rel_l2(dgb[1], br.grad) < 1e-4
     else:
         assert dgb is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,p,wt,wi", [(40, 1024, 1, 1.0, 1.0), (40, 600, 5, 0.7, 1.3), (80, 256, 6, 1.0, 1.0), (160, 64, 16, 2.0, 0.0), (40, 520, 16, 0.0, 2.0)])
+def test_cross_attention_backward_kernels(rec_cls, d, n, p, wt, wi):
+    """pv_cross_attention_backward (dq pass, dK / dV partials per 512-query chunk, ordered reduce) against torch autograd over the fp32
+    two-SDPA formula of the processor (attention_processor.py:317-322, :400-420) on the same fp16 operands, with the to_v_ip_norm
+    regulariser gradient (:397) folded in; query counts that leave ragged chunks / tiles."""
+    B, H, NT = 2, 8, 77
+    C = H * d
+    q, kvt, kvip, do = h16(B * n, C, seed=61), h16(B * NT, 2 * C, seed=62), h16(B * p, 2 * C, seed=63), h16(B * n, C, seed=64)
+    coef = 0.05
+    rec = rec_cls("cuda")
+    dq_, dt, di, dd = q.cuda(), kvt.cuda(), kvip.cuda(), do.cuda()
+    dq, dkv_t, dkv_i = rec.cross_attention_backward(dq_, dt[:, :C], dt[:, C:], di[:, :C], di[:, C:], dd, batch=B, heads=H, nq=n, nt=NT, nip=p, d=d,
+                                                    w_text=wt, w_ip=wi, vnorm_coef=coef)
+    rec.run()
+    torch.cuda.synchronize()
+    hv = lambda t, m: t.view(B, m, H, d).transpose(1, 2)
+    qr, kt, vt = (x.float().requires_grad_(True) for x in (q, kvt[:, :C], kvt[:, C:]))
+    ki, vi = (x.float().requires_grad_(True) for x in (kvip[:, :C], kvip[:, C:]))
+    ot = F.scaled_dot_product_attention(hv(qr, n), hv(kt, NT), hv(vt, NT))
+    oi = F.scaled_dot_product_attention(hv(qr, n), hv(ki, p), hv(vi, p))
+    out = (wt * ot + wi * oi).transpose(1, 2).reshape(B * n, C)
+    loss = (out * do.float()).sum() + coef * hv(vi, p).norm(dim=-1).sum()
+    loss.backward()
+    assert rel_l2(dq.float(), qr.grad) < 3e-3
+    if wt != 0.0:
+        assert rel_l2(dkv_t[:, :C], kt.grad) < 2e-3 and rel_l2(dkv_t[:, C:], vt.grad) < 2e-3
+    else:
+        assert float(dkv_t.abs().max()) == 0.0
+    assert rel_l2(dkv_i[:, C:], vi.grad) < 2e-3
+    if p == 1:
+        assert float(dkv_i[:, :C].abs().max()) < 1e-4           # softmax over ONE key is constant: its key gets no gradient
+    elif wi != 0.0:
+        assert rel_l2(dkv_i[:, :C], ki.grad) < 2e-3
