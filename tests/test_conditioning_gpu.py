@@ -1192,3 +1192,52 @@ def test_gradient_reducer_over_rccl_one_rank(need_gpu):
             assert torch.equal(p.grad, x) and p.grad.data_ptr() >= red.flat.data_ptr()
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_training_step_batch_replication(need_gpu):
+    """configs[3] at its FULL size (bs=16, 64x64 latents, 5 tokens, SD-v1.5-sized UNet, LoRA r=8) through a size-independent property: every
+    loss term is a batch mean, so a batch of 16 copies of one sample must give the loss and the gradients of that sample alone (B=1, itself
+    checked against the fp32 oracle in test_full_size_training_gradients_match_oracle_autograd).  Covers what no oracle run can reach in
+    test time: the M = 65536 GEMM / conv / weight-gradient shapes, their split-K choices and the 16-sample attention launches of the backward."""
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    from photoverse_amd.clip import CLIPTextModel
+    from photoverse_amd.lora import LoraConfig, LoRALinear, inject_adapter_in_model
+    from photoverse_amd.train import TrainStep
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    E, T, D = 5, 257, 1024
+    unet = UNet2DConditionModel()
+    set_visual_cross_attention_adapter(unet, (E,))
+    inject_adapter_in_model(LoraConfig(r=8, lora_alpha=1), unet)
+    g = torch.Generator().manual_seed(51)
+    for m in unet.modules():
+        if isinstance(m, LoRALinear):
+            m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)
+    text_encoder, image_adapter, text_adapter = CLIPTextModel(), PhotoVerseAdapter(D, 768, E), PhotoVerseAdapter(D, 768, E)
+    for m in (unet, text_encoder, image_adapter, text_adapter):
+        m.to("cuda")
+    one = dict(noisy_latents=torch.randn(1, 4, 64, 64, generator=g), noise=torch.randn(1, 4, 64, 64, generator=g), timesteps=torch.tensor([633]),
+               text_input_ids=torch.randint(0, 49000, (1, 77), generator=g), placeholder_idx=torch.tensor([[4]]),
+               image_embeddings=[torch.randn(1, T, D, generator=g).half() for _ in range(E)])
+    forced = [0.5] * 16
+    forced[2], forced[11] = 0.1, 0.9
+
+    def run(B):
+        ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=64, w=64, n_tokens=E, grad_scale=4096.0, fusion_seed=5)
+        rep = lambda t: t.repeat(B, *([1] * (t.dim() - 1)))
+        kw = {k: ([rep(e).cuda() for e in v] if isinstance(v, list) else (rep(v) if k == "timesteps" else rep(v).cuda())) for k, v in one.items()}
+        out = ts.step(**kw, forced_fusion=forced)
+        torch.cuda.synchronize()
+        groups = ts.trainable_parameters()
+        res = {k: torch.cat([p.grad.detach().float().flatten() for p in ps]).cpu() for k, ps in groups.items()}
+        loss = float(out["loss"])
+        del ts
+        torch.cuda.empty_cache()
+        return loss, res
+    loss1, g1 = run(1)
+    loss16, g16 = run(16)
+    assert loss16 == pytest.approx(loss1, rel=2e-3)
+    errs = {k: rel_l2(g16[k], g1[k]) for k in g1}
+    print("bs=16 replicated vs bs=1 gradient rel-L2 per module:", errs)
+    # measured: UNet (to_k_ip / to_v_ip, LoRA) 3.5e-4, image adapter 7.7e-4, text adapter 1.2e-3
+    assert max(errs.values()) < 3e-3, errs
