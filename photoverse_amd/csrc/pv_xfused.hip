@@ -123,6 +123,15 @@ __device__ __forceinline__ half8_t vt_frag80(const half_t* sV, int key0, int dv0
 
 __device__ __forceinline__ half8_t cat4(half4_t a, half4_t b) { return half8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
+// Materialise a converted fragment HERE: without it LLVM sinks the fp32 -> fp16 conversion to the fragment's first use (a phase
+// later) and keeps - or spills - the fp32 accumulators in between.
+__device__ __forceinline__ void xf_pin(half4_t& v) {
+    typedef unsigned xf_u2 __attribute__((ext_vector_type(2)));
+    xf_u2 t = __builtin_bit_cast(xf_u2, v);
+    asm volatile("" : "+v"(t));
+    v = __builtin_bit_cast(half4_t, t);
+}
+
 template <int N>
 __device__ __forceinline__ void xf_wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -167,6 +176,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wo), 0, (int)p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.kimg), 0, (int)p.kimg_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vimg), 0, (int)p.vimg_bytes, 0x00020000);
+    // the workgroup's 128 rows of hs / out through buffer descriptors: one 32-bit row offset per lane instead of 64-bit pointers
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(hs) + (size_t)m0 * p.ld_hs, 0, 128 * p.ld_hs * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<half_t*>(p.out) + (size_t)m0 * p.ld_out, 0, 128 * p.ld_out * 2, 0x00020000);
 
     // ---- LDS-DMA issue helpers (one piece = one wave instruction = 1 KiB) -----------------------------------------------
     // Ring stage t of a [C][C] weight: rows [80 (t/KT), +80) x k [64 (t%KT), +64); 10 pieces of 8 rows x 128 B: waves 0,1 issue 3,
@@ -228,12 +240,14 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     // ---- phase 0: X^T into registers (+ LayerNorm) -----------------------------------------------------------------------
     half8_t xf[KK][2];
     int mrow[2];
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        mrow[qi] = m0 + wave * 32 + qi * 16 + fr;
-        const half_t* src = hs + (size_t)mrow[qi] * p.ld_hs + g * 8;
+        mrow[qi] = wave * 32 + qi * 16 + fr;                 // row inside the workgroup's block
+        const int off = mrow[qi] * p.ld_hs * 2 + g * 16;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = *reinterpret_cast<const half8_t*>(src + kk * 32);
+        for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rh, off, kk * 64, 0));
     }
     issue_group(0, buf1);                 // K/V of group 0 waits in buffer 1 while the Wq ring runs in buffer 0
     issue_stage(rq, buf0, 0);
@@ -312,9 +326,11 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi)
+                    for (int qi = 0; qi < 2; ++qi) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) qf[nc * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
+                        xf_pin(qf[nc * 5 + i][qi]);      // convert here: do not carry fp32 accumulators into the next chunk / phase
+                    }
             }
         }
     }
@@ -324,11 +340,13 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     wg_barrier();                          // every wave is done with the Wq ring (buffer 0)
     issue_group(1, buf0);
     half4_t cf[NFR][2];                    // context fragments, same layout as qf
-    bool tmask[4], imask[4];               // validity of this lane's keys in fragment 4 (text tail) and fragment 5 (image tokens)
+    // padding keys of fragment 4 (text tail) and fragment 5 (image tokens): their K rows are zero, so the MFMA leaves the
+    // accumulator's initial value in place - start those from -inf instead of selecting per score afterwards
+    float4_t tinit, iinit;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        tmask[r] = 64 + g * 4 + r < p.nt;
-        imask[r] = g * 4 + r < p.nip;
+        tinit[r] = 64 + g * 4 + r < p.nt ? 0.f : -INFINITY;
+        iinit[r] = g * 4 + r < p.nip ? 0.f : -INFINITY;
     }
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
             float4_t s[6][2];
 #pragma unroll
-            for (int kb = 0; kb < 6; ++kb) s[kb][0] = s[kb][1] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < 6; ++kb) s[kb][0] = s[kb][1] = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 half8_t bq[2];
@@ -366,11 +384,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             for (int qi = 0; qi < 2; ++qi) {
                 float mt = -INFINITY, mi = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!tmask[r]) s[4][qi][r] = -INFINITY;
-                    if (!imask[r]) s[5][qi][r] = -INFINITY;
-                    mi = fmaxf(mi, s[5][qi][r]);
-                }
+                for (int r = 0; r < 4; ++r) mi = fmaxf(mi, s[5][qi][r]);
 #pragma unroll
                 for (int kb = 0; kb < 5; ++kb)
 #pragma unroll
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 }
                 lt = pv_quad_sum(lt);
                 li = pv_quad_sum(li);
-                const float ft = w_text / lt, fi = w_ip / li;
+                const float ft = w_text * __builtin_amdgcn_rcpf(lt), fi = w_ip * __builtin_amdgcn_rcpf(li);
 #pragma unroll
                 for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
@@ -421,6 +435,8 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                         cf[grp * 5 + 0][qi][r] = (half_t)o[0][qi][r];
                         cf[grp * 5 + 1][qi][r] = (half_t)o[1][qi][r];
                     }
+                    xf_pin(cf[grp * 5 + 0][qi]);
+                    xf_pin(cf[grp * 5 + 1][qi]);
                     o2_h0[qi] = o[2][qi];
                 } else {
 #pragma unroll
@@ -429,6 +445,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                         cf[grp * 5 + 3][qi][r] = (half_t)o[1][qi][r];
                         cf[grp * 5 + 4][qi][r] = (half_t)o[2][qi][r];
                     }
+                    xf_pin(cf[grp * 5 + 2][qi]);
+                    xf_pin(cf[grp * 5 + 3][qi]);
+                    xf_pin(cf[grp * 5 + 4][qi]);
                 }
             }
         }
@@ -443,10 +462,14 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     }
 
     // ---- phase 3: out^T = Wo' . ctx^T, + bias + residual ----------------------------------------------------------------
+    // A lane's accumulator registers are 4 consecutive output columns of fragment i (8 bytes of fp16).  v_permlane16_swap trades the
+    // even lane-rows' fragment 2q+1 against the odd lane-rows' fragment 2q, after which every lane owns 8 CONSECUTIVE columns: the
+    // residual rows are fetched and the output rows stored with 16 bytes per lane (fragment 4, the odd one out, keeps 8 bytes).
     {
-        half_t* outp = reinterpret_cast<half_t*>(p.out);
         float4_t acc[5][2];
-        half4_t res[5][2];
+        uint4_t res16[2][2];              // residual of fragment pairs (0,1), (2,3) in the swapped (16-byte) layout
+        uint2_t res8[2];                  // residual of fragment 4
+        const int pcol = (g & 1) ? 16 + (g - 1) * 4 : g * 4;      // this lane's 8 columns inside a fragment pair
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int nc = t / KT, kt = t % KT;
@@ -454,10 +477,14 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             if (kt == 0) {
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < 5; ++i)
                     acc[i][0] = acc[i][1] = p.bias_o ? *reinterpret_cast<const float4_t*>(p.bias_o + nb + i * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) res[i][qi] = *reinterpret_cast<const half4_t*>(hs + (size_t)mrow[qi] * p.ld_hs + nb + i * 16);
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int roff = mrow[qi] * p.ld_hs * 2;
+                    res16[0][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2, nc * (GF * 2), 0);
+                    res16[1][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2, nc * (GF * 2) + 64, 0);
+                    res8[qi] = __builtin_amdgcn_raw_buffer_load_b64(rh, roff + g * 8, nc * (GF * 2) + 128, 0);
                 }
             }
             wait_except(t + 1 < NT ? 1 : 0, 0);
@@ -478,14 +505,36 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             }
             if (kt == KT - 1) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int ooff = mrow[qi] * p.ld_out * 2;
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) {
-                        half4_t ov;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(acc[i][qi][r] + (float)res[i][qi][r]);
-                        *reinterpret_cast<half4_t*>(outp + (size_t)mrow[qi] * p.ld_out + nb + i * 16) = ov;
+                    for (int q = 0; q < 2; ++q) {
+                        // residual back to the accumulator layout (the swap is its own inverse), add in fp32, round once, swap, store
+                        const auto u0 = __builtin_amdgcn_permlane16_swap(res16[q][qi][0], res16[q][qi][2], false, false);
+                        const auto u1 = __builtin_amdgcn_permlane16_swap(res16[q][qi][1], res16[q][qi][3], false, false);
+                        const unsigned ra0 = u0[0], rb0 = u0[1], ra1 = u1[0], rb1 = u1[1];
+                        const half2_t r00 = __builtin_bit_cast(half2_t, ra0), r01 = __builtin_bit_cast(half2_t, ra1);
+                        const half2_t r10 = __builtin_bit_cast(half2_t, rb0), r11 = __builtin_bit_cast(half2_t, rb1);
+                        const float4_t a0 = acc[2 * q][qi], a1 = acc[2 * q + 1][qi];
+                        const unsigned p00 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a0[0] + (float)r00[0]), (half_t)(a0[1] + (float)r00[1])});
+                        const unsigned p01 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a0[2] + (float)r01[0]), (half_t)(a0[3] + (float)r01[1])});
+                        const unsigned p10 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a1[0] + (float)r10[0]), (half_t)(a1[1] + (float)r10[1])});
+                        const unsigned p11 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a1[2] + (float)r11[0]), (half_t)(a1[3] + (float)r11[1])});
+                        const auto v0 = __builtin_amdgcn_permlane16_swap(p00, p10, false, false);
+                        const auto v1 = __builtin_amdgcn_permlane16_swap(p01, p11, false, false);
+                        const unsigned sa0 = v0[0], sb0 = v0[1], sa1 = v1[0], sb1 = v1[1];
+                        // constant part of the address in the IMMEDIATE offset, never in soffset: with an SGPR soffset the compiler does not separate a
+                        // > 8-byte store from a following VALU write of its data registers (the store then reads overwritten data in some lanes)
+                        __builtin_amdgcn_raw_buffer_store_b128(uint4_t{sa0, sa1, sb0, sb1}, rout, ooff + pcol * 2 + (nc * (GF * 2) + q * 64), 0, 0);
+                        asm volatile("s_nop 1" ::: "memory");
                     }
+                    const half2_t r0 = __builtin_bit_cast(half2_t, (unsigned)res8[qi][0]), r1 = __builtin_bit_cast(half2_t, (unsigned)res8[qi][1]);
+                    const float4_t a4 = acc[4][qi];
+                    const unsigned p0 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a4[0] + (float)r0[0]), (half_t)(a4[1] + (float)r0[1])});
+                    const unsigned p1 = __builtin_bit_cast(unsigned, half2_t{(half_t)(a4[2] + (float)r1[0]), (half_t)(a4[3] + (float)r1[1])});
+                    __builtin_amdgcn_raw_buffer_store_b64(uint2_t{p0, p1}, rout, ooff + g * 8 + (nc * (GF * 2) + 128), 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -517,7 +566,7 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     static_cast<pv_xattn_fused_params&>(p) = *pp;
     const int C = p.heads * p.d;
     if (!p.hs || !p.wq || !p.wo || !p.kimg || !p.vimg || !p.out || p.batch <= 0 || p.nq <= 0 || (p.nq % 128) || p.d != 40 || C != 320 ||
-        p.nt <= 64 || p.nt > XIP0 || p.nip <= 0 || p.nip > XK - XIP0 || (p.ld_hs % 8) || (p.ld_out % 4))
+        p.nt <= 64 || p.nt > XIP0 || p.nip <= 0 || p.nip > XK - XIP0 || (p.ld_hs % 8) || (p.ld_out % 8))
         return (int)hipErrorInvalidValue;
     p.w_bytes = (uint32_t)C * C * 2;
     const size_t kb = (size_t)p.batch * p.heads * XK * KROW, vb = (size_t)p.batch * (C / GF) * XK * GF * 2;
