@@ -8,7 +8,7 @@
 // read of hs and one write of out.  Built for the C = 320 / d = 40 layers (64x64 and larger levels: 63 % of attn2's launches'
 // time at 512x512), where M = B*N is large and the GEMMs are too short-K to run well on their own.
 //
-// Structure: one workgroup = 128 query rows x ALL heads, 4 waves, 78 KiB of LDS -> two workgroups per CU.  A wave owns 32 query
+// Structure: one workgroup = 128 query rows x ALL heads, 4 waves, 80 KiB of LDS -> two workgroups per CU.  A wave owns 32 query
 // rows (two 16-column MFMA operands) for the whole chain, so no activation ever leaves the register file:
 //
 //   phase 0  X^T (B operand of v_mfma_f32_16x16x32_f16: lane = query, 8 consecutive channels per k-group) is loaded straight
@@ -142,7 +142,11 @@ struct pv_xfused_params_dev : pv_xattn_fused_params {
     uint32_t w_bytes, kimg_bytes, vimg_bytes;
 };
 
-template <int C>
+// IP1: exactly one image token (the reference's inference default, token_index = 0 -> (B, 1, 768), adapters.py:32-37).  A softmax over
+// ONE key is 1 whatever the query, so the whole image-token branch is "+ w_ip * v_ip": its score fragment, its max / exp / sum and its
+// two 4-lane reductions disappear (a fifth of the attention phase's VALU work); the value row still rides in the P.V contraction with
+// the constant probability w_ip.
+template <int C, bool IP1>
 __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_params_dev p) {
     static_assert(C % GF == 0 && C % 64 == 0, "C must be a multiple of 80 and of 64");
     constexpr int D = 40;
@@ -151,18 +155,19 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     constexpr int KK = C / 32;        // 32-deep contraction steps over C: 10
     constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk: 5
     constexpr int NT = NG * KT;       // ring stages per GEMM phase: 20
-    constexpr int S = 3;              // ring depth
+    constexpr int S = 4;              // ring slots: two stages being read + two in flight (one workgroup barrier per PAIR of stages)
     constexpr int TILE_BYTES = GF * 128;                   // one stage: 80 weight rows x 64 k = 10 KiB
     constexpr int KIMG_BYTES = XK * KROW;                  // one head
     constexpr int VIMG_BYTES = XK * GF * 2;
     constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;   // K images of the group's two heads + V image: 39 KiB
     constexpr int GROUP_PIECES = GROUP_BYTES / 1024;
-    static_assert(GROUP_BYTES % 1024 == 0 && S * TILE_BYTES <= GROUP_BYTES, "LDS plan: a weight ring fits inside one K/V buffer");
-    // LDS: two 39-KiB buffers.  Buffer 0 = Wq ring (phase 1), K/V of groups 1 and 3; buffer 1 = K/V of groups 0 and 2, Wo ring (phase 3).
-    // 78 KiB per workgroup -> TWO independent workgroups per CU (each other's barrier / DMA / HBM waits are covered, as in the GEMM).
+    constexpr int BUF_BYTES = S * TILE_BYTES;              // 40 KiB
+    static_assert(GROUP_BYTES % 1024 == 0 && GROUP_BYTES <= BUF_BYTES, "LDS plan: a K/V group fits inside one ring buffer");
+    // LDS: two 40-KiB buffers.  Buffer 0 = Wq ring (phase 1), K/V of groups 1 and 3; buffer 1 = K/V of groups 0 and 2, Wo ring (phase 3).
+    // 80 KiB per workgroup -> TWO independent workgroups per CU (each other's barrier / DMA / HBM waits are covered, as in the GEMM).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const buf0 = smem;
-    char* const buf1 = smem + GROUP_BYTES;
+    char* const buf1 = smem + BUF_BYTES;
 
     const int lane = pv_lane_id(), wave = pv_wave_id();
     const int fr = lane & 15, g = lane >> 4;
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             case 3: xf_wait_vmcnt<3>(); break;
             case 4: xf_wait_vmcnt<4>(); break;
             case 6: xf_wait_vmcnt<6>(); break;
+            case 12: xf_wait_vmcnt<12>(); break;
             case 9: xf_wait_vmcnt<9>(); break;
             case 10: xf_wait_vmcnt<10>(); break;
             case 13: xf_wait_vmcnt<13>(); break;   // 2 stages (waves 2,3: 4) + group (wave 3: 9)
@@ -309,9 +315,14 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 for (int i = 0; i < 5; ++i)
                     acc[i][0] = acc[i][1] = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + nc * GF + i * 16 + g * 4) : float4_t{0.f, 0.f, 0.f, 0.f};
             }
-            if (t >= 1) wait_except(t + 1 < NT ? 1 : 0, 0);       // stage t landed; stage t+1 (issued an iteration ago) may be in flight
-            wg_barrier();                                          // ... for every wave, and buffer (t-1) % S is read out
-            if (t + 2 < NT) issue_stage(rq, buf0, t + 2);
+            if ((t & 1) == 0) {
+                // ONE barrier per pair of stages: stages t and t+1 were issued two stages ago right behind that barrier and nothing younger
+                // is in flight, so "landed" is vmcnt(0); behind the barrier the slots of stages t-2 / t-1 are read out by every wave
+                if (t >= 2) wait_except(0, 0);
+                wg_barrier();
+                if (t + 2 < NT) issue_stage(rq, buf0, t + 2);
+                if (t + 3 < NT) issue_stage(rq, buf0, t + 3);
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* base = buf0 + (t % S) * TILE_BYTES + ring_lane[ks];
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
         tinit[r] = 64 + g * 4 + r < p.nt ? 0.f : -INFINITY;
         iinit[r] = g * 4 + r < p.nip ? 0.f : -INFINITY;
     }
+    const half4_t ip1p = half4_t{g == 0 ? (half_t)w_ip : (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
         // group grp landed; in flight behind it: group grp+1 (grp < 3); at grp == 3 additionally the three Wo stages issued after group 2
@@ -362,16 +374,17 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
         for (int hh = 0; hh < 2; ++hh) {
             const char* sK = sbuf + hh * KIMG_BYTES;
             const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
-            float4_t s[6][2];
+            constexpr int NKB = IP1 ? 5 : 6;   // score fragments: 5 of text keys (+ 1 of image-token keys)
+            float4_t s[NKB][2];
 #pragma unroll
-            for (int kb = 0; kb < 6; ++kb) s[kb][0] = s[kb][1] = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < NKB; ++kb) s[kb][0] = s[kb][1] = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 half8_t bq[2];
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) bq[qi] = ks == 0 ? cat4(qf[fa][qi], qf[fb][qi]) : cat4(qf[f2][qi], qf[f2][qi]);
 #pragma unroll
-                for (int kb = 0; kb < 6; ++kb) {
+                for (int kb = 0; kb < NKB; ++kb) {
                     const half8_t a = ld_frag128(sK, kb * 16 + fr, ks * 4 + g);
 #pragma unroll
                     for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
@@ -382,16 +395,13 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
             half8_t pb[3][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
-                float mt = -INFINITY, mi = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mi = fmaxf(mi, s[5][qi][r]);
+                float mt = -INFINITY;
 #pragma unroll
                 for (int kb = 0; kb < 5; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kb][qi][r]);
                 mt = pv_quad_max(mt);
-                mi = pv_quad_max(mi);
-                float lt = 0.f, li = 0.f;
+                float lt = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 5; ++kb)
 #pragma unroll
@@ -399,21 +409,36 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                         s[kb][qi][r] = PV_EXP2(s[kb][qi][r] - mt);       // exp2(-inf) = 0 for the padding keys
                         lt += s[kb][qi][r];
                     }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[5][qi][r] = PV_EXP2(s[5][qi][r] - mi);
-                    li += s[5][qi][r];
-                }
                 lt = pv_quad_sum(lt);
-                li = pv_quad_sum(li);
-                const float ft = w_text * __builtin_amdgcn_rcpf(lt), fi = w_ip * __builtin_amdgcn_rcpf(li);
+                const float ft = w_text * __builtin_amdgcn_rcpf(lt);
 #pragma unroll
-                for (int s2 = 0; s2 < 3; ++s2)
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pb[s2][qi][r] = (half_t)(s[2 * s2][qi][r] * ft);
-                        pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * (s2 == 2 ? fi : ft));
+                        pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * ft);
                     }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[2][qi][r] = (half_t)(s[4][qi][r] * ft);
+                if constexpr (IP1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = ip1p[r];      // softmax over one key = 1: P = w_ip at key XIP0, 0 elsewhere
+                } else {
+                    float mi = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mi = fmaxf(mi, s[NKB - 1][qi][r]);
+                    mi = pv_quad_max(mi);
+                    float li = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s[NKB - 1][qi][r] = PV_EXP2(s[NKB - 1][qi][r] - mi);
+                        li += s[NKB - 1][qi][r];
+                    }
+                    li = pv_quad_sum(li);
+                    const float fi = w_ip * __builtin_amdgcn_rcpf(li);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = (half_t)(s[NKB - 1][qi][r] * fi);
+                }
             }
             // O^T = V^T . P^T for this head's three fragments of the group's 80 value columns
             float4_t o[3][2];
@@ -474,6 +499,28 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
         for (int t = 0; t < NT; ++t) {
             const int nc = t / KT, kt = t % KT;
             const int nb = nc * GF + g * 4;
+            if ((t & 1) == 0) {
+                // stages t, t+1 (issued two stages ago) landed.  vmcnt retires in order, so only what this wave issued AFTER those pieces may
+                // stay in flight: the 6 output stores of a chunk that ended in stage t-2 or t-1 and the 6 residual loads of a chunk that
+                // started there (the bias loads are not counted: a smaller count only waits longer).  Counting them exactly keeps the HBM
+                // write latency of a chunk's stores out of the next stages' critical path.
+                constexpr int RES = 6, STO = 6;
+                int younger = 0;
+                if (t >= 2) {
+                    if ((t - 2) % KT == 0) younger += RES;
+                    if ((t - 2) % KT == KT - 1) younger += STO;
+                    if ((t - 1) % KT == 0) younger += RES;
+                    if ((t - 1) % KT == KT - 1) younger += STO;
+                }
+                switch (younger) {
+                    case 6: xf_wait_vmcnt<6>(); break;
+                    case 12: xf_wait_vmcnt<12>(); break;
+                    default: xf_wait_vmcnt<0>(); break;
+                }
+                wg_barrier();
+                if (t + 2 < NT) issue_stage(ro, buf1, t + 2);
+                if (t + 3 < NT) issue_stage(ro, buf1, t + 3);
+            }
             if (kt == 0) {
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
 #pragma unroll
@@ -482,14 +529,11 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
                     const int roff = mrow[qi] * p.ld_hs * 2;
-                    res16[0][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2, nc * (GF * 2), 0);
-                    res16[1][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2, nc * (GF * 2) + 64, 0);
-                    res8[qi] = __builtin_amdgcn_raw_buffer_load_b64(rh, roff + g * 8, nc * (GF * 2) + 128, 0);
+                    res16[0][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2 + nc * (GF * 2), 0, 0);
+                    res16[1][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2 + nc * (GF * 2) + 64, 0, 0);
+                    res8[qi] = __builtin_amdgcn_raw_buffer_load_b64(rh, roff + g * 8 + nc * (GF * 2) + 128, 0, 0);
                 }
             }
-            wait_except(t + 1 < NT ? 1 : 0, 0);
-            wg_barrier();
-            if (t + 2 < NT) issue_stage(ro, buf1, t + 2);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* base = buf1 + (t % S) * TILE_BYTES + ring_lane[ks];
@@ -573,12 +617,13 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     if (kb >= (1ull << 31) || vb >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
-    constexpr int SMEM = 2 * (2 * XK * KROW + XK * GF * 2);   // two 39-KiB K/V buffers (the weight rings alias them): two workgroups per CU
-    static bool attr_set_dev[64] = {};
+    constexpr int SMEM = 2 * 4 * GF * 128;   // two 40-KiB buffers (4-slot weight ring / one 39-KiB K/V group each): two workgroups per CU
+    static bool attr_set_dev[64][2] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
-    bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = xattn_fused_kernel<320>;
+    const bool ip1 = p.nip == 1;
+    bool& attr_set = attr_set_dev[dev_id & 63][ip1 ? 1 : 0];
+    auto kern = ip1 ? xattn_fused_kernel<320, true> : xattn_fused_kernel<320, false>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
