@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 7
+#define PV_ABI_VERSION 8
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -330,19 +330,20 @@ int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
 int pv_reduce_blocks(const float* x, int32_t nblk, int64_t inner, float scale, float* out, void* stream);
 /* out[0] = scale * sum(a^2), deterministic (gradient norms of clip_grad_norm_) */
 int pv_reduce_sumsq(const float* a, int64_t n, float scale, float* partial, int32_t n_partial, float* out, void* stream);
-/* torch.optim.AdamW step on one fp32 tensor (train.py:372-377, :545); gscale (device scalar or NULL) multiplies the gradient
- * first - it carries 1/loss_scale and the clip_grad_norm_ coefficient without a host sync */
-int pv_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int32_t step, const float* gscale, void* stream);
 /* Multi-tensor forms of the three optimizer launches: ONE launch each over every parameter tensor.  entries: int64 [T][6] =
  * {param, grad, exp_avg, exp_avg_sq, gscale pointer (or 0), n}; workgroup b handles elements [blk_chunk[b] * chunk, + chunk) of tensor
  * blk_tensor[b].  pv_sumsq_multi: partial[b] = sum of grad^2 of that range; pv_clip_coef_groups: group g owns partial[group_start[g] ..
  * group_start[g+1]): out[2g] = base * min(1, max_norm / (base * sqrt(sum) + 1e-6)), out[2g+1] = base * sqrt(sum) (base = 1 / loss scale);
- * pv_adamw_multi: the AdamW update of every range, reading its tensor's gscale. */
+ * pv_adamw_multi: the AdamW update (torch.optim.AdamW, train.py:372-377, :545) of every range, reading its tensor's gscale.
+ * Overflow guard (fp16 gradients under a static loss scale): when any group norm is not finite, pv_clip_coef_groups writes -1 into every
+ * out[2g] and adds 1 to counters[1]; otherwise it adds 1 to counters[0] (applied steps).  pv_adamw_multi skips tensors whose gscale is
+ * negative and, given counters, takes its bias-correction step from counters[0] instead of `step` - the behaviour of torch's GradScaler,
+ * without a host synchronisation.  counters may be NULL (no guard bookkeeping; `step` is used). */
 int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float* partial, void* stream);
-int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, void* stream);
+int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, int32_t* counters,
+                        void* stream);
 int pv_adamw_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+                   float beta2, float eps, float weight_decay, int32_t step, const int32_t* counters, void* stream);
 /* The fp16 working copies of the trainable weights, re-made from their fp32 masters after every optimizer step (the reference's autocast does
  * the same cast inside every Linear, train.py:464-470) - ONE launch over all of them.  entries: int64 [E][9] = {src (fp32), ld_src, rows, cols,
  * scale (float bits in the low word), dst (fp16), ld_dst, dstT (fp16 or 0), ld_dstT}: dst[r][c] = fp16(scale * src[r][c]) and, when given,
@@ -350,8 +351,6 @@ int pv_adamw_multi(const int64_t* entries, const int32_t* blk_tensor, const int3
  * over ceil(rows/32) x ceil(cols/32)) of entry blk_entry[b].  A destination may be a block of a larger zero-padded matrix (block-diagonal LoRA
  * factors, stacked k / v projections). */
 int pv_pack_weights(const int64_t* entries, const int32_t* blk_entry, const int32_t* blk_tile, int32_t n_blocks, void* stream);
-/* clip_grad_norm_ (train.py:538-541): out[0] = base * min(1, max_norm / (sqrt(sum_i sumsq[i]) + 1e-6)), out[1] = the norm */
-int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream);
 /* out[c] = sum_r x[r][c] over fp16 rows (bias gradients); partial: nblk*cols floats */
 int pv_colsum_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, float* partial, int32_t nblk, float* out, void* stream);
 

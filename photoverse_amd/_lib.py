@@ -104,8 +104,6 @@ SIGNATURES = {
     "pv_layernorm_backward": (c_int, [C.POINTER(LayerNormBwdParams), c_void_p]),
     "pv_reduce_blocks": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]),
     "pv_colsum_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "pv_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
-                              c_void_p]),
     "pv_attention_backward": (c_int, [C.POINTER(AttnBwdParams), c_void_p]),
     "pv_groupnorm_backward": (c_int, [C.POINTER(GroupNormBwdParams), c_void_p]),
     "pv_geglu_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -129,9 +127,8 @@ SIGNATURES = {
     "pv_reduce_sumsq": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "pv_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pv_sumsq_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "pv_clip_coef_groups": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
-    "pv_adamw_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
-    "pv_clip_coef": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "pv_clip_coef_groups": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pv_adamw_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "pv_geglu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pv_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -153,7 +150,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -214,35 +214,7 @@ __global__ __launch_bounds__(256) void colsum_f16_kernel(const half_t* x, int ld
     partial[(size_t)blockIdx.y * cols + c] = a;
 }
 
-// torch.optim.AdamW step (train.py:372-377), one launch per parameter tensor, fp32 state:
-//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),   g = grad * gscale
-// gscale folds the loss-scale removal and the clip_grad_norm_ coefficient; it is read from DEVICE memory (no host sync).
-__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt, const float* gscale) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gs = gscale ? gscale[0] : 1.f;
-    const float gi = g[i] * gs;
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
-    p[i] = pi; m[i] = mi; v[i] = vi;
-}
 
-// clip coefficient of torch.nn.utils.clip_grad_norm_: out[0] = min(1, max_norm / (sqrt(sum_sq) + 1e-6)) * base, sum_sq = sum of sq[i]
-__global__ void clip_coef_kernel(const float* sq, int n, float max_norm, float base, float* out) {
-    float a = 0.f;
-    for (int i = 0; i < n; ++i) a += sq[i];
-    const float norm = sqrtf(a);
-    out[0] = fminf(1.f, max_norm / (norm + 1e-6f)) * base;
-    out[1] = norm;
-}
-
-
-// ---- multi-tensor forms: ONE launch over every parameter tensor (a training step has ~220 of them; three launches instead of ~700) ----
-// entry t = 6 x int64 {param, grad, exp_avg, exp_avg_sq, gscale (device float or 0), n}; workgroup b works on elements
-// [blk_chunk[b] * chunk, +chunk) of tensor blk_tensor[b]
 struct MtEntry { float* p; const float* g; float* m; float* v; const float* gs; long n; };
 
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const MtEntry* e, const int* blk_tensor, const int* blk_chunk, int chunk, float* partial) {
@@ -257,22 +229,36 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const MtEntry* e, cons
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// group g owns the partial sums [start[g], start[g+1]) (fixed order): out[g] = {base * min(1, max_norm / (norm + 1e-6)), norm}, norm of grad / scale
-__global__ void clip_coef_groups_kernel(const float* partial, const int* start, int groups, float max_norm, float base, float* out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
-    float a = 0.f;
-    for (int i = start[g]; i < start[g + 1]; ++i) a += partial[i];
-    const float norm = sqrtf(a) * base;
-    out[2 * g] = fminf(1.f, max_norm / (norm + 1e-6f)) * base;
-    out[2 * g + 1] = norm;
+// group g owns the partial sums [start[g], start[g+1]) (fixed order): out[g] = {base * min(1, max_norm / (norm + 1e-6)), norm}, norm of grad / scale.
+// OVERFLOW GUARD (gradients are fp16 with a static loss scale; the fp32 reference cannot overflow there): if ANY group's norm is not finite
+// the whole optimizer step is skipped, as torch's GradScaler does - every coefficient becomes -1 (pv_adamw_multi leaves parameters, moments
+// and the bias-correction step untouched) and counters[1] counts the skipped step; otherwise counters[0], the number of APPLIED steps, advances.
+__global__ __launch_bounds__(256) void clip_coef_groups_kernel(const float* partial, const int* start, int groups, float max_norm, float base, float* out, int* counters) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        float a = 0.f;
+        for (int i = start[g]; i < start[g + 1]; ++i) a += partial[i];
+        const float norm = sqrtf(a) * base;
+        out[2 * g] = fminf(1.f, max_norm / (norm + 1e-6f)) * base;
+        out[2 * g + 1] = norm;
+        if (!isfinite(norm)) atomicOr(&bad, 1);          // LDS flag; the result does not depend on arrival order
+    }
+    __syncthreads();
+    if (bad)
+        for (int g = threadIdx.x; g < groups; g += 256) out[2 * g] = -1.f;
+    if (threadIdx.x == 0 && counters) counters[bad ? 1 : 0] += 1;
 }
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const MtEntry* e, const int* blk_tensor, const int* blk_chunk, int chunk, float lr, float b1, float b2,
-                                                          float eps, float wd, float bc1, float bc2_sqrt) {
+                                                          float eps, float wd, int step, const int* counters) {
     const MtEntry t = e[blk_tensor[blockIdx.x]];
     const long i0 = (long)blk_chunk[blockIdx.x] * chunk, i1 = min(i0 + chunk, t.n);
     const float gs = t.gs ? t.gs[0] : 1.f;
+    if (gs < 0.f) return;                                // overflow in this step's gradients: skipped (clip_coef_groups_kernel)
+    const int tstep = counters ? counters[0] : step;     // bias correction counts APPLIED steps
+    const float bc1 = 1.f - powf(b1, (float)tstep), bc2_sqrt = sqrtf(1.f - powf(b2, (float)tstep));
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
         const float gi = t.g[i] * gs;
         float pi = t.p[i] * (1.f - lr * wd);
@@ -330,34 +316,18 @@ extern "C" int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor,
     return PV_CHECK_LAUNCH();
 }
 
-extern "C" int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, void* stream) {
+extern "C" int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, int32_t* counters,
+                                   void* stream) {
     if (!partial || !group_start || !out || groups <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(clip_coef_groups_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, (hipStream_t)stream, partial, group_start, groups, max_norm, base,
-                       out);
+    hipLaunchKernelGGL(clip_coef_groups_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, group_start, groups, max_norm, base, out, counters);
     return PV_CHECK_LAUNCH();
 }
 
 extern "C" int pv_adamw_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int32_t step, void* stream) {
-    if (!entries || !blk_tensor || !blk_chunk || n_blocks <= 0 || chunk <= 0 || step <= 0) return (int)hipErrorInvalidValue;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+                              float beta2, float eps, float weight_decay, int32_t step, const int32_t* counters, void* stream) {
+    if (!entries || !blk_tensor || !blk_chunk || n_blocks <= 0 || chunk <= 0 || (step <= 0 && !counters)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MtEntry*>(entries), blk_tensor,
-                       blk_chunk, chunk, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
-    return PV_CHECK_LAUNCH();
-}
-
-extern "C" int pv_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int32_t step, const float* gscale, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return (int)hipErrorInvalidValue;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2s, gscale);
-    return PV_CHECK_LAUNCH();
-}
-
-extern "C" int pv_clip_coef(const float* sumsq, int32_t n, float max_norm, float base, float* out, void* stream) {
-    if (!sumsq || !out || n <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, n, max_norm, base, out);
+                       blk_chunk, chunk, lr, beta1, beta2, eps, weight_decay, step, counters);
     return PV_CHECK_LAUNCH();
 }
 

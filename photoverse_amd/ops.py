@@ -73,6 +73,8 @@ class Recorder:
             raise RuntimeError("photoverse_amd: a HIP device is required; there is no CPU path")
         self.calls: List[tuple] = []
         self.tags: List[tuple] = []        # per call: (kernel name, algorithmic flops, algorithmic bytes)
+        self.roles: List[Optional[str]] = []   # per call: the role label active when it was recorded (``self.role``; measurement only)
+        self.role: Optional[str] = None
         self.keep: List[object] = []       # tensors / structs referenced by raw pointer
         self.colstats: dict = {}           # (data_ptr, rows, cols) of a GEMM output -> its epilogue column statistics
         self.bytes_allocated = 0
@@ -93,6 +95,7 @@ class Recorder:
         self.keep.extend(a for a in args if isinstance(a, C.Structure))
         self.calls.append((fn, tuple(C.byref(a) if isinstance(a, C.Structure) else a for a in args)))
         self.tags.append(tag if tag is not None else (fn.__name__, 0, 0))
+        self.roles.append(self.role)
 
     def subset(self, pred) -> "Recorder":
         """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
@@ -101,6 +104,14 @@ class Recorder:
         sel = [i for i, t in enumerate(self.tags) if pred(t)]
         r.calls = [self.calls[i] for i in sel]
         r.tags = [self.tags[i] for i in sel]
+        r.roles, r.role = [self.roles[i] for i in sel], None
+        return r
+
+    def subset_role(self, role: str) -> "Recorder":
+        """The calls recorded under ``self.role == role`` (e.g. the attn2 branch of one channel width), for per-branch timing."""
+        r = self.subset(lambda t: True)
+        sel = [i for i, ro in enumerate(self.roles) if ro == role]
+        r.calls, r.tags, r.roles = [self.calls[i] for i in sel], [self.tags[i] for i in sel], [self.roles[i] for i in sel]
         return r
 
     def run(self, stream: Optional[int] = None):
@@ -212,7 +223,7 @@ class Recorder:
         ldo, _ = _rows(out)
         p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal), _ptr(lse))
         self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
-        self._add(self.lib.pv_attention, p)
+        self._add(self.lib.pv_attention, p, tag=("pv_attention", 4.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (2 * nq + 2 * nk)))
         return out
 
     # ---- backward of the stock blocks the training gradient crosses (pv_train.hip) ----
@@ -228,7 +239,8 @@ class Recorder:
                           _ptr(lse), _ptr(delta), _ptr(qs), C_, _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
                           int(causal))
         self.keep.extend((q, k, v, out, dout, lse, dq, dk, dv))
-        self._add(self.lib.pv_attention_backward, p)
+        # five matrix products of 2 nq nk d each (S, dP, dV, dK, dQ): the usual algorithmic count of a flash backward
+        self._add(self.lib.pv_attention_backward, p, tag=("pv_attention_backward", 10.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (4 * nq + 4 * nk)))
         return dq, dk, dv
 
     def groupnorm_backward(self, x, dy, stats, gamma, beta, *, batch, hw, x1=None, act=ACT_NONE, groups=32, add0=None, add1=None,
@@ -389,7 +401,7 @@ class Recorder:
                         _rows(vip)[0], _ptr(out), _rows(out)[0], _ptr(vnorm), batch, heads, nq, nt, nip, d, float(w_text), float(w_ip),
                         _ptr(fusion))
         self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm, fusion) if t is not None)
-        self._add(self.lib.pv_cross_attention, p)
+        self._add(self.lib.pv_cross_attention, p, tag=("pv_cross_attention", 4.0 * batch * nq * (nt + nip) * heads * d, 2.0 * 2 * batch * nq * heads * d))
         return out, p
 
     # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual), C = 320 / d = 40 layers ----
@@ -431,7 +443,7 @@ class Recorder:
         self.keep.extend(t for t in (hs, wq, q_bias, wo_packed, bias_o, kimg, vimg, fusion, out) if t is not None)
         M = batch * nq
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
-        self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320>", flops, 2.0 * (3 * M * C + 2 * C * C)))
+        self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320, %s>" % ("true" if nip == 1 else "false"), flops, 2.0 * (3 * M * C + 2 * C * C)))
         return out, p
 
     # ---- backward of PhotoVerse's own trainable modules (pv_backward.hip) ----
@@ -451,7 +463,7 @@ class Recorder:
                            _ptr(dout), _rows(dout)[0], _ptr(dq), C_, _ptr(partial), _ptr(stats), _ptr(dkt), _ptr(dvt), _ptr(dkip), _ptr(dvip), 2 * C_, 2 * C_, batch, heads, nq, nt,
                            nip, d, float(w_text), float(w_ip), _ptr(fusion), float(out_scale), float(vnorm_coef), _ptr(vnorm_grad))
         self.keep.extend(t for t in (q, kt, vt, kip, vip, dout, fusion, vnorm_grad) if t is not None)
-        self._add(self.lib.pv_cross_attention_backward, p)
+        self._add(self.lib.pv_cross_attention_backward, p, tag=("pv_cross_attention_backward", 10.0 * batch * nq * (nt + nip) * heads * d, 2.0 * 3 * batch * nq * heads * d))
         return dq, dkv_t, dkv_i
 
     def transpose(self, x, rows_pad=None):

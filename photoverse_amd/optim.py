@@ -4,6 +4,10 @@
 Same update rule as ``torch.optim.AdamW`` (decoupled weight decay, bias correction).  The clip coefficient and the loss-scale removal
 are computed ON THE DEVICE (``pv_sumsq_multi`` -> ``pv_clip_coef_groups`` -> read by ``pv_adamw_multi``: three multi-tensor launches over all
 ~220 parameter tensors, fixed summation order), so a step needs no host synchronisation.  State (exp_avg, exp_avg_sq) is fp32; parameters must be fp32 CUDA tensors.
+
+Overflow guard: the training plans carry fp16 gradients under a static loss scale; the fp32 reference cannot overflow there.  When a
+clip group's gradient norm is not finite the WHOLE step is skipped on the device (parameters, moments and the bias-correction step stay
+untouched), as ``torch.cuda.amp.GradScaler`` does; ``skipped_steps`` / ``applied_steps`` read the device counters.
 """
 from __future__ import annotations
 
@@ -23,16 +27,29 @@ class AdamW:
             if not p.is_cuda or p.dtype != torch.float32:
                 raise RuntimeError("photoverse_amd.optim.AdamW updates fp32 parameters on a HIP device (no CPU path)")
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self.step_count = 0                # calls of step(); the bias correction uses the device's count of APPLIED steps
         self.state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.params}
+        self._counters = torch.zeros(2, dtype=torch.int32, device=self.params[0].device)     # [applied, skipped] (written by pv_clip_coef_groups)
+
+    @property
+    def applied_steps(self) -> int:
+        """Steps whose update was applied (host sync).  Equals ``step_count`` unless gradients overflowed."""
+        return int(self._counters[0].item()) if self._guarded else self.step_count
+
+    @property
+    def skipped_steps(self) -> int:
+        return int(self._counters[1].item())
+
+    _guarded = False                       # becomes True once a step ran with clip groups (the guard lives in the clip-coefficient kernel)
 
     # ---- torch.optim.AdamW's checkpoint format (modeling_utils.save_progress stores optimizer.state_dict(), modeling_utils.py:43-44) ----
     def state_dict(self):
         state = {}
         if self.step_count:
+            applied = self.applied_steps
             for i, p in enumerate(self.params):
                 m, v = self.state[id(p)]
-                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+                state[i] = {"step": torch.tensor(float(applied)), "exp_avg": m, "exp_avg_sq": v}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": True,     # torch >= 2.6: AdamW is Adam with this flag; a group without it loads as coupled L2 decay
@@ -56,6 +73,8 @@ class AdamW:
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ: this optimizer keeps one step counter")
         self.step_count = steps.pop() if steps else 0
+        self._counters.zero_()
+        self._counters[0] = self.step_count
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -112,8 +131,13 @@ class AdamW:
         rec = Recorder(dev)
         if used:
             rec._add(rec.lib.pv_sumsq_multi, _ptr(mt["entries"]), _ptr(mt["blk_t"]), _ptr(mt["blk_c"]), mt["n_grouped"], self.CHUNK, _ptr(mt["partial"]))
-            rec._add(rec.lib.pv_clip_coef_groups, _ptr(mt["partial"]), _ptr(mt["starts"]), len(used), float(max_norm), 1.0 / grad_scale, _ptr(mt["coef"]))
+            rec._add(rec.lib.pv_clip_coef_groups, _ptr(mt["partial"]), _ptr(mt["starts"]), len(used), float(max_norm), 1.0 / grad_scale, _ptr(mt["coef"]),
+                     _ptr(self._counters))
+            self._guarded = True
+        elif self._guarded:
+            self._counters[0] += 1                                               # keep the applied-step count moving without clip groups
         rec._add(rec.lib.pv_adamw_multi, _ptr(mt["entries"]), _ptr(mt["blk_t"]), _ptr(mt["blk_c"]), mt["n_blocks"], self.CHUNK, float(self.lr),
-                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count)
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count,
+                 _ptr(self._counters) if self._guarded else 0)
         rec.run()
         return [mt["coef"][slot[g], 1:2] for g in used]

@@ -279,6 +279,7 @@ class UNetEngine:
         if self.fusion_tab is not None:                      # this layer's (w_text, w_ip) slot of the device-side draw
             fus = self.fusion_tab[len(self.fusion_names)]
             self.fusion_names.append(name)
+        rec.role = f"attn2:{C}"                           # measurement label: the per-step launches of this layer's attn2 branch
         if USE_XFUSED and Recorder.xattn_fused_supported(C, heads, n, self.NT, self.P):
             # ONE launch for norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual (pv_xfused.hip); the K / V images and
             # to_v_ip_norm depend on the conditioning only (rec_cond)
@@ -295,6 +296,7 @@ class UNetEngine:
                                          nip=self.P, d=d, vnorm=vnorm, fusion=fus)
             self.xattn_params[name] = xp
             hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
+        rec.role = None
         # --- GEGLU feed-forward ---
         n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
         wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))

@@ -345,6 +345,41 @@ def test_adamw_and_clip_match_torch(grad_scale):
             assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
 
 
+@pytest.mark.gpu
+def test_adamw_skips_a_step_whose_gradients_overflowed():
+    """fp16 gradients under a static loss scale can overflow where the fp32 reference cannot: a non-finite group norm must SKIP the step
+    (parameters, moments and the bias-correction count untouched - GradScaler semantics, decided on the device), not write NaN into
+    every parameter of the group; the following steps equal torch.optim.AdamW stepping only on the finite gradients."""
+    from photoverse_amd.optim import AdamW
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 48), (48,), (33, 5)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    o_hip = AdamW(mine, lr=1e-2, weight_decay=1e-2)
+    groups = ([0, 1], [2])
+    for step, poison in enumerate((None, float("inf"), float("nan"), None, None)):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone()
+            q.grad = (gr * 128.0).cuda()
+        before = [q.detach().clone() for q in mine]
+        if poison is not None:
+            mine[2].grad[3, 1] = poison                    # one element of ONE group: the whole step is skipped, every group
+        else:
+            for grp in groups:
+                torch.nn.utils.clip_grad_norm_([ref[i] for i in grp], 1.0)
+            o_ref.step()
+        o_hip.step(clip_groups=[[mine[i] for i in grp] for grp in groups], max_norm=1.0, grad_scale=128.0)
+        for b, q, p in zip(before, mine, ref):
+            assert torch.isfinite(q).all()
+            if poison is not None:
+                assert torch.equal(q.detach(), b)
+            assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
+    assert o_hip.skipped_steps == 2 and o_hip.applied_steps == 3 and o_hip.step_count == 5
+    assert int(o_hip.state_dict()["state"][0]["step"]) == 3             # the checkpoint carries the applied count (torch's bias correction)
+
+
 @pytest.mark.parametrize("p_drop,hw", [(0.0, 16), (0.1, 16), (0.0, 20)])
 def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     """The whole backward of a training step (train.py:495-536 without the optional face loss) on the HIP plans: gradient of
@@ -491,94 +526,6 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     upd_h = torch.cat([(h_params[n].detach().cpu() - before[n].cpu()).flatten() for n in train_names])
     upd_r = torch.cat([(r_params[n].detach() - before[n].cpu()).flatten() for n in train_names])
     assert rel_l2(upd_h, upd_r) < 0.15          # sign flips of near-zero gradient entries dominate: each flips a full +-lr step
-
-
-def test_full_size_training_gradients_match_oracle_autograd(need_gpu):
-    """The training backward at the FULL model sizes (SD-v1.5 UNet 859.5 M parameters, 12-layer CLIP text encoder, 1024-wide adapters,
-    5 tokens, LoRA r=8), B=1, 64x64 latents: gradients of every trainable group against torch autograd over the fp32 oracle
-    (~1.5 min of host time).  Covers the N=4096 / d=40 attention backward, all four resolution levels, skip connections."""
-    import torch.nn.functional as F
-    from oracle.adapters_ref import PhotoVerseAdapterRef
-    from oracle.clip_ref import CLIPTextModelRef
-    from oracle.unet_ref import UNet2DConditionModelRef, get_visual_cross_attention_values_norm_ref, set_visual_cross_attention_adapter_ref
-    from photoverse_amd.adapters import PhotoVerseAdapter
-    from photoverse_amd.clip import CLIPTextModel
-    from photoverse_amd.lora import LoraConfig, LoRALinear, inject_adapter_in_model
-    from photoverse_amd.train import TrainStep
-    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
-    torch.manual_seed(0)
-    E, B, T, D = 5, 1, 257, 1024
-    lcfg = LoraConfig(r=8, lora_alpha=1)
-    r_unet = UNet2DConditionModelRef().eval()
-    set_visual_cross_attention_adapter_ref(r_unet, (E,))
-    inject_adapter_in_model(lcfg, r_unet)
-    g = torch.Generator().manual_seed(41)
-    for m in r_unet.modules():
-        if isinstance(m, LoRALinear):
-            m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)
-    r_txt = CLIPTextModelRef().eval()
-    r_ia, r_ta = PhotoVerseAdapterRef(D, 768, E).eval(), PhotoVerseAdapterRef(D, 768, E).eval()
-    unet = UNet2DConditionModel()
-    set_visual_cross_attention_adapter(unet, (E,))
-    inject_adapter_in_model(lcfg, unet)
-    unet.load_state_dict(r_unet.state_dict())
-    text_encoder = CLIPTextModel(); text_encoder.load_state_dict(r_txt.state_dict())
-    image_adapter = PhotoVerseAdapter(D, 768, E); image_adapter.load_state_dict(r_ia.state_dict())
-    text_adapter = PhotoVerseAdapter(D, 768, E); text_adapter.load_state_dict(r_ta.state_dict())
-    for m in (unet, text_encoder, image_adapter, text_adapter):
-        m.to("cuda")
-    for p in list(r_unet.parameters()) + list(r_txt.parameters()):
-        p.requires_grad_(False)
-    r_params = dict(r_unet.named_parameters())
-    train_names = [n for n in r_params if "to_k_ip" in n or "to_v_ip" in n or "lora_" in n]
-    for n in train_names:
-        r_params[n].requires_grad_(True)
-    noisy, noise = torch.randn(B, 4, 64, 64, generator=g), torch.randn(B, 4, 64, 64, generator=g)
-    timesteps = torch.tensor([417])
-    ids = torch.randint(0, 49000, (B, 77), generator=g)
-    pidx = torch.tensor([[4]])
-    embs = [torch.randn(B, T, D, generator=g).half() for _ in range(E)]
-    forced = [0.5] * 16                                   # (1, 1) everywhere: every branch of every layer carries gradient
-    forced[3], forced[9] = 0.1, 0.9                       # ... except one text-only and one image-only layer
-    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=64, w=64, n_tokens=E, grad_scale=4096.0, fusion_seed=3)
-    out = ts.step(noisy_latents=noisy.cuda(), noise=noise.cuda(), timesteps=timesteps, text_input_ids=ids.cuda(), placeholder_idx=pidx.cuda(),
-                  image_embeddings=[e.cuda() for e in embs], forced_fusion=forced)
-    torch.cuda.synchronize()
-    LoRALinear.forward = lambda self, x: F.linear(x, self.weight, self.bias)
-    try:
-        e32 = [e.float() for e in embs]
-        concept = r_ta(e32)
-        ehs = r_txt({"text_input_ids": ids, "concept_text_embeddings": concept, "concept_placeholder_idx": pidx})[0]
-        ehs_img = r_ia(e32)
-        mods = dict(r_unet.named_modules())
-        for name, u in zip(ts.fusion_names, forced):
-            mods[name + ".transformer_blocks.0.attn2"].processor.forced_fusion_seed = u
-        with torch.enable_grad():
-            pred = r_unet(noisy, timesteps, encoder_hidden_states=(ehs, ehs_img)).sample
-            vn = get_visual_cross_attention_values_norm_ref(r_unet)
-            loss = F.mse_loss(pred, noise) + 0.01 * concept.abs().mean() + 0.001 * vn.mean()
-            loss.backward()
-    finally:
-        del LoRALinear.forward
-    assert out["loss"].item() == pytest.approx(loss.item(), rel=5e-3)
-    S = ts.grad_scale
-    h_params = dict(unet.named_parameters())
-
-    def group_err(pairs):
-        a = torch.cat([(hp.grad.float().cpu() / S).flatten() for hp, _ in pairs])
-        b = torch.cat([(rp.grad if rp.grad is not None else torch.zeros_like(rp)).flatten() for _, rp in pairs])
-        return rel_l2(a, b)
-    groups = dict(ip=[(h_params[n], r_params[n]) for n in train_names if "_ip" in n],
-                  lora_A=[(h_params[n], r_params[n]) for n in train_names if "lora_A" in n],
-                  lora_B=[(h_params[n], r_params[n]) for n in train_names if "lora_B" in n],
-                  image_adapter=list(zip(image_adapter.parameters(), r_ia.parameters())),
-                  text_adapter=list(zip(text_adapter.parameters(), r_ta.parameters())))
-    assert len(groups["ip"]) == 32 and len(groups["lora_A"]) == 48
-    errs = {k: group_err(v) for k, v in groups.items()}
-    print("full-size training-step gradient rel-L2 per group:", errs)
-    # measured: ip 9.1e-4, LoRA A / B 1.0e-3 / 7.8e-4, image / text adapter 1.3e-3 / 3.1e-3
-    assert max(errs["ip"], errs["lora_A"], errs["lora_B"]) < 5e-3, errs
-    assert max(errs["image_adapter"], errs["text_adapter"]) < 1.5e-2, errs
 
 
 @pytest.mark.parametrize("smooth_face", [False, True])

@@ -271,10 +271,22 @@ def main():
         m.to(device)
     face = None
     if args.face_loss:
+        # the reference builds ArcFaceResNet18(pretrained=True) (models/loss.py:21-22): an identity loss against a randomly initialised
+        # network is meaningless, so weights are REQUIRED unless the whole run is a random-init smoke run
+        smoke = args.tiny or args.pretrained_model_name_or_path in (None, "random")
+        if not args.arcface_weights and not smoke:
+            raise SystemExit("--face_loss arcface needs --arcface_weights <state dict of the ArcFace IR-ResNet18> (the reference downloads "
+                             "them, this build has no network); only --tiny / random-init runs may use a randomly initialised ArcFace")
         face = FaceLoss(device, args.face_loss)
         if args.arcface_weights:
-            face.model.load_state_dict(torch.load(args.arcface_weights, map_location="cpu"))
+            sd = torch.load(args.arcface_weights, map_location="cpu")
+            # the published checkpoint is a DataParallel state dict (models/arcface_resnet.py:131-134): strip its 'module.' prefix
+            sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+            face.model.load_state_dict(sd)
             face.model.to(device)
+        elif main_process:
+            print("WARNING: --face_loss arcface without --arcface_weights: the identity loss uses a RANDOMLY INITIALISED ArcFace network "
+                  "(smoke run only)", flush=True)
     os.makedirs(args.output_dir, exist_ok=True)
     lat = args.resolution // 8
     B = args.train_batch_size
@@ -284,7 +296,13 @@ def main():
                      fusion_seed=args.seed or 0, face_loss=face, vae=vae if face is not None else None, noise_scheduler=noise_scheduler,
                      face_samples=max(int(args.face_loss_sample_ratio * B), 1), guidance_scale=args.guidance_scale, image_size=args.resolution)
     groups = step.trainable_parameters()
-    optimizer = AdamW([p for g in groups.values() for p in g], lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+    # parameter ORDER as the reference builds it (train.py:366-372: image_adapter, text_adapter, then the UNet's trainable parameters in
+    # named_parameters() order): torch.optim state dicts are keyed by index, so the 'optimizer' entry of a checkpoint is only portable
+    # between the two code bases with the same order (the two adapters have identical shapes - a swap would load without an error)
+    trainable = {id(p) for g in groups.values() for p in g}
+    ordered = list(image_adapter.parameters()) + list(text_adapter.parameters()) + [p for _n, p in unet.named_parameters() if id(p) in trainable]
+    assert {id(p) for p in ordered} == trainable and len(ordered) == len(trainable)
+    optimizer = AdamW(ordered, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
                       weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)                                         # train.py:372-377
     sched = lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps)
     if args.synthetic_data:
@@ -320,6 +338,11 @@ def main():
                 logs["loss_face"] = float(out["face_loss"])
             if main_process:
                 print(f"step {global_step}: " + ", ".join(f"{k}={v:.6g}" for k, v in logs.items()), flush=True)
+            if not all(math.isfinite(v) for v in logs.values()):
+                # fp16 activations / gradients under a static loss scale can overflow where the fp32 reference cannot; the optimizer skips
+                # steps whose gradient norm is not finite (optim.AdamW), a non-finite LOSS means the forward itself overflowed: stop
+                raise SystemExit(f"non-finite loss at step {global_step} ({logs}); optimizer skipped {optimizer.skipped_steps} step(s) so far - "
+                                 "lower --grad_scale or the learning rate")
             if main_process and args.samples_save_steps and global_step % args.samples_save_steps == 0:                            # train.py:555-596
                 save_samples(args, global_step, batch, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae,
                              noise_scheduler, device, face)
