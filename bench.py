@@ -57,6 +57,38 @@ def cpu_baseline(seconds_budget=40.0):
                       f"(+{build_s:.1f} s model build, untimed); value = (1/{dt:.2f})/16"}
 
 
+def build_random_unet(ip_tokens, dev):
+    """SD-v1.5-shaped UNet + PhotoVerse processors with seeded random weights, drawn ON THE DEVICE: torch's default CPU initialisers take
+    ~30 s for the 878 M parameters (the driver's clock runs around the whole script); U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like
+    nn.Linear / nn.Conv2d defaults, norm scales 1 / biases 0, identical on every rank (same seed)."""
+    import torch
+    import torch.nn as nn
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    saved = [(cls, cls.reset_parameters) for cls in (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm)]
+    for cls, _ in saved:
+        cls.reset_parameters = lambda self: None
+    try:
+        unet = UNet2DConditionModel()
+        set_visual_cross_attention_adapter(unet, (ip_tokens,))
+    finally:
+        for cls, fn in saved:
+            cls.reset_parameters = fn
+    gen = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for name, p_ in unet.named_parameters():
+            q = torch.empty(p_.shape, dtype=p_.dtype, device=dev)
+            if p_.ndim >= 2:
+                bound = 1.0 / (p_[0].numel() ** 0.5)
+                q.uniform_(-bound, bound, generator=gen)
+            elif name.endswith("weight"):
+                q.fill_(1.0)
+            else:
+                q.zero_()
+            p_.data = q
+    unet.to(dev)          # packs the fp16 operands of the engines
+    return unet
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -296,12 +328,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from photoverse_amd.pipeline import DenoiseLoop, gather_latents, shard_batch
-    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    from photoverse_amd.unet import set_visual_cross_attention_adapter
 
-    torch.manual_seed(0)                       # identical random-init weights on every rank
-    unet = UNet2DConditionModel()
-    set_visual_cross_attention_adapter(unet, (args.ip_tokens,))
-    unet.to(dev)
+    torch.manual_seed(0)
+    unet = build_random_unet(args.ip_tokens, dev)          # identical random-init weights on every rank
 
     B, S, P, T = args.batch, args.latent, args.ip_tokens, max(args.steps, args.warmup, 1)   # the schedule covers the warm-up too
     loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream, batch_splits=args.batch_splits)

@@ -32,7 +32,16 @@ struct ACfg {
     __device__ static __forceinline__ int koff(int row, int chunk) {
         return KSWZ ? row * KS + ((chunk ^ (row & 7)) << 3) : row * KS + (chunk << 3);
     }
-    static constexpr int VS = DVF * 16 + 8;
+    // V row stride in halfs.  The P.V operand is read with ds_read_b64_tr_b16: a 32-lane group reads 8 consecutive key rows x 32 B, so
+    // the eight rows must land on eight DIFFERENT 32-B slots of the 256-B bank window: stride = 8 * odd dwords (mod 64).  The smallest
+    // such stride that holds the DVF fragments: d = 40 -> 48 halfs (the old 56 put rows 0 and 7 on the same banks: SQ_LDS_BANK_CONFLICT
+    // was 37 % of the kernel's LDS cycles, profiles/r03_base_pmc_attn40.txt), d = 64 / 80 -> 80, d = 160 -> 176.
+    static constexpr int vs_dwords() {
+        int v = DVF * 8;
+        while ((v & 63) != 8 && (v & 63) != 24 && (v & 63) != 40 && (v & 63) != 56) v += 4;
+        return v;
+    }
+    static constexpr int VS = vs_dwords() * 2;
     static constexpr int CH = D / 8;               // 16-byte chunks per row
 };
 

@@ -273,7 +273,117 @@ def test_fifty_step_loop_latent_tolerance(tiny_pair, golden_dir):
     err = rel_l2(got, fx["latents_50step"])
     print(f"50-step latents rel-L2 vs fp32 oracle: {err:.3e}")
     assert torch.isfinite(got).all()
-    assert err < 4e-3            # tiny random-init config: measured 7.9e-4 .. 2e-3 depending on the fp32 summation order
+    assert err < 1.5e-3          # measured 7.9e-4 .. 8.1e-4 on MI355X (north_star target 1e-3); headroom for fp32 summation-order variation
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract keys plus the roofline object (short run, no CPU baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f16" and "workload" in d["config"] and d["finite"] is True
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.05 < rf["frac"] < 1.0
+    # derived label, self-verifying multi-GPU fields, the attn2 branch over ALL layers
+    assert d["config"]["workload"].startswith("configs[1] shape timed over 3 steps") and d["rccl_world"] == 1
+    assert d["ms_per_step_ranks"]["n"] == 1 and d["ms_per_step_ranks"]["max"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    xa = d["xattn_fused"]
+    assert set(xa["levels"]) == {"320", "640", "1280"} and xa["levels"]["320"]["fused"] and xa["levels"]["320"]["launches_per_layer"] == 1
+    assert xa["all_layers"]["layers_per_step"] == 32 and 0.02 < xa["all_layers"]["frac"] < 1.0 and xa["north_star_target_frac"] == 0.40
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                         "--no-train-forward"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])["config"]["workload"].startswith("custom shape (NOT a BASELINE config)")
+
+
+def test_bench_under_torch_distributed_run_uses_rccl_and_agrees_with_the_plain_run():
+    """The driver's N > 1 launch form with ONE rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` initialises RCCL,
+    runs the barrier / all_gather path (`force=True`) and must report the same throughput as the plain single-process run (within 3 %),
+    with `rccl_world` = 1 taken from the process group and every rank's own ms_per_step in the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--no-roofline", "--no-train-forward"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", "29533", os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in dist.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["collective"].startswith("none") and b["collective"].startswith("all_gather_into_tensor over RCCL") and b["rccl_world"] == 1
+    assert b["n_gpus"] == 1 and b["ms_per_step_ranks"]["n"] == 1 and b["finite"] is True
+    print(f"plain {a['value']:.2f} steps/s vs under torch.distributed.run (RCCL) {b['value']:.2f} steps/s")
+    assert abs(a["value"] - b["value"]) < 0.03 * a["value"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# headline-config coverage that needs no oracle time: batch invariance at bs=16, full model size (BASELINE configs[1])
+def test_bs16_full_size_samples_match_bs1_runs(monkeypatch, full_hip_unet):
+    """configs[1] beyond `finite`: 2 graph-replayed CFG steps at the headline shape (full SD-v1.5 size, bs=16, 64x64 latents,
+    guidance 7.5); sample i of the batch must equal the bs=1 run of the same sample.  Samples never interact inside the UNet
+    and no kernel's arithmetic depends on the batch, EXCEPT the split-K decision (small-M layers split K, which changes the fp32
+    summation order): with split-K disabled the two runs are BIT-IDENTICAL; with the default heuristic they differ by the fp16
+    storage noise (a different fp32 rounding flips fp16 roundings downstream - measured 1e-3 per forward, the same size as the
+    error against the fp32 oracle), which guidance 7.5 amplifies in a 2-step loop."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from photoverse_amd import ops
+    from photoverse_amd.pipeline import DenoiseLoop
+    hip = full_hip_unet
+    g = torch.Generator().manual_seed(77)
+    B, P, T = 16, 1, 2
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, 64, 64, generator=g)
+
+    def run_pair():
+        big = DenoiseLoop(hip, B, 64, P, T, 7.5)
+        big.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        big.reset(noise)
+        full = big.run().clone().cpu()
+        del big
+        one = DenoiseLoop(hip, 1, 64, P, T, 7.5)
+        singles = {}
+        for i in (0, 7, 15):
+            one.set_conditioning(tuple(t[i:i + 1].cuda() for t in cond), tuple(t[i:i + 1].cuda() for t in uncond))
+            one.reset(noise[i:i + 1])
+            singles[i] = one.run().clone().cpu()
+        return full, singles
+
+    monkeypatch.setattr(ops, "SPLITK_MAX", 1)            # no split-K anywhere: the bs=1 plan runs the same arithmetic as the bs=16 plan
+    full, singles = run_pair()
+    assert torch.isfinite(full).all()
+    for i, s1 in singles.items():
+        assert torch.equal(full[i:i + 1], s1), f"sample {i} of the bs=16 run differs from its bs=1 run with split-K off"
+    monkeypatch.undo()
+    full2, singles2 = run_pair()                          # default split-K heuristic (what the bench runs)
+    worst = max(rel_l2(full2[i:i + 1], s1) for i, s1 in singles2.items())
+    print(f"bs=16 sample vs its bs=1 run (default split-K), 2 CFG steps, full size: worst rel-L2 = {worst:.3e}")
+    assert worst < 4e-3
 
 
 def _two_rank_loop_worker(rank, world, port, q):
