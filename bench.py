@@ -399,9 +399,9 @@ def main():
         # collected in their own runs, so the number is read from the committed summary, not measured in this process)
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r02_pmc_traffic.json: " + pmc.get("note", "")
+            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r03_pmc_traffic.json: " + pmc.get("note", "")
         except (OSError, ValueError):
             pass
         algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl

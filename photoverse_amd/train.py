@@ -608,6 +608,9 @@ class TrainStep:
         f.rec_stack.add_rows(ip_c.t, zt[:ns], out=ip2[ns:])
         for half in (lat2[:ns], lat2[ns:]):               # every step: both halves read the current latents
             lrf.affine_rows(f.lat.view(1, -1), one, out=half.view(1, -1))
+        # every replayed pass draws FRESH LoRA-dropout masks, as peft does on every forward: the masks are keyed on rng[2], which only the
+        # fusion draws of section B advanced - one more counter bump per pass (the no-grad passes have no backward that would re-derive them)
+        lrf.step_advance(rng[2:3])
         self._enter(tape=tl, B=2 * ns, t_state=(f.ts, f.state), fusion_names=[], site_base=2000)
         eps2, _ = self._unet_pass(lat2, Var(text2, False), Var(ip2, False))
         lrf.cfg_dpm_step(eps2[:ns], eps2[ns:], f.lat, f.x0_prev, f.coef, f.state, guidance)

@@ -408,9 +408,11 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     for m in unet.modules():
         if isinstance(m, LoRALinear):
             m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)     # B = 0 at init would zero dA
+    from oracle.lora_ref import LoraLinearRef, inject_adapter_in_model_ref
     r_unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
     set_visual_cross_attention_adapter_ref(r_unet, (ENT + 1,))
-    inject_adapter_in_model(lcfg, r_unet)
+    # the oracle's LoRA is the INDEPENDENT peft restatement (oracle/lora_ref.py: un-merged base(x) + (alpha / r) B(A(dropout(x)))), not the product's
+    inject_adapter_in_model_ref(r_unet, r=lcfg.r, lora_alpha=lcfg.lora_alpha, target_modules=lcfg.target_modules, lora_dropout=0.0)
     r_unet.load_state_dict(unet.state_dict())
     r_txt = CLIPTextModelRef(**TXT).eval(); r_txt.load_state_dict(text_encoder.state_dict())
     r_ia = PhotoVerseAdapterRef(D, 768, ENT + 1).eval(); r_ia.load_state_dict(image_adapter.state_dict())
@@ -463,13 +465,10 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
                 masks[mods[base + "to_k"]], masks[mods[base + "to_v"]] = m[:, :cols], m[:, cols:]
         assert not torch.equal(masks[mods[base + "to_k"]], masks[mods[base + "to_v"]])
 
-    def lora_forward(self, x):                            # the oracle calls attn.to_q(x); CPU fp32 only
-        if self not in masks:
-            return F.linear(x, self.weight, self.bias)
-        xd = (x.reshape(-1, x.shape[-1]) * masks[self]).view_as(x)        # peft: base(x) + B(A(dropout(x))) * scaling
-        return F.linear(x, self.base_layer.weight, self.bias) + self.scaling * F.linear(F.linear(xd, self.lora_A["default"].weight),
-                                                                                        self.lora_B["default"].weight)
-    LoRALinear.forward = lora_forward
+    # the device draws the dropout masks (counter-based generator); the oracle's LoRA layers apply exactly those masks through their hook
+    for mod, msk in masks.items():
+        assert isinstance(mod, LoraLinearRef)
+        mod.dropout_hook = lambda self, x, msk=msk: (x.reshape(-1, x.shape[-1]) * msk).view_as(x)
     try:
         e32 = [e.float() for e in embs]
         concept = r_ta(e32)
@@ -484,7 +483,8 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
             loss = d_loss + 0.01 * c_loss + 0.001 * v_loss
             loss.backward()
     finally:
-        del LoRALinear.forward
+        for mod in masks:
+            mod.dropout_hook = None
     assert out["loss"].item() == pytest.approx(loss.item(), rel=5e-3)
     assert out["diffusion_loss"].item() == pytest.approx(d_loss.item(), rel=5e-3)
     assert rel_l2(out["noise_pred"], pred.detach()) < 1e-2
@@ -557,9 +557,10 @@ def test_training_step_with_face_loss_matches_oracle_autograd(need_gpu, smooth_f
     for m in unet.modules():
         if isinstance(m, LoRALinear):
             m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)
+    from oracle.lora_ref import inject_adapter_in_model_ref
     r_unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
     set_visual_cross_attention_adapter_ref(r_unet, (ENT + 1,))
-    inject_adapter_in_model(lcfg, r_unet)
+    inject_adapter_in_model_ref(r_unet, r=lcfg.r, lora_alpha=lcfg.lora_alpha, target_modules=lcfg.target_modules)   # independent peft restatement
     r_unet.load_state_dict(unet.state_dict())
     r_txt = CLIPTextModelRef(**TXT).eval(); r_txt.load_state_dict(text_encoder.state_dict())
     r_ia = PhotoVerseAdapterRef(D, 768, ENT + 1).eval(); r_ia.load_state_dict(image_adapter.state_dict())
@@ -613,7 +614,6 @@ def test_training_step_with_face_loss_matches_oracle_autograd(need_gpu, smooth_f
                   image_embeddings=[e.cuda() for e in embs], forced_fusion=forced, face_inputs=fi)
     torch.cuda.synchronize()
 
-    LoRALinear.forward = lambda self, x: F.linear(x, self.weight, self.bias)
     mods = dict(r_unet.named_modules())
 
     def force(vals):
@@ -654,7 +654,7 @@ def test_training_step_with_face_loss_matches_oracle_autograd(need_gpu, smooth_f
             main_only = torch.autograd.grad(main_loss, plist, retain_graph=True, allow_unused=True)
             loss.backward()
     finally:
-        del LoRALinear.forward
+        pass
     print(f"face branch: floss {out['face_loss'].item():.5f} vs {floss.item():.5f}; images rel-L2 {rel_l2(out['face_images'], images.detach()):.3e}")
     assert rel_l2(out["face_images"], images.detach()) < 2e-2
     assert out["face_loss"].item() == pytest.approx(floss.item(), rel=3e-2, abs=2e-3)
@@ -781,12 +781,13 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     torch.manual_seed(0)
     E, B, T, D, STEPS, G, FW = 5, 1, 257, 1024, 2, 2.0, 2.0
     lcfg = LoraConfig(r=8, lora_alpha=1)
+    from oracle.lora_ref import LoraLinearRef, inject_adapter_in_model_ref
     r_unet = UNet2DConditionModelRef().eval()
     set_visual_cross_attention_adapter_ref(r_unet, (E,))
-    inject_adapter_in_model(lcfg, r_unet)
+    inject_adapter_in_model_ref(r_unet, r=lcfg.r, lora_alpha=lcfg.lora_alpha, target_modules=lcfg.target_modules)   # independent peft restatement
     g = torch.Generator().manual_seed(71)
     for m in r_unet.modules():
-        if isinstance(m, LoRALinear):
+        if isinstance(m, LoraLinearRef):
             m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)
     r_txt = CLIPTextModelRef().eval()
     r_ia, r_ta = PhotoVerseAdapterRef(D, 768, E).eval(), PhotoVerseAdapterRef(D, 768, E).eval()
@@ -837,7 +838,6 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     out = ts.step(noisy_latents=noisy.cuda(), noise=noise.cuda(), timesteps=timesteps, text_input_ids=ids.cuda(), placeholder_idx=pidx.cuda(),
                   image_embeddings=[e.cuda() for e in embs], forced_fusion=forced, face_inputs=fi)
     torch.cuda.synchronize()
-    LoRALinear.forward = lambda self, x: F.linear(x, self.weight, self.bias)
     mods = dict(r_unet.named_modules())
 
     def force(vals):
@@ -875,7 +875,7 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
             loss = main_loss + FW * floss
             loss.backward()
     finally:
-        del LoRALinear.forward
+        pass
     err_img = rel_l2(out["face_images"], images.detach())
     print(f"full-size face branch: floss {out['face_loss'].item():.5f} vs {floss.item():.5f}; 512x512 image rel-L2 {err_img:.3e}")
     assert err_img < 2e-2
