@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 8
+#define PV_ABI_VERSION 9
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -279,6 +279,26 @@ int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt,
                      int32_t ldkip, int32_t ldvip, void* kimg, void* vimg, float* vnorm, int32_t batch,
                      int32_t heads, int32_t d, int32_t nt, int32_t nip, void* stream);
 int pv_xattn_fused_wo_slot(int32_t slot);
+
+/* ------------------------------------------------------------------------------------------
+ * pv_row_gemm: LayerNorm + Linear (+ GEGLU gate) for the K = 320 layers of the 64x64-level transformer blocks as ONE row-owning
+ * launch: BasicTransformerBlock.norm1 -> [to_q; to_k; to_v] of attn1 (stock AttnProcessor2_0, /root/reference/models/unet.py:20-24) and
+ * norm3 -> ff.net[0] (GEGLU) [EXT diffusers transformer block, driven by /root/reference/models/infer.py:103-114].
+ *   out[M][N'] = epi( ((x - mean) * rstd)[M][320] . w[N][320]^T + bias ),  N' = N, or N / 2 with geglu (value * gelu_erf(gate))
+ * ln != 0: rows are normalised WITHOUT the affine part - the caller folds gamma into the columns of w and w . beta into bias.
+ * geglu: w / bias rows packed per 160-row chunk c as 10 fragments of 16 rows, fragment 2q = value rows of output columns
+ * 80 c + 16 q .. + 15, fragment 2q + 1 = their gate rows.  N % 320 == 0; K must be 320; M arbitrary (tails through the descriptors).
+ */
+typedef struct pv_row_gemm_params {
+    const void* x; int32_t ld_x;               /* fp16 [M][K] rows */
+    int32_t M, K, N;
+    const void* w;                             /* fp16 [N][K] */
+    const float* bias;                         /* fp32 [N] or NULL */
+    int32_t ln; float ln_eps;
+    int32_t geglu;
+    void* out; int32_t ld_out;                 /* fp16 [M][N or N/2] */
+} pv_row_gemm_params;
+int pv_row_gemm(const pv_row_gemm_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BACKWARD of PhotoVerse's own trainable modules (the backward of the stock SD-v1.5 / CLIP blocks the gradient crosses is

@@ -70,6 +70,11 @@ class XAttnFusedParams(C.Structure):
                 ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
 
 
+class RowGemmParams(C.Structure):
+    _fields_ = [("x", c_void_p), ("ld_x", c_int), ("M", c_int), ("K", c_int), ("N", c_int), ("w", c_void_p), ("bias", c_void_p),
+                ("ln", c_int), ("ln_eps", c_float), ("geglu", c_int), ("out", c_void_p), ("ld_out", c_int)]
+
+
 class XAttnBwdParams(C.Structure):
     _fields_ = [("q", c_void_p), ("ldq", c_int), ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int),
                 ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int), ("dout", c_void_p), ("lddo", c_int),
@@ -99,6 +104,7 @@ SIGNATURES = {
     "pv_xattn_pack_kv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_xattn_fused_wo_slot": (c_int, [c_int]),
+    "pv_row_gemm": (c_int, [C.POINTER(RowGemmParams), c_void_p]),
     "pv_cross_attention_backward": (c_int, [C.POINTER(XAttnBwdParams), c_void_p]),
     "pv_transpose_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "pv_layernorm_backward": (c_int, [C.POINTER(LayerNormBwdParams), c_void_p]),
@@ -150,7 +156,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

@@ -48,7 +48,21 @@ __device__ __forceinline__ float pv_erf_fast(float x) {
 #ifdef PV_GELU_IDENTITY   // timing experiment only (wrong results): what the erf costs the GEGLU epilogue
 __device__ __forceinline__ float pv_gelu_erf(float x) { return x; }
 #else
-__device__ __forceinline__ float pv_gelu_erf(float x) { return 0.5f * x * (1.0f + pv_erf_fast(x * 0.70710678118654752440f)); }
+// Exact-erf GELU as it is used in the GEMM epilogues (diffusers GEGLU: hidden * F.gelu(gate), [EXT]): the GEGLU launches are bound by this
+// function's VALU issue (84 M evaluations per 64x64-level launch), so it is written for instruction count:
+//   gelu(x) = x * Phi(x) = max(x, 0) - |x| * Q(|x|),   Q(a) = 1 - Phi(a) = 0.5 * erfc(a / sqrt 2)
+// (for x < 0: x * Phi(x) = -|x| * Q(|x|); for x > 0: x * (1 - Q) = x - |x| Q) - no sign transfer and no "1 -" on the erf side - with
+// erfc by Abramowitz & Stegun 7.1.25: erfc(z) = (a1 t + a2 t^2 + a3 t^3) exp(-z^2), t = 1 / (1 + p z), |error| <= 2.5e-5, i.e. an absolute
+// error <= 1.25e-5 |x| on gelu - a twentieth of the fp16 rounding of the output.  11 VALU ops, two of them transcendental (v_rcp, v_exp).
+__device__ __forceinline__ float pv_gelu_erf(float x) {
+    const float b = fabsf(x) * 0.84932180028801904272f;                 // z * sqrt(log2 e), z = |x| / sqrt 2: exp(-z^2) = exp2(-b^2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.39170375623211625f, b, 1.0f));   // p z = 0.47047 z = (0.47047 / sqrt(log2 e)) b
+    float poly = fmaf(0.3739278f, t, -0.0479399f);                      // 0.5 * (a3, a2, a1) = 0.5 * (0.7478556, -0.0958798, 0.3480242)
+    poly = fmaf(poly, t, 0.1740121f);
+    const float e = __builtin_amdgcn_exp2f(-b * b);
+    const float q = poly * t * e;                                        // Q(|x|)
+    return fmaxf(x, 0.f) - fabsf(x) * q;
+}
 #endif
 __device__ __forceinline__ float pv_apply_act(float x, int act) {
     switch (act) {

@@ -62,6 +62,18 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     return weight[src].contiguous(), (None if bias is None else bias[src].contiguous())
 
 
+def pack_geglu_rows(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """GEGLU ``proj`` rows in the order ``pv_row_gemm`` wants them: per 160-row chunk c, fragment 2q = the 16 VALUE rows of output columns
+    80 c + 16 q .. + 15, fragment 2q + 1 = their GATE rows (weight [2 n, k] with value rows first, as diffusers' GEGLU.chunk(2) reads them)."""
+    n2 = weight.shape[0]
+    n = n2 // 2
+    assert n2 % 320 == 0
+    p = torch.arange(n2, device=weight.device)
+    c, i, e = p // 160, (p % 160) // 16, p % 16
+    src = 80 * c + 16 * (i // 2) + e + (i & 1) * n
+    return weight[src].contiguous(), (None if bias is None else bias[src].contiguous())
+
+
 _NO_COLSTATS = bool(os.environ.get("PV_NO_COLSTATS"))   # A/B switch: GroupNorm statistics by a pass over the tensor
 
 
@@ -445,6 +457,35 @@ class Recorder:
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
         self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320, %s>" % ("true" if nip == 1 else "false"), flops, 2.0 * (3 * M * C + 2 * C * C)))
         return out, p
+
+    # ---- LayerNorm + Linear (+ GEGLU) of the K = 320 transformer layers as one row-owning launch (pv_rowgemm.hip) ----
+    @staticmethod
+    def row_gemm_supported(K: int, N: int) -> bool:
+        return K == 320 and N % 320 == 0
+
+    def row_gemm(self, x, w, *, bias=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5, geglu=False, out=None):
+        """``out = epi(LayerNorm(x) . w^T + bias)``: ``w`` fp16 [N][320] (for ``geglu``: rows and bias already in ``pack_geglu_rows`` order).
+        With ``ln_gamma`` / ``ln_beta`` the kernel normalises the rows in registers; the affine part is folded here, once at plan-build
+        time: gamma scales the columns of w, w . beta joins the bias."""
+        M, K = x.shape
+        N = w.shape[0]
+        assert Recorder.row_gemm_supported(K, N) and w.shape[1] == K and w.dtype == torch.float16
+        ln = ln_gamma is not None
+        b32 = None if bias is None else bias.detach().float()
+        if ln:
+            wf = w.float()
+            fold = wf @ ln_beta.detach().float().to(w.device)
+            b32 = fold if b32 is None else b32 + fold
+            w = (wf * ln_gamma.detach().float().to(w.device)[None, :]).to(torch.float16)
+        w = w.contiguous()
+        b32 = None if b32 is None else b32.contiguous()
+        n_out = N // 2 if geglu else N
+        if out is None:
+            out = self.empty((M, n_out), torch.float16)
+        p = _lib.RowGemmParams(_ptr(x), _rows(x)[0], M, K, N, _ptr(w), _ptr(b32), 1 if ln else 0, float(ln_eps), 1 if geglu else 0, _ptr(out), _rows(out)[0])
+        self.keep.extend(t for t in (x, w, b32, out) if t is not None)
+        self._add(self.lib.pv_row_gemm, p, tag=("row_gemm_kernel<%s>" % ("true" if geglu else "false"), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out)))
+        return out
 
     # ---- backward of PhotoVerse's own trainable modules (pv_backward.hip) ----
     def cross_attention_backward(self, q, kt, vt, kip, vip, dout, *, batch, heads, nq, nt, nip, d, w_text=1.0, w_ip=1.0, fusion=None,

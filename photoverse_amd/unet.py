@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from .attention_processor import AttnProcessor2_0, PhotoVerseAttnProcessor2_0
-from .ops import ACT_NONE, ACT_SILU, Recorder, pack_geglu
+from .ops import ACT_NONE, ACT_SILU, Recorder, pack_geglu, pack_geglu_rows
 
 SD15_CONFIG = dict(
     in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
@@ -167,6 +167,7 @@ class TimestepEmbedding(_Holder):
 
 #: A/B switch: PV_NO_XFUSED=1 runs attn2 as the four separate launches (LayerNorm, to_q GEMM, dual-branch SDPA, to_out GEMM)
 USE_XFUSED = not os.environ.get("PV_NO_XFUSED")
+USE_ROWGEMM = not os.environ.get("PV_NO_ROWGEMM")     # A/B switch: LayerNorm + K = 320 Linear as one row-owning launch (pv_rowgemm.hip)
 
 
 def _f16(t: torch.Tensor) -> torch.Tensor:
@@ -261,9 +262,13 @@ class UNetEngine:
         hs = rec.gemm(g, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), rows_per_image=n)
         # --- attn1 (stock AttnProcessor2_0, models/unet.py:20-24) ---
         a1 = blk.attn1
-        n1 = rec.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
         wqkv = torch.cat([_f16(a1.to_q.weight), _f16(a1.to_k.weight), _f16(a1.to_v.weight)], 0).contiguous()
-        qkv = rec.gemm(n1, wqkv, rows_per_image=n)
+        if USE_ROWGEMM and Recorder.row_gemm_supported(C, 3 * C):
+            # norm1 + [to_q; to_k; to_v] as ONE row-owning launch (pv_rowgemm.hip): rows normalised in registers, weights streamed
+            qkv = rec.row_gemm(hs, wqkv, ln_gamma=_f32(blk.norm1.weight), ln_beta=_f32(blk.norm1.bias), ln_eps=blk.norm1.eps)
+        else:
+            n1 = rec.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
+            qkv = rec.gemm(n1, wqkv, rows_per_image=n)
         sa = rec.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=b, heads=heads, nq=n, nk=n, d=d)
         hs = rec.gemm(sa, _f16(a1.to_out[0].weight), bias=_f32(a1.to_out[0].bias), residual=hs, rows_per_image=n)
         # --- attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435) ---
@@ -298,9 +303,14 @@ class UNetEngine:
             hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         rec.role = None
         # --- GEGLU feed-forward ---
-        n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
-        wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
-        gg = rec.gemm(n3, wg, bias=bg, geglu=True, rows_per_image=n)
+        if USE_ROWGEMM and Recorder.row_gemm_supported(C, blk.ff.net[0].proj.weight.shape[0]):
+            # norm3 + GEGLU projection + gate as ONE row-owning launch
+            wg, bg = pack_geglu_rows(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
+            gg = rec.row_gemm(hs, wg, bias=bg, ln_gamma=_f32(blk.norm3.weight), ln_beta=_f32(blk.norm3.bias), ln_eps=blk.norm3.eps, geglu=True)
+        else:
+            n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
+            wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
+            gg = rec.gemm(n3, wg, bias=bg, geglu=True, rows_per_image=n)
         hs = rec.gemm(gg, _f16(blk.ff.net[2].weight), bias=_f32(blk.ff.net[2].bias), residual=hs, rows_per_image=n)
         return rec.gemm(hs, _conv1_w(m.proj_out.weight), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n, colstats=True)
 

@@ -356,6 +356,43 @@ def test_cross_attention_fused_branch(rec_cls, n, p, wt, wi, ln, fus):
     torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
 
 
+@pytest.mark.parametrize("M,N,geglu,ln,bias", [(1000, 960, False, True, False), (256, 320, False, False, True), (4096, 2560, True, True, True),
+                                              (130, 640, True, False, False)])
+def test_row_gemm_layernorm_linear_geglu(rec_cls, M, N, geglu, ln, bias):
+    """pv_row_gemm (LayerNorm -> K = 320 Linear -> optional GEGLU gate in ONE row-owning launch) vs an fp32 torch reference on the same
+    fp16-rounded operands and vs the two-launch path it replaces; ragged M (tails through the buffer descriptors)."""
+    from photoverse_amd.ops import pack_geglu, pack_geglu_rows
+    K = 320
+    x = h16(M, K, seed=60)
+    x[:, ::5] += 1.0
+    w = h16(N, K, scale=K ** -0.5, seed=61)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(62)) if bias else None
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(63))
+    beta = 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(64))
+    rec = rec_cls("cuda")
+    dx, dw = x.cuda(), w.cuda()
+    db = None if b is None else b.cuda()
+    if geglu:
+        wp, bp = pack_geglu_rows(dw, db)
+    else:
+        wp, bp = dw, db
+    out = rec.row_gemm(dx, wp, bias=bp, ln_gamma=gamma.cuda() if ln else None, ln_beta=beta.cuda() if ln else None, geglu=geglu)
+    n1 = rec.layernorm(dx, gamma.cuda(), beta.cuda()) if ln else dx
+    if geglu:
+        w2, b2 = pack_geglu(dw, db if db is not None else torch.zeros(N, device="cuda"))
+        two = rec.gemm(n1, w2, bias=b2, geglu=True)
+    else:
+        two = rec.gemm(n1, dw, bias=db)
+    rec.run()
+    torch.cuda.synchronize()
+    xn = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) if ln else x.float()
+    y = xn @ w.float().t() + (b if b is not None else 0.0)
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:]) if geglu else y
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    print(f"row_gemm M={M} N={N} geglu={geglu} ln={ln}: vs fp32 {rel_l2(out, ref):.2e}, two-launch path vs fp32 {rel_l2(two, ref):.2e}")
+    assert rel_l2(out, ref) < 1e-3 and rel_l2(two, ref) < 1e-3 and rel_l2(out, two) < 1e-3
+
+
 def test_conv_in_out_timestep(rec_cls):
     B, h = 2, 16
     x = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(30))

@@ -103,6 +103,27 @@ def xfused(name, n, p=1, fused=True):
     cases.append((name, f))
 
 
+def rowgemm(name, M, N, geglu=False, fused=True):
+    """LayerNorm + K = 320 Linear (+ GEGLU): the row-owning launch (pv_row_gemm) or the two launches it replaces."""
+    def f():
+        from photoverse_amd.ops import pack_geglu_rows
+        rec = Recorder(dev)
+        x, w = h16(M, 320), h16(N, 320, scale=0.02)
+        b = torch.zeros(N, device=dev)
+        g, bt = torch.ones(320, device=dev), torch.zeros(320, device=dev)
+        if fused:
+            if geglu:
+                w, b = pack_geglu_rows(w, b)
+            rec.row_gemm(x, w, bias=b, ln_gamma=g, ln_beta=bt, geglu=geglu)
+        else:
+            if geglu:
+                w, b = pack_geglu(w, b)
+            n1 = rec.layernorm(x, g, bt)
+            rec.gemm(n1, w, bias=b, geglu=geglu)
+        return rec, 2.0 * M * N * 320, 2.0 * (M * 320 + N * 320 + M * (N // 2 if geglu else N))
+    cases.append((name, f))
+
+
 def gn(name, c, hw):
     def f():
         rec = Recorder(dev)
@@ -235,6 +256,10 @@ gemm("gemm 4096x1280->1280", 4096, 1280, 1280)
 gemm("geglu 4096x1280->10240", 4096, 1280, 10240, geglu=True)
 gemm("gemm 4096x5120->1280 (ff2)", 4096, 5120, 1280)
 gemm("gemm 1232x768->640 (text kv)", 1232, 768, 640, res=False)
+rowgemm("ln+qkv 65536x320->960 ROW-OWNER", 65536, 960)
+rowgemm("ln+qkv 65536x320->960 2 launches", 65536, 960, fused=False)
+rowgemm("ln+geglu 65536x320->2560 ROW-OWNER", 65536, 2560, geglu=True)
+rowgemm("ln+geglu 65536x320->2560 2 launches", 65536, 2560, geglu=True, fused=False)
 attn("attn d40 n4096", 40, 4096)
 attn("attn d80 n1024", 80, 1024)
 attn("attn d160 n256", 160, 256)
