@@ -65,16 +65,14 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
     // LDS position (lane & 7) of row r holds chunk (lane & 7) ^ (r & 7)
     const int lrow = lane >> 3;
     const unsigned w_lane_off = (unsigned)lrow * (unsigned)(C * 2) + (unsigned)(((lane & 7) ^ lrow) << 4);
-    unsigned piece_off[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) piece_off[i] = w_lane_off + (unsigned)((wave + 4 * i) * 8) * (unsigned)(C * 2);
+    const unsigned piece_off = w_lane_off + (unsigned)(wave * 8) * (unsigned)(C * 2);   // piece i adds 32 i rows: scalar part of the address
     auto issue_stage = [&](int t) {                        // t: runtime stage index (chunk t / 5, k-stage t % 5)
         const int nc = t / KT, kt = t - nc * KT;
         char* dst = smem + (t & (RG_SLOTS - 1)) * RG_TILE;
         const int soff = nc * RG_CHUNK * (C * 2) + kt * 128;
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + (wave + 4 * i) * 1024), 16, (int)piece_off[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + (wave + 4 * i) * 1024), 16, (int)piece_off, soff + i * 32 * (C * 2), 0, 0);
     };
     auto wg_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -150,7 +148,6 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
     constexpr int STORES = GEGLU ? 6 : 10;                            // VMEM stores per wave at a chunk's end (vmcnt bookkeeping)
 
     float4_t acc[NFC][2];
-    float4_t bias_v[NFC];
     for (int it = 0; it < n_chunks / 2; ++it) {
         const int t0 = it * (2 * KT);
 #pragma unroll
@@ -169,12 +166,10 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
                 if (t + 3 < NT) issue_stage(t + 3);
             }
             if (kt == 0) {
+                // accumulators start from the bias (rows 4g .. 4g+3 of each fragment): no bias registers beside them
 #pragma unroll
-                for (int i = 0; i < NFC; ++i) acc[i][0] = acc[i][1] = float4_t{0.f, 0.f, 0.f, 0.f};
-            }
-            if (kt == KT - 2 && p.bias) {             // the chunk's bias: requested two stages before the epilogue consumes it
-#pragma unroll
-                for (int i = 0; i < NFC; ++i) bias_v[i] = *reinterpret_cast<const float4_t*>(p.bias + nc * RG_CHUNK + i * 16 + g * 4);
+                for (int i = 0; i < NFC; ++i)
+                    acc[i][0] = acc[i][1] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nc * RG_CHUNK + i * 16 + g * 4) : float4_t{0.f, 0.f, 0.f, 0.f};
             }
             const char* slot = smem + (t & (RG_SLOTS - 1)) * RG_TILE;
 #pragma unroll
@@ -197,16 +192,14 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
                     if (GEGLU) {
 #pragma unroll
                         for (int q = 0; q < NFC / 2; ++q) {
-                            float4_t v = acc[2 * q][qi], gt = acc[2 * q + 1][qi];
-                            if (p.bias) { v += bias_v[2 * q]; gt += bias_v[2 * q + 1]; }
+                            const float4_t v = acc[2 * q][qi], gt = acc[2 * q + 1][qi];
                             pk[q][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[0] * pv_gelu_erf(gt[0])), (half_t)(v[1] * pv_gelu_erf(gt[1]))});
                             pk[q][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[2] * pv_gelu_erf(gt[2])), (half_t)(v[3] * pv_gelu_erf(gt[3]))});
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < NFC; ++i) {
-                            float4_t v = acc[i][qi];
-                            if (p.bias) v += bias_v[i];
+                            const float4_t v = acc[i][qi];
                             pk[i][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[0], (half_t)v[1]});
                             pk[i][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)v[2], (half_t)v[3]});
                         }
