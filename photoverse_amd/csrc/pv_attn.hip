@@ -67,9 +67,14 @@ constexpr int attn_min_waves() { return 1; }
 
 // NQ: 16-query fragments per wave (a workgroup owns 64 * NQ queries): every K / V fragment read from LDS and every staged tile (two
 // barriers) serves NQ fragments
-template <int D, int NQ>
+// DMA (d = 40 only): the K / V tiles reach LDS by LDS-DMA through buffer descriptors (the swizzle and the zero padding are per-lane
+// SOURCE offsets, out-of-range offsets read zeros) into a ring of four tile slots with one raw s_barrier per PAIR of tiles, instead
+// of global -> registers -> ds_write with two __syncthreads per tile: the per-tile stamps of round 2 put 1.4 k of a wave's 5.5 k cycles
+// per tile into that staging (tools/diag/attn_stamps.py).
+template <int D, int NQ, bool DMA>
 __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv_attn_params p) {
     using C = ACfg<D>;
+    static_assert(!DMA || (C::KSWZ && C::VS == 48 && D == 40), "the DMA staging is laid out for d = 40 (128-B swizzled K rows, 96-B V rows)");
     constexpr int KB = 64;
     constexpr int NCHUNK = KB * C::CH;
     constexpr int KPT = (NCHUNK + 255) / 256;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 
     // pad columns, written once (staging only touches columns [0, D)): K pads are zero (the contraction runs over DK >= D);
     // V pads are zero except column D = 1.0 when ONES
-    for (int st = 0; st < (DBUF ? 2 : 1); ++st) {
+    for (int st = 0; st < (DMA ? 4 : DBUF ? 2 : 1); ++st) {
         half_t* sK = sbase + st * STAGE;
         half_t* sV = sK + KB * C::KS;
         constexpr int NPC = C::KCH - C::CH, NPV = (C::VS - D) / 8;
@@ -268,6 +273,53 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 
     int ntiles = (p.nk + KB - 1) / KB;
     if (p.causal) ntiles = min(ntiles, (min(qt * QW + QW - 1, p.nq - 1)) / KB + 1);
+    if constexpr (DMA) {
+        // K tile = 64 rows x 128 B = 8 pieces of 8 rows (waves w: pieces w, w + 4); V tile = 64 rows x 96 B = 6 linear pieces (waves 0, 1: two,
+        // waves 2, 3: one).  Lane l of K piece j: row 8 j + (l >> 3), LDS position l & 7 holds data chunk (l & 7) ^ (row & 7); chunks >= 5
+        // (the zero padding of the 64-deep contraction) and keys >= nk read out of range = zeros.  V: linear 16-B chunk 64 j + l = (row, c) of
+        // the [64][6] tile; c == 5 is the pad chunk holding the 1.0 column, written once above: those lanes stay out of the DMA (EXEC mask).
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Kg), 0, ((p.nk - 1) * p.ldk + D) * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Vg), 0, ((p.nk - 1) * p.ldv + D) * 2, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;
+        unsigned koff[2], voff[2];
+        bool vlive[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 8 * (wave + 4 * i) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+            koff[i] = c < C::CH ? (unsigned)(r * p.ldk * 2 + c * 16) : OOB;
+            const int q = 64 * (wave + 4 * i) + lane, vr = q / 6, vc = q - vr * 6;
+            voff[i] = (unsigned)(vr * p.ldv * 2 + vc * 16);
+            vlive[i] = vc < C::CH;
+        }
+        auto issue_tile = [&](int t) {
+            char* sK = reinterpret_cast<char*>(sbase + (t & 3) * STAGE);
+            char* sV = sK + KB * C::KS * 2;
+            const int sk = t * KB * p.ldk * 2, sv = t * KB * p.ldv * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(sK + (wave + 4 * i) * 1024), 16, (int)koff[i], sk, 0, 0);
+            if (vlive[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(sV + wave * 1024), 16, (int)voff[0], sv, 0, 0);
+            if (wave < 2) {
+                if (vlive[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(sV + (wave + 4) * 1024), 16, (int)voff[1], sv, 0, 0);
+            }
+        };
+        __syncthreads();                           // the pad columns written above are visible before any tile is read
+        issue_tile(0);
+        if (ntiles > 1) issue_tile(1);
+        for (int t = 0; t < ntiles; ++t) {
+            if ((t & 1) == 0) {
+                // ONE barrier per PAIR of tiles (four slots: two being read, two in flight): tiles t and t + 1 were issued two tiles ago and
+                // nothing younger is in flight, so "landed" is vmcnt(0); behind the barrier the slots of tiles t - 2 / t - 1 are read out
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + 2 < ntiles) issue_tile(t + 2);
+                if (t + 3 < ntiles) issue_tile(t + 3);
+            }
+            const bool need_mask = p.causal || (t + 1) * KB > p.nk;
+            tile(t, t & 3, need_mask, t == 0);
+        }
+    } else {
     gload(0);
     if (DBUF) {
         swrite(0);
@@ -287,6 +339,7 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
             if (t + 1 < ntiles) swrite(st ^ 1);   // the other stage was last read in iteration t-1 (barrier below)
             __syncthreads();
         }
+    }
     }
 
     half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
@@ -511,8 +564,26 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
     static const int nq_env = getenv("PV_ATTN_NQ") ? atoi(getenv("PV_ATTN_NQ")) : 0;
     const long wg256 = (long)((p.nq + 255) / 256) * p.heads * p.batch;
     const bool four = D == 40 && (nq_env ? nq_env == 4 : wg256 >= 1024);
-    if (four) hipLaunchKernelGGL((attn_kernel<D, D == 40 ? 4 : 2>), dim3((unsigned)wg256), dim3(256), smem1, s, p);
-    else hipLaunchKernelGGL((attn_kernel<D, 2>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem1, s, p);
+    if constexpr (D == 40) {
+        static const bool no_dma = getenv("PV_ATTN_NO_DMA") != nullptr;      // A/B switch
+        if (!no_dma && (size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < (1ull << 31)) {
+            constexpr int smem3 = 4 * smem1;            // 56 KiB: above the 48-KiB default of dynamic LDS
+            static bool attr_set_dev[64] = {};
+            int dev_id = 0;
+            (void)hipGetDevice(&dev_id);
+            if (!attr_set_dev[dev_id & 63]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<40, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<40, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+                if (e != hipSuccess) return (int)e;
+                attr_set_dev[dev_id & 63] = true;
+            }
+            if (four) hipLaunchKernelGGL((attn_kernel<40, 4, true>), dim3((unsigned)wg256), dim3(256), smem3, s, p);
+            else hipLaunchKernelGGL((attn_kernel<40, 2, true>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem3, s, p);
+            return PV_CHECK_LAUNCH();
+        }
+    }
+    if (four) hipLaunchKernelGGL((attn_kernel<D, D == 40 ? 4 : 2, false>), dim3((unsigned)wg256), dim3(256), smem1, s, p);
+    else hipLaunchKernelGGL((attn_kernel<D, 2, false>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem1, s, p);
     return PV_CHECK_LAUNCH();
 }
 
