@@ -757,11 +757,13 @@ def test_adamw_state_dict_is_interchangeable_with_torch(need_gpu):
     assert torch.equal(o3.state[id(o3.params[0])][0], o2.state[qs[0]]["exp_avg"])
 
 
-def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
+def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu, full_weights):
     """The identity-loss branch at the FULL model sizes: SD-v1.5 UNet, 12-layer text encoder, 1024-wide adapters, the real VAE decoder
-    (64x64 latents -> 512x512 image, mid-block attention over 4096 tokens of width 512), ArcFace IR-ResNet18 at 128x128; B = 1, one face
+    (32x32 latents -> 256x256 image, mid-block attention over 1024 tokens of width 512), ArcFace IR-ResNet18 at 128x128; B = 1, one face
     sample, two inference steps (one without, one with gradient), guidance 2.  Image, loss and every gradient group against torch autograd
-    over the fp32 oracle composition (~4 min of host time)."""
+    over the LIVE fp32 oracle composition (the device draws the posterior / fusion samples, so this one cannot be a fixture): a quarter of the
+    512x512 spatial size keeps the oracle's autograd at ~30 s of host time - the 64x64-latent shapes (N = 4096 attention backward, every level)
+    are covered by tests/test_fullsize_gpu.py::test_full_size_training_gradients and the 512x512 decode by test_whole_generation_full_size."""
     import torch.nn.functional as F
     from types import SimpleNamespace
     from oracle.adapters_ref import PhotoVerseAdapterRef
@@ -778,20 +780,27 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     from photoverse_amd.train import TrainStep
     from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
     from photoverse_amd.vae import AutoencoderKL
+    from oracle import fullsize as fs
     torch.manual_seed(0)
     E, B, T, D, STEPS, G, FW = 5, 1, 257, 1024, 2, 2.0, 2.0
+    LAT, IMG = 32, 256
     lcfg = LoraConfig(r=8, lora_alpha=1)
     from oracle.lora_ref import LoraLinearRef, inject_adapter_in_model_ref
-    r_unet = UNet2DConditionModelRef().eval()
-    set_visual_cross_attention_adapter_ref(r_unet, (E,))
+    with fs.no_init():                                      # the session's seeded full-size weights (tests/conftest.py): no 40 s of default inits
+        r_unet = UNet2DConditionModelRef().eval()
+        set_visual_cross_attention_adapter_ref(r_unet, (E,))
+    r_unet.load_state_dict(full_weights("unet"))
     inject_adapter_in_model_ref(r_unet, r=lcfg.r, lora_alpha=lcfg.lora_alpha, target_modules=lcfg.target_modules)   # independent peft restatement
     g = torch.Generator().manual_seed(71)
     for m in r_unet.modules():
         if isinstance(m, LoraLinearRef):
             m.lora_B["default"].weight.data.normal_(0, 0.05, generator=g)
-    r_txt = CLIPTextModelRef().eval()
-    r_ia, r_ta = PhotoVerseAdapterRef(D, 768, E).eval(), PhotoVerseAdapterRef(D, 768, E).eval()
-    r_vae = AutoencoderKLDecoderRef().eval()
+    with fs.no_init():
+        r_txt = CLIPTextModelRef().eval()
+        r_ia, r_ta = PhotoVerseAdapterRef(D, 768, E).eval(), PhotoVerseAdapterRef(D, 768, E).eval()
+        r_vae = AutoencoderKLDecoderRef().eval()
+    r_txt.load_state_dict(full_weights("text")); r_ia.load_state_dict(full_weights("image_adapter")); r_ta.load_state_dict(full_weights("text_adapter"))
+    r_vae.load_state_dict({k: v for k, v in full_weights("vae").items() if k.startswith(("decoder.", "post_quant_conv."))})
     r_face_net = ArcFaceResNet18Ref().eval()
     for m in r_face_net.modules():
         if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
@@ -800,14 +809,17 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     with torch.no_grad():
         r_face_net(torch.randn(8, 1, 128, 128, generator=g) * 0.5)
     r_face_net.eval()
-    unet = UNet2DConditionModel()
-    set_visual_cross_attention_adapter(unet, (E,))
-    inject_adapter_in_model(lcfg, unet)
+    with fs.no_init():
+        unet = UNet2DConditionModel()
+        set_visual_cross_attention_adapter(unet, (E,))
+        inject_adapter_in_model(lcfg, unet)
+        text_encoder = CLIPTextModel()
+        image_adapter, text_adapter = PhotoVerseAdapter(D, 768, E), PhotoVerseAdapter(D, 768, E)
+        vae = AutoencoderKL(with_encoder=False) if "with_encoder" in AutoencoderKL.__init__.__code__.co_varnames else AutoencoderKL()
     unet.load_state_dict(r_unet.state_dict())
-    text_encoder = CLIPTextModel(); text_encoder.load_state_dict(r_txt.state_dict())
-    image_adapter = PhotoVerseAdapter(D, 768, E); image_adapter.load_state_dict(r_ia.state_dict())
-    text_adapter = PhotoVerseAdapter(D, 768, E); text_adapter.load_state_dict(r_ta.state_dict())
-    vae = AutoencoderKL(with_encoder=False) if "with_encoder" in AutoencoderKL.__init__.__code__.co_varnames else AutoencoderKL()
+    text_encoder.load_state_dict(r_txt.state_dict())
+    image_adapter.load_state_dict(r_ia.state_dict())
+    text_adapter.load_state_dict(r_ta.state_dict())
     vae.load_state_dict(r_vae.state_dict(), strict=False)
     face_net = ArcFaceResNet18(); face_net.load_state_dict(r_face_net.state_dict())
     for m in (unet, text_encoder, image_adapter, text_adapter, vae):
@@ -819,18 +831,18 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     train_names = [n for n in r_params if "to_k_ip" in n or "to_v_ip" in n or "lora_" in n]
     for n in train_names:
         r_params[n].requires_grad_(True)
-    noisy, noise = torch.randn(B, 4, 64, 64, generator=g), torch.randn(B, 4, 64, 64, generator=g)
+    noisy, noise = torch.randn(B, 4, LAT, LAT, generator=g), torch.randn(B, 4, LAT, LAT, generator=g)
     timesteps = torch.tensor([417])
     ids, pidx = torch.randint(0, 49000, (B, 77), generator=g), torch.tensor([[4]])
     embs = [torch.randn(B, T, D, generator=g).half() for _ in range(E)]
     forced = [0.5] * 16
-    real = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
-    start = torch.randn(1, 4, 64, 64, generator=g)
+    real = torch.rand(1, 3, IMG, IMG, generator=g) * 2 - 1
+    start = torch.randn(1, 4, LAT, LAT, generator=g)
     emb_u = torch.randn(1, T, D, generator=g).half()
     ids_p, ids_u = torch.randint(0, 49000, (1, 77), generator=g), torch.randint(0, 49000, (1, 77), generator=g)
     forced_u, forced_c = [0.5] * 16, [0.5] * 16
     forced_c[2], forced_u[7] = 0.05, 0.95
-    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=64, w=64, n_tokens=E, grad_scale=4096.0, fusion_seed=3, face_loss=face,
+    ts = TrainStep(unet, text_encoder, text_adapter, image_adapter, batch=B, h=LAT, w=LAT, n_tokens=E, grad_scale=4096.0, fusion_seed=3, face_loss=face,
                    vae=vae, noise_scheduler=SimpleNamespace(config=DPMSolverMultistepScheduler().config), face_samples=1, face_weight=FW,
                    guidance_scale=G, infer_steps=STEPS, use_graph=False)
     fi = dict(pixel_values=real.cuda(), start_latents=start.cuda(), image_embeddings=embs[0].cuda(), uncond_image_embeddings=emb_u.cuda(),
@@ -877,7 +889,7 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu):
     finally:
         pass
     err_img = rel_l2(out["face_images"], images.detach())
-    print(f"full-size face branch: floss {out['face_loss'].item():.5f} vs {floss.item():.5f}; 512x512 image rel-L2 {err_img:.3e}")
+    print(f"full-size face branch: floss {out['face_loss'].item():.5f} vs {floss.item():.5f}; {IMG}x{IMG} image rel-L2 {err_img:.3e}")
     assert err_img < 2e-2
     assert out["face_loss"].item() == pytest.approx(floss.item(), rel=3e-2, abs=3e-3)
     S = ts.grad_scale
