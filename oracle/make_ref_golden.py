@@ -13,6 +13,7 @@ numbers; per-tensor checksums are stored so a test can prove it).
                            chosen global seeds), tuple / list / deprecated bare-tensor conventions, P in {1, 5}, gradients
   ref_unet_golden.pt       ``set_visual_cross_attention_adapter`` + ``get_visual_cross_attention_values_norm`` (models/unet.py:8-47) on the
                            oracle's tiny UNet with the REFERENCE processor class installed: eps, V-norm stack, processor inventory
+  ref_adapter17_golden.pt  the real ``PhotoVerseAdapter`` with 17 mapping pairs on 6 hidden states (BASELINE configs[4] conditioning shape)
   ref_arcface_golden.pt    ``ArcFaceResNet18(pretrained=False)`` (models/arcface_resnet.py:12-134) and ``FaceLoss.preprocess`` / ``forward``
                            (models/loss.py:26-78): embeddings, preprocess output, loss, d loss / d x_gen
 """
@@ -180,9 +181,25 @@ def arcface_golden():
                 "loss_minimize": loss_min, "d_x_gen": xg.grad.clone()}, os.path.join(OUT, "ref_arcface_golden.pt"))
 
 
+def adapter17_golden():
+    """BASELINE configs[4] conditioning shape: extra_num_tokens = 16 -> 17 mapping pairs, encoder_layers_idx = 4,8,12,16,20 -> 6 CLIP hidden states
+    (infer.py:80-84), executed on the REAL reference class (models/adapters.py imports without diffusers).  Inputs are re-drawn from the seed by the tests."""
+    import sys
+    sys.path.insert(0, ref_exec.REF_ROOT)
+    from models.adapters import PhotoVerseAdapter
+    sys.path.pop(0)
+    ad = PhotoVerseAdapter(clip_embedding_dim=1024, cross_attention_dim=768, num_tokens=17).eval()
+    fill_state_(ad, 91)
+    g = torch.Generator().manual_seed(92)
+    embs = [torch.randn(2, 257, 1024, generator=g).half().float() for _ in range(6)]
+    with torch.no_grad():
+        outs = {"none": ad(embs), "0": ad(embs, token_index=0), "5": ad(embs, token_index=5)}
+    torch.save({"weights_seed": 91, "input_seed": 92, "n_state": len(ad.state_dict()), "outs": outs}, os.path.join(OUT, "ref_adapter17_golden.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for fn in (inject_golden, text_golden, processor_golden, unet_golden, arcface_golden):
+    for fn in (inject_golden, text_golden, processor_golden, unet_golden, arcface_golden, adapter17_golden):
         fn()
         print("wrote", fn.__name__)
     print("stand-ins used:")

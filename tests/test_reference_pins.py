@@ -192,3 +192,20 @@ def test_lora_oracle_is_independent_of_the_product_and_agrees_with_it():
     exp = x @ a.attn2.to_q.base_layer.weight.T + 2.0 * (x @ a.attn2.to_q.lora_A["default"].weight.T) @ a.attn2.to_q.lora_B["default"].weight.T
     torch.testing.assert_close(y, exp, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(torch.nn.functional.linear(x, b.attn2.to_q.weight), y, rtol=1e-5, atol=1e-5)   # product's merged weight
+
+
+def test_adapter_configs4_shape_matches_reference_class(golden_dir):
+    """The REAL models/adapters.py class with 17 mapping pairs on 6 CLIP hidden states (extra_num_tokens = 16, five encoder layers + the last:
+    BASELINE configs[4]) vs ``PhotoVerseAdapterRef`` - seeded weights, inputs re-drawn from the seed."""
+    from oracle.adapters_ref import PhotoVerseAdapterRef
+    g = _load(golden_dir, "ref_adapter17_golden.pt")
+    ad = PhotoVerseAdapterRef(1024, 768, 17).eval()
+    fill_state_(ad, g["weights_seed"])
+    assert len(ad.state_dict()) == g["n_state"]
+    gen = torch.Generator().manual_seed(g["input_seed"])
+    embs = [torch.randn(2, 257, 1024, generator=gen).half().float() for _ in range(6)]
+    with torch.no_grad():
+        for key, ti in (("none", None), ("0", 0), ("5", 5)):
+            out = ad(embs, token_index=ti)
+            assert out.shape == g["outs"][key].shape == ((2, 6, 768) if ti is None else (2, 1, 768))
+            torch.testing.assert_close(out, g["outs"][key], rtol=1e-5, atol=1e-5)

@@ -163,3 +163,21 @@ def test_arcface_loss_matches_reference_classes(need_gpu, golden_dir):
     assert loss.item() == pytest.approx(g["loss"].item(), rel=3e-2, abs=5e-4)
     assert float(lmin) == pytest.approx(g["loss_minimize"].item(), rel=1e-3)
     assert rel_l2(dimg, g["d_x_gen"]) < 1e-1
+
+
+def test_adapter_configs4_shape_matches_reference_class(need_gpu, golden_dir):
+    """HIP adapter with 17 mapping pairs on 6 CLIP hidden states (BASELINE configs[4] conditioning: extra_num_tokens = 16, five encoder layers + the
+    last) vs the REAL models/adapters.py class (fixture produced by executing it)."""
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    g = _load(golden_dir, "ref_adapter17_golden.pt")
+    ad = PhotoVerseAdapter(1024, 768, num_tokens=17)
+    fill_state_(ad, g["weights_seed"])
+    assert len(ad.state_dict()) == g["n_state"]
+    ad.to("cuda")
+    gen = torch.Generator().manual_seed(g["input_seed"])
+    embs = [torch.randn(2, 257, 1024, generator=gen).half().cuda() for _ in range(6)]
+    for key, ti in (("none", None), ("0", 0), ("5", 5)):
+        out = ad(embs, token_index=ti)
+        err = rel_l2(out, g["outs"][key])
+        print(f"17-mapping adapter token_index={ti}: rel-L2 vs reference class {err:.3e}")
+        assert out.shape == g["outs"][key].shape and err < 3e-3
