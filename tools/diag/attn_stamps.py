@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: in-kernel s_memtime stamps of one wave of the d=40 self-attention kernel (stamped COPY of pv_attn.hip, private lib).
-Per 64-key tile: barrier + LDS write + barrier | global prefetch issue | QK^T MFMAs | softmax | P.V MFMAs.  XA_ABLATE=nobar drops the
+Per 64-key tile of the LDS-DMA kernel: wait + barrier + DMA issue (even tiles) | QK^T MFMAs | softmax | P.V MFMAs.  XA_ABLATE=nobar drops the
 two workgroup barriers per tile (wrong results, timing only)."""
 import ctypes, os, subprocess, sys
 import torch
@@ -12,13 +12,11 @@ s = open(os.path.join(b.CSRC, "pv_attn.hip")).read()
 s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long at_stamps[16];\n'
               '#define STAMP(i) do { if (D == 40 && blockIdx.x == 1000 && threadIdx.x == 0 && t == 20) at_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
               % os.path.join(b.CSRC, "pv_common.h"))
-rep = [("        if (!DBUF) {\n            __syncthreads();  // previous tile fully consumed\n            swrite(0);\n            __syncthreads();\n        }",
-        "        STAMP(0);\n        if (!DBUF) {\n            %s\n            swrite(0);\n            %s\n        }\n        STAMP(1);" % (("", "") if "nobar" in ABL else ("__syncthreads();", "__syncthreads();"))),
-       ("        if (t + 1 < ntiles) gload(t + 1);\n", "        if (t + 1 < ntiles) gload(t + 1);\n        STAMP(2);\n"),
+rep = [("            if ((t & 1) == 0) {\n                // ONE barrier per PAIR of tiles", "            STAMP(0);\n            if ((t & 1) == 0) {\n                // ONE barrier per PAIR of tiles"),
+       ("            const bool need_mask = p.causal || (t + 1) * KB > p.nk;\n            tile(t, t & 3, need_mask, t == 0);\n", "            STAMP(1);\n            const bool need_mask = p.causal || (t + 1) * KB > p.nk;\n            tile(t, t & 3, need_mask, t == 0);\n            STAMP(5);\n"),
        ("        half8_t pb[2][NQ];\n#pragma unroll\n        for (int qi = 0; qi < NQ; ++qi) {\n            if (MASKED) {", "        STAMP(3);\n        half8_t pb[2][NQ];\n#pragma unroll\n        for (int qi = 0; qi < NQ; ++qi) {\n            if (MASKED) {"),
        ("#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);",
-        "        STAMP(4);\n#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);"),
-       ("        tile(t, st, need_mask, t == 0);\n", "        tile(t, st, need_mask, t == 0);\n        STAMP(5);\n")]
+        "        STAMP(4);\n#pragma unroll\n        for (int s2 = 0; s2 < 2; ++s2)\n#pragma unroll\n            for (int f = 0; f < C::DVF; ++f) {\n                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);")]
 for a, c in rep:
     assert a in s, a[:60]
     s = s.replace(a, c, 1)
@@ -55,7 +53,8 @@ fn = rec.lib.pv_at_stamps
 fn.restype = ctypes.c_int
 assert fn(out) == 0
 t = list(out)[:6]
-names = ["barrier + LDS write + barrier", "prefetch issue (next tile)", "QK^T (16 MFMA + reads)", "softmax (VALU)", "P.V (12 MFMA + tr reads)"]
+t = [t[0], t[1], t[1], t[3], t[4], t[5]]
+names = ["wait + barrier + DMA issue (even tile)", "-", "QK^T (32 MFMA + reads)", "softmax (VALU)", "P.V (24 MFMA + tr reads)"]
 print(f"ablate={ABL or '-'}  launch {e0.elapsed_time(e1) / 5 * 1e3:.1f} us;  tile 20 of workgroup 2000, wave 0:")
 for i in range(5):
     print(f"  {names[i]:34s} {t[i + 1] - t[i]:6d} cycles")
