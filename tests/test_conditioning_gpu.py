@@ -116,7 +116,9 @@ def test_run_inference_end_to_end_matches_oracle(need_gpu):
             cond, uncond = conditioning_ref(example, r_vis, r_txt, r_ta, r_ia, layers, token_index=token_index, uncond_input_ids=uids)
             exp = denoise_ref(r_unet, draw_noise_ref(B, 4, 16, seed=9), cond, uncond, guidance_scale=3.0, timesteps=3)
         assert got.shape == exp.shape
-        assert rel_l2(got, exp) < 1e-2
+        err = rel_l2(got, exp)
+        print(f"run_inference end to end (tiny config, token_index={token_index}): latents rel-L2 vs oracle {err:.3e}")
+        assert err < 3e-3           # measured 6.5e-4; the full-size counterpart (tests/test_fullsize_gpu.py::test_whole_generation_full_size) asserts 3e-3
     with pytest.raises(NotImplementedError):
         run_inference(example, tok, image_encoder, text_encoder, unet, text_adapter, image_adapter, None, scheduler, "cuda", [1],
                       latent_size=16, timesteps=2, from_noised_image=True)

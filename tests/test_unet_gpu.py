@@ -204,7 +204,7 @@ def test_processor_backward_matches_oracle_autograd(tiny_pair, name, N):
                 assert a is None or a.abs().max() < 1e-6, k
                 continue
             assert a is not None and a.shape == b.shape, k
-            assert rel_l2(a, b) < 1e-2, (k, seed, rel_l2(a, b))
+            assert rel_l2(a, b) < 4e-3, (k, seed, rel_l2(a, b))      # measured 4e-4 .. 1.5e-3 (the reference-code fixture: tests/test_reference_pins_gpu.py)
     ra.processor.forced_fusion_seed = ha.processor.forced_fusion_seed = None
     for _, get in plist:
         get(ha).grad = None
