@@ -455,7 +455,8 @@ def main():
         if levels:
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             xfused = {"what": "attn2 branch of every transformer block: norm2 -> to_q -> text + image-token SDPA (two softmaxes) -> to_out + bias + "
-                              "residual; ONE launch (pv_cross_attention_fused) at C = 320 / d = 40, four launches at C = 640 / 1280",
+                              "residual; ONE launch (pv_cross_attention_fused) at C = 320 / d = 40 and C = 640 / d = 80, four launches at C = 1280 "
+                              "(16 x 256 rows = 32 row-owning workgroups for 256 CUs)",
                       "levels": levels, "all_layers": {"layers_per_step": tot_n, "ms_per_step": round(tot_ms, 4), "achieved": round(ach, 1),
                                                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "weighting": "sum of algorithmic flops / sum of time"},
                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "north_star_target_frac": 0.40,

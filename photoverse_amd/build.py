@@ -19,7 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 #: per-source extra flags.  The attention kernels keep MFMA results in VGPRs (the softmax VALU work reads them directly;
 #: AGPR-form costs ~200 v_accvgpr moves per tile); the 256-row GEMM variant needs the AGPR half for its accumulators.
 EXTRA_FLAGS = {"pv_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
-               "pv_xfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+               "pv_xfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans",
+                                 "-mllvm", "-pragma-unroll-threshold=4000000"],   # the C = 640 body must unroll fully: register arrays
+
                "pv_rowgemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "pv_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}   # attention backward: 136 accvgpr moves per tile otherwise
 

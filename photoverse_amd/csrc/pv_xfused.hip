@@ -6,10 +6,12 @@
 // SDPA, :392-420 image-token SDPA + fusion, :423 to_out[0]) -> residual add of the transformer block.  It replaces four
 // launches (LayerNorm, to_q GEMM, dual-branch attention, to_out GEMM) and six passes of a (B*N, C) tensor through HBM by one
 // read of hs and one write of out.  Built for the C = 320 / d = 40 layers (64x64 and larger levels: 63 % of attn2's launches'
-// time at 512x512), where M = B*N is large and the GEMMs are too short-K to run well on their own.
+// time at 512x512), where M = B*N is large and the GEMMs are too short-K to run well on their own; the C = 640 / d = 80
+// instantiation (one head per 80-feature group) runs 64-row workgroups so that the 16 x 1024 rows of a 32x32 level still fill the chip
+// (74 us vs 80 us for the four launches; 128-row workgroups = 128 of 256 CUs: 99 us).  C = 1280 (16 x 256 rows) stays on four launches.
 //
 // Structure: one workgroup = 128 query rows x ALL heads, 4 waves, 80 KiB of LDS -> two workgroups per CU.  A wave owns 32 query
-// rows (two 16-column MFMA operands) for the whole chain, so no activation ever leaves the register file:
+// rows (two 16-column MFMA operands; NQ = 1: 16 rows) for the whole chain, so no activation ever leaves the register file:
 //
 //   phase 0  X^T (B operand of v_mfma_f32_16x16x32_f16: lane = query, 8 consecutive channels per k-group) is loaded straight
 //            into registers; LayerNorm statistics by v_dot2_f32_f16 + a 4-lane swap reduction; normalised in place (its affine
@@ -55,16 +57,26 @@ __host__ __device__ inline int kslot_feature40(int hh, int kappa) {
     return gf >= 40 ? gf - 40 : -1;
 }
 
+// d = 80 (C = 640): one head = one 80-feature group = five whole fragments.  Slot kappa (0..127; 128 slots = 256-B K image rows, the fourth
+// k-step never read) of k-step s = kappa >> 5: s < 2 pairs the fragments 2s, 2s+1; s == 2 is fragment 4 alone (upper half zero).
+__host__ __device__ inline int kslot_feature80(int kappa) {
+    const int s = kappa >> 5, g = (kappa >> 3) & 3, jj = kappa & 7;
+    if (s < 2) return jj < 4 ? 32 * s + 4 * g + jj : 32 * s + 16 + 4 * g + (jj - 4);
+    if (s == 2 && jj < 4) return 64 + 4 * g + jj;
+    return -1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // pv_xattn_pack_kv: builds, once per conditioning, the exact LDS images the fused kernel DMA-copies:
-//   kimg [B][heads][96][64] fp16, slot order of kslot_feature40, 16-B chunk c of row r stored at position c ^ (r & 7)
+//   d = 40: kimg [B][heads][96][64] fp16, slot order of kslot_feature40, 16-B chunk c of row r stored at position c ^ (r & 7)
+//   d = 80: kimg [B][heads][96][128] fp16, slot order of kslot_feature80, chunk c of row r at position c ^ (r & 15) (256-B rows span all banks)
 //   vimg [B][C/80][96][80] fp16 (natural column order)
 //   vnorm[B][heads][nip]   = ||Vip[b, p, h, :]||_2   (attention_processor.py:397)
 __global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const half_t* kt, const half_t* vt, int ldkt, int ldvt, const half_t* kip,
                                                             const half_t* vip, int ldkip, int ldvip, half_t* kimg, half_t* vimg,
-                                                            float* vnorm, int heads, int nt, int nip) {
+                                                            float* vnorm, int heads, int nt, int nip, int d) {
     const int b = blockIdx.x / XK, key = blockIdx.x % XK;
-    const int C = heads * 40;
+    const int C = heads * d;
     const half_t *krow = nullptr, *vrow = nullptr;
     if (key < nt) {
         krow = kt + (size_t)(b * nt + key) * ldkt;
@@ -74,17 +86,32 @@ __global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const half_t* kt, co
         vrow = vip + (size_t)(b * nip + key - XIP0) * ldvip;
     }
     const int tid = threadIdx.x;
-    for (int i = tid; i < heads * 8; i += 256) {        // K: one 16-B chunk (8 slots) per item
-        const int h = i >> 3, c = i & 7;
-        half8_t v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        if (krow) {
+    if (d == 40) {
+        for (int i = tid; i < heads * 8; i += 256) {        // K: one 16-B chunk (8 slots) per item
+            const int h = i >> 3, c = i & 7;
+            half8_t v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (krow) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int f = kslot_feature40(h & 1, c * 8 + jj);
-                if (f >= 0) v[jj] = krow[h * 40 + f];
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int f = kslot_feature40(h & 1, c * 8 + jj);
+                    if (f >= 0) v[jj] = krow[h * 40 + f];
+                }
             }
+            *reinterpret_cast<half8_t*>(kimg + ((size_t)(b * heads + h) * XK + key) * 64 + ((c ^ (key & 7)) << 3)) = v;
         }
-        *reinterpret_cast<half8_t*>(kimg + ((size_t)(b * heads + h) * XK + key) * 64 + ((c ^ (key & 7)) << 3)) = v;
+    } else {
+        for (int i = tid; i < heads * 16; i += 256) {       // d = 80: sixteen chunks per 256-B row
+            const int h = i >> 4, c = i & 15;
+            half8_t v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (krow) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int f = kslot_feature80(c * 8 + jj);
+                    if (f >= 0) v[jj] = krow[h * 80 + f];
+                }
+            }
+            *reinterpret_cast<half8_t*>(kimg + ((size_t)(b * heads + h) * XK + key) * 128 + ((c ^ (key & 15)) << 3)) = v;
+        }
     }
     for (int i = tid; i < C / 8; i += 256) {            // V: 16-B chunks, natural order
         const int grp = (i * 8) / GF, j = i * 8 - grp * GF;
@@ -94,8 +121,8 @@ __global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const half_t* kt, co
     }
     if (vnorm && key >= XIP0 && key < XIP0 + nip && tid < heads) {
         float a = 0.f;
-        for (int d = 0; d < 40; ++d) {
-            const float v = (float)vrow[tid * 40 + d];
+        for (int j = 0; j < d; ++j) {
+            const float v = (float)vrow[tid * d + j];
             a += v * v;
         }
         vnorm[((size_t)b * heads + tid) * nip + (key - XIP0)] = sqrtf(a);
@@ -105,6 +132,9 @@ __global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const half_t* kt, co
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ half8_t ld_frag128(const char* base, int row, int chunk) {   // 128-B rows, chunk ^= row & 7
     return *reinterpret_cast<const half8_t*>(base + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ half8_t ld_frag256(const char* base, int row, int chunk) {   // 256-B rows (d = 80 K image), chunk ^= row & 15
+    return *reinterpret_cast<const half8_t*>(base + row * 256 + ((chunk ^ (row & 15)) << 4));
 }
 
 // V^T fragment (MFMA-A): output rows dv0..dv0+15, contraction slots = keys {key0+4g..+3, key0+16+4g..+3}
@@ -146,11 +176,15 @@ struct pv_xfused_params_dev : pv_xattn_fused_params {
 // ONE key is 1 whatever the query, so the whole image-token branch is "+ w_ip * v_ip": its score fragment, its max / exp / sum and its
 // two 4-lane reductions disappear (a fifth of the attention phase's VALU work); the value row still rides in the P.V contraction with
 // the constant probability w_ip.
-template <int C, bool IP1>
-__global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_params_dev p) {
+// C = 640 (d = 80): the same four phases; a group is ONE head of 80 features (five whole fragments), the K image rows are 256 B (three 32-slot
+// k-steps used).  The row operands alone are X^ (160 VGPRs) + Q / context (160): one wave per SIMD (512-register budget, one workgroup per CU).
+template <int C, bool IP1, int NQ = 2>
+__global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fused_kernel(const pv_xfused_params_dev p) {
+    constexpr int ROWS = 64 * NQ;     // query rows per workgroup: each of the 4 waves owns NQ 16-row MFMA column tiles
     static_assert(C % GF == 0 && C % 64 == 0, "C must be a multiple of 80 and of 64");
-    constexpr int D = 40;
-    constexpr int NG = C / GF;        // feature groups (pairs of heads): 4
+    constexpr int D = C / 8;          // 8 heads: d = 40 (C = 320) or 80 (C = 640)
+    static_assert(D == 40 || D == 80, "instantiated for the C = 320 and C = 640 layers");
+    constexpr int NG = C / GF;        // 80-feature groups: 4 pairs of heads (d = 40) or 8 heads (d = 80)
     constexpr int NFR = C / 16;       // 16-feature fragments per row: 20
     constexpr int KK = C / 32;        // 32-deep contraction steps over C: 10
     constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk: 5
@@ -171,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 
     const int lane = pv_lane_id(), wave = pv_wave_id();
     const int fr = lane & 15, g = lane >> 4;
-    const int m0 = (int)blockIdx.x * 128;
+    const int m0 = (int)blockIdx.x * ROWS;
     const int b = m0 / p.nq;
     const half_t* hs = reinterpret_cast<const half_t*>(p.hs);
     const float w_text = p.fusion ? p.fusion[0] : p.w_text;
@@ -182,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.kimg), 0, (int)p.kimg_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vimg), 0, (int)p.vimg_bytes, 0x00020000);
     // the workgroup's 128 rows of hs / out through buffer descriptors: one 32-bit row offset per lane instead of 64-bit pointers
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(hs) + (size_t)m0 * p.ld_hs, 0, 128 * p.ld_hs * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<half_t*>(p.out) + (size_t)m0 * p.ld_out, 0, 128 * p.ld_out * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(hs) + (size_t)m0 * p.ld_hs, 0, ROWS * p.ld_hs * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<half_t*>(p.out) + (size_t)m0 * p.ld_out, 0, ROWS * p.ld_out * 2, 0x00020000);
 
     // ---- LDS-DMA issue helpers (one piece = one wave instruction = 1 KiB) -----------------------------------------------
     // Ring stage t of a [C][C] weight: rows [80 (t/KT), +80) x k [64 (t%KT), +64); 10 pieces of 8 rows x 128 B: waves 0,1 issue 3,
@@ -244,13 +278,13 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     };
 
     // ---- phase 0: X^T into registers (+ LayerNorm) -----------------------------------------------------------------------
-    half8_t xf[KK][2];
-    int mrow[2];
+    half8_t xf[KK][NQ];
+    int mrow[NQ];
     typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
     typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        mrow[qi] = wave * 32 + qi * 16 + fr;                 // row inside the workgroup's block
+    for (int qi = 0; qi < NQ; ++qi) {
+        mrow[qi] = wave * (16 * NQ) + qi * 16 + fr;                 // row inside the workgroup's block
         const int off = mrow[qi] * p.ld_hs * 2 + g * 16;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rh, off, kk * 64, 0));
@@ -266,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
         typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
         const h2_t ones = h2_t{(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
             float sum = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
@@ -302,10 +336,10 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 
     // ---- phase 1: Q^T = Wq . X^T -----------------------------------------------------------------------------------------
     // qf[f][qi]: fp16 of fragment f (features 16 f + 4g + r) for this lane's query, pre-scaled by log2(e)/sqrt(d)
-    half4_t qf[NFR][2];
+    half4_t qf[NFR][NQ];
     const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
     {
-        float4_t acc[5][2];
+        float4_t acc[5][NQ];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int nc = t / KT, kt = t % KT;
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 // accumulators start from the query bias (beta of the folded LayerNorm pushed through to_q), rows 4g..4g+3 of each fragment
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    acc[i][0] = acc[i][1] = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + nc * GF + i * 16 + g * 4) : float4_t{0.f, 0.f, 0.f, 0.f};
+                    { const float4_t v0 = p.q_bias ? *reinterpret_cast<const float4_t*>(p.q_bias + nc * GF + i * 16 + g * 4) : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) acc[i][qi] = v0; }
             }
             if ((t & 1) == 0) {
                 // ONE barrier per pair of stages: stages t and t+1 were issued two stages ago right behind that barrier and nothing younger
@@ -330,14 +364,14 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 for (int i = 0; i < 5; ++i) {
                     const half8_t a = *reinterpret_cast<const half8_t*>(base + i * 2048);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[2 * kt + ks][qi], acc[i][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[2 * kt + ks][qi], acc[i][qi], 0, 0, 0);
                 }
             }
             if (kt == KT - 1) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) {
+                    for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) qf[nc * 5 + i][qi][r] = (half_t)(acc[i][qi][r] * qscale);
                         xf_pin(qf[nc * 5 + i][qi]);      // convert here: do not carry fp32 accumulators into the next chunk / phase
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     // group g lives in buffer (g + 1) & 1: group 0 was prefetched into buffer 1 at kernel start
     wg_barrier();                          // every wave is done with the Wq ring (buffer 0)
     issue_group(1, buf0);
-    half4_t cf[NFR][2];                    // context fragments, same layout as qf
+    half4_t cf[NFR][NQ];                    // context fragments, same layout as qf
     // padding keys of fragment 4 (text tail) and fragment 5 (image tokens): their K rows are zero, so the MFMA leaves the
     // accumulator's initial value in place - start those from -inf instead of selecting per score afterwards
     float4_t tinit, iinit;
@@ -369,32 +403,29 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
         wg_barrier();
         const char* sbuf = ((grp + 1) & 1) ? buf1 : buf0;
         const half_t* sV = reinterpret_cast<const half_t*>(sbuf + 2 * KIMG_BYTES);
-        float4_t o2_h0[2];                 // head 0's fragment 2 (its rows 0-7 are head 0's features 32..39)
+        if constexpr (D == 80) {
+            // ---- d = 80: the group IS one head; five whole fragments, three 32-slot k-steps (the third half empty) ----------------------
+            const char* sK = sbuf;
+            const int f0 = grp * 5;
+            constexpr int NKB = IP1 ? 5 : 6;
+            float4_t s[NKB][NQ];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const char* sK = sbuf + hh * KIMG_BYTES;
-            const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
-            constexpr int NKB = IP1 ? 5 : 6;   // score fragments: 5 of text keys (+ 1 of image-token keys)
-            float4_t s[NKB][2];
+            for (int kb = 0; kb < NKB; ++kb) { const float4_t v0 = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = v0; }
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) s[kb][0] = s[kb][1] = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < 3; ++ks) {
+                half8_t bq[NQ];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                half8_t bq[2];
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) bq[qi] = ks == 0 ? cat4(qf[fa][qi], qf[fb][qi]) : cat4(qf[f2][qi], qf[f2][qi]);
+                for (int qi = 0; qi < NQ; ++qi) bq[qi] = ks < 2 ? cat4(qf[f0 + 2 * ks][qi], qf[f0 + 2 * ks + 1][qi]) : cat4(qf[f0 + 4][qi], qf[f0 + 4][qi]);
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
-                    const half8_t a = ld_frag128(sK, kb * 16 + fr, ks * 4 + g);
+                    const half8_t a = ld_frag256(sK, kb * 16 + fr, ks * 4 + g);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
                 }
             }
-            // two independent softmaxes over the key axis (registers r, fragments kb, and the 4 lane groups).  Text keys are
-            // fragments 0..4 (keys 0..79; only the tail of fragment 4 can be padding), image-token keys are fragment 5.
-            half8_t pb[3][2];
+            half8_t pb[3][NQ];
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
+            for (int qi = 0; qi < NQ; ++qi) {
                 float mt = -INFINITY;
 #pragma unroll
                 for (int kb = 0; kb < 5; ++kb)
@@ -406,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 for (int kb = 0; kb < 5; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s[kb][qi][r] = PV_EXP2(s[kb][qi][r] - mt);       // exp2(-inf) = 0 for the padding keys
+                        s[kb][qi][r] = PV_EXP2(s[kb][qi][r] - mt);
                         lt += s[kb][qi][r];
                     }
                 lt = pv_quad_sum(lt);
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 for (int r = 0; r < 4; ++r) pb[2][qi][r] = (half_t)(s[4][qi][r] * ft);
                 if constexpr (IP1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = ip1p[r];      // softmax over one key = 1: P = w_ip at key XIP0, 0 elsewhere
+                    for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = ip1p[r];
                 } else {
                     float mi = -INFINITY;
 #pragma unroll
@@ -440,39 +471,131 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                     for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = (half_t)(s[NKB - 1][qi][r] * fi);
                 }
             }
-            // O^T = V^T . P^T for this head's three fragments of the group's 80 value columns
-            float4_t o[3][2];
+            float4_t o[5][NQ];
 #pragma unroll
-            for (int fi = 0; fi < 3; ++fi) o[fi][0] = o[fi][1] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int fi = 0; fi < 5; ++fi) { const float4_t v0 = float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = v0; }
 #pragma unroll
             for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
-                for (int fi = 0; fi < 3; ++fi) {
-                    const half8_t a = vt_frag80(sV, s2 * 32, (hh == 0 ? fi : fi + 2) * 16, fr, g);
+                for (int fi = 0; fi < 5; ++fi) {
+                    const half8_t a = vt_frag80(sV, s2 * 32, fi * 16, fr, g);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[fi][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[fi][qi], 0, 0, 0);
                 }
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                if (hh == 0) {
+            for (int fi = 0; fi < 5; ++fi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        cf[grp * 5 + 0][qi][r] = (half_t)o[0][qi][r];
-                        cf[grp * 5 + 1][qi][r] = (half_t)o[1][qi][r];
-                    }
-                    xf_pin(cf[grp * 5 + 0][qi]);
-                    xf_pin(cf[grp * 5 + 1][qi]);
-                    o2_h0[qi] = o[2][qi];
-                } else {
+                for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        cf[grp * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
-                        cf[grp * 5 + 3][qi][r] = (half_t)o[1][qi][r];
-                        cf[grp * 5 + 4][qi][r] = (half_t)o[2][qi][r];
+                    for (int r = 0; r < 4; ++r) cf[f0 + fi][qi][r] = (half_t)o[fi][qi][r];
+                    xf_pin(cf[f0 + fi][qi]);
+                }
+        } else {
+            float4_t o2_h0[NQ];                 // head 0's fragment 2 (its rows 0-7 are head 0's features 32..39)
+    #pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const char* sK = sbuf + hh * KIMG_BYTES;
+                const int fa = grp * 5 + (hh == 0 ? 0 : 3), fb = fa + 1, f2 = grp * 5 + 2;
+                constexpr int NKB = IP1 ? 5 : 6;   // score fragments: 5 of text keys (+ 1 of image-token keys)
+                float4_t s[NKB][NQ];
+    #pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) { const float4_t v0 = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = v0; }
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    half8_t bq[NQ];
+    #pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) bq[qi] = ks == 0 ? cat4(qf[fa][qi], qf[fb][qi]) : cat4(qf[f2][qi], qf[f2][qi]);
+    #pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        const half8_t a = ld_frag128(sK, kb * 16 + fr, ks * 4 + g);
+    #pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
                     }
-                    xf_pin(cf[grp * 5 + 2][qi]);
-                    xf_pin(cf[grp * 5 + 3][qi]);
-                    xf_pin(cf[grp * 5 + 4][qi]);
+                }
+                // two independent softmaxes over the key axis (registers r, fragments kb, and the 4 lane groups).  Text keys are
+                // fragments 0..4 (keys 0..79; only the tail of fragment 4 can be padding), image-token keys are fragment 5.
+                half8_t pb[3][NQ];
+    #pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    float mt = -INFINITY;
+    #pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kb][qi][r]);
+                    mt = pv_quad_max(mt);
+                    float lt = 0.f;
+    #pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s[kb][qi][r] = PV_EXP2(s[kb][qi][r] - mt);       // exp2(-inf) = 0 for the padding keys
+                            lt += s[kb][qi][r];
+                        }
+                    lt = pv_quad_sum(lt);
+                    const float ft = w_text * __builtin_amdgcn_rcpf(lt);
+    #pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pb[s2][qi][r] = (half_t)(s[2 * s2][qi][r] * ft);
+                            pb[s2][qi][r + 4] = (half_t)(s[2 * s2 + 1][qi][r] * ft);
+                        }
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[2][qi][r] = (half_t)(s[4][qi][r] * ft);
+                    if constexpr (IP1) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = ip1p[r];      // softmax over one key = 1: P = w_ip at key XIP0, 0 elsewhere
+                    } else {
+                        float mi = -INFINITY;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) mi = fmaxf(mi, s[NKB - 1][qi][r]);
+                        mi = pv_quad_max(mi);
+                        float li = 0.f;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s[NKB - 1][qi][r] = PV_EXP2(s[NKB - 1][qi][r] - mi);
+                            li += s[NKB - 1][qi][r];
+                        }
+                        li = pv_quad_sum(li);
+                        const float fi = w_ip * __builtin_amdgcn_rcpf(li);
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) pb[2][qi][r + 4] = (half_t)(s[NKB - 1][qi][r] * fi);
+                    }
+                }
+                // O^T = V^T . P^T for this head's three fragments of the group's 80 value columns
+                float4_t o[3][NQ];
+    #pragma unroll
+                for (int fi = 0; fi < 3; ++fi) { const float4_t v0 = float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = v0; }
+    #pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2)
+    #pragma unroll
+                    for (int fi = 0; fi < 3; ++fi) {
+                        const half8_t a = vt_frag80(sV, s2 * 32, (hh == 0 ? fi : fi + 2) * 16, fr, g);
+    #pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[fi][qi], 0, 0, 0);
+                    }
+    #pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    if (hh == 0) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            cf[grp * 5 + 0][qi][r] = (half_t)o[0][qi][r];
+                            cf[grp * 5 + 1][qi][r] = (half_t)o[1][qi][r];
+                        }
+                        xf_pin(cf[grp * 5 + 0][qi]);
+                        xf_pin(cf[grp * 5 + 1][qi]);
+                        o2_h0[qi] = o[2][qi];
+                    } else {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            cf[grp * 5 + 2][qi][r] = (half_t)(g < 2 ? o2_h0[qi][r] : o[0][qi][r]);
+                            cf[grp * 5 + 3][qi][r] = (half_t)o[1][qi][r];
+                            cf[grp * 5 + 4][qi][r] = (half_t)o[2][qi][r];
+                        }
+                        xf_pin(cf[grp * 5 + 2][qi]);
+                        xf_pin(cf[grp * 5 + 3][qi]);
+                        xf_pin(cf[grp * 5 + 4][qi]);
+                    }
                 }
             }
         }
@@ -491,9 +614,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
     // even lane-rows' fragment 2q+1 against the odd lane-rows' fragment 2q, after which every lane owns 8 CONSECUTIVE columns: the
     // residual rows are fetched and the output rows stored with 16 bytes per lane (fragment 4, the odd one out, keeps 8 bytes).
     {
-        float4_t acc[5][2];
-        uint4_t res16[2][2];              // residual of fragment pairs (0,1), (2,3) in the swapped (16-byte) layout
-        uint2_t res8[2];                  // residual of fragment 4
+        float4_t acc[5][NQ];
+        uint4_t res16[2][NQ];              // residual of fragment pairs (0,1), (2,3) in the swapped (16-byte) layout
+        uint2_t res8[NQ];                  // residual of fragment 4
         const int pcol = (g & 1) ? 16 + (g - 1) * 4 : g * 4;      // this lane's 8 columns inside a fragment pair
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -504,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 // stay in flight: the 6 output stores of a chunk that ended in stage t-2 or t-1 and the 6 residual loads of a chunk that
                 // started there (the bias loads are not counted: a smaller count only waits longer).  Counting them exactly keeps the HBM
                 // write latency of a chunk's stores out of the next stages' critical path.
-                constexpr int RES = 6, STO = 6;
+                constexpr int RES = 3 * NQ, STO = 3 * NQ;
                 int younger = 0;
                 if (t >= 2) {
                     if ((t - 2) % KT == 0) younger += RES;
@@ -513,6 +636,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                     if ((t - 1) % KT == KT - 1) younger += STO;
                 }
                 switch (younger) {
+                    case 3: xf_wait_vmcnt<3>(); break;
                     case 6: xf_wait_vmcnt<6>(); break;
                     case 12: xf_wait_vmcnt<12>(); break;
                     default: xf_wait_vmcnt<0>(); break;
@@ -525,9 +649,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    acc[i][0] = acc[i][1] = p.bias_o ? *reinterpret_cast<const float4_t*>(p.bias_o + nb + i * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+                    { const float4_t v0 = p.bias_o ? *reinterpret_cast<const float4_t*>(p.bias_o + nb + i * 16) : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) acc[i][qi] = v0; }
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) {
+                for (int qi = 0; qi < NQ; ++qi) {
                     const int roff = mrow[qi] * p.ld_hs * 2;
                     res16[0][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2 + nc * (GF * 2), 0, 0);
                     res16[1][qi] = __builtin_amdgcn_raw_buffer_load_b128(rh, roff + pcol * 2 + nc * (GF * 2) + 64, 0, 0);
@@ -537,19 +661,19 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* base = buf1 + (t % S) * TILE_BYTES + ring_lane[ks];
-                half8_t bc[2];
+                half8_t bc[NQ];
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) bc[qi] = cat4(cf[2 * (2 * kt + ks)][qi], cf[2 * (2 * kt + ks) + 1][qi]);
+                for (int qi = 0; qi < NQ; ++qi) bc[qi] = cat4(cf[2 * (2 * kt + ks)][qi], cf[2 * (2 * kt + ks) + 1][qi]);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const half8_t a = *reinterpret_cast<const half8_t*>(base + i * 2048);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bc[qi], acc[i][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi) acc[i][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bc[qi], acc[i][qi], 0, 0, 0);
                 }
             }
             if (kt == KT - 1) {
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) {
+                for (int qi = 0; qi < NQ; ++qi) {
                     const int ooff = mrow[qi] * p.ld_out * 2;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -589,12 +713,12 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const pv_xfused_par
 extern "C" int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt, const void* kip, const void* vip, int32_t ldkip,
                                 int32_t ldvip, void* kimg, void* vimg, float* vnorm, int32_t batch, int32_t heads, int32_t d, int32_t nt,
                                 int32_t nip, void* stream) {
-    if (!kt || !vt || !kip || !vip || !kimg || !vimg || batch <= 0 || heads <= 0 || (heads & 1) || d != 40 || nt <= 0 || nt > XIP0 || nip <= 0 ||
+    if (!kt || !vt || !kip || !vip || !kimg || !vimg || batch <= 0 || heads <= 0 || (heads & 1) || (d != 40 && d != 80) || nt <= 0 || nt > XIP0 || nip <= 0 ||
         nip > XK - XIP0 || (ldkt % 8) || (ldvt % 8) || (ldkip % 8) || (ldvip % 8))
         return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3(batch * XK), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const half_t*>(kt),
                        reinterpret_cast<const half_t*>(vt), ldkt, ldvt, reinterpret_cast<const half_t*>(kip), reinterpret_cast<const half_t*>(vip),
-                       ldkip, ldvip, reinterpret_cast<half_t*>(kimg), reinterpret_cast<half_t*>(vimg), vnorm, heads, nt, nip);
+                       ldkip, ldvip, reinterpret_cast<half_t*>(kimg), reinterpret_cast<half_t*>(vimg), vnorm, heads, nt, nip, d);
     return PV_CHECK_LAUNCH();
 }
 
@@ -609,26 +733,35 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     pv_xfused_params_dev p;
     static_cast<pv_xattn_fused_params&>(p) = *pp;
     const int C = p.heads * p.d;
-    if (!p.hs || !p.wq || !p.wo || !p.kimg || !p.vimg || !p.out || p.batch <= 0 || p.nq <= 0 || (p.nq % 128) || p.d != 40 || C != 320 ||
+    if (!p.hs || !p.wq || !p.wo || !p.kimg || !p.vimg || !p.out || p.batch <= 0 || p.nq <= 0 || (p.nq % 128) || p.heads != 8 || (C != 320 && C != 640) ||
         p.nt <= 64 || p.nt > XIP0 || p.nip <= 0 || p.nip > XK - XIP0 || (p.ld_hs % 8) || (p.ld_out % 8))
         return (int)hipErrorInvalidValue;
     p.w_bytes = (uint32_t)C * C * 2;
-    const size_t kb = (size_t)p.batch * p.heads * XK * KROW, vb = (size_t)p.batch * (C / GF) * XK * GF * 2;
+    const size_t kb = (size_t)p.batch * p.heads * XK * (p.d == 40 ? 128 : 256), vb = (size_t)p.batch * (C / GF) * XK * GF * 2;
     if (kb >= (1ull << 31) || vb >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
     constexpr int SMEM = 2 * 4 * GF * 128;   // two 40-KiB buffers (4-slot weight ring / one 39-KiB K/V group each): two workgroups per CU
-    static bool attr_set_dev[64][2] = {};
+    // rows per workgroup: 128 (a wave owns two 16-row tiles: every weight fragment read from LDS feeds two MFMAs) or 64.  The C = 640 levels
+    // have 16 x 1024 rows = 128 workgroups of 128 - half of the 256 CUs; 64-row workgroups fill the chip (PV_XF_ROWS=64/128 overrides).
+    static const int rows_env = [] { const char* e = getenv("PV_XF_ROWS"); return e ? atoi(e) : 0; }();
+    const size_t M = (size_t)p.batch * p.nq;
+    int rows = C == 640 && M / 128 < 384 ? 64 : 128;
+    if (C == 640 && (rows_env == 64 || rows_env == 128)) rows = rows_env;
+    static bool attr_set_dev[64][6] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const bool ip1 = p.nip == 1;
-    bool& attr_set = attr_set_dev[dev_id & 63][ip1 ? 1 : 0];
-    auto kern = ip1 ? xattn_fused_kernel<320, true> : xattn_fused_kernel<320, false>;
+    const int variant = C == 320 ? 0 : rows == 128 ? 1 : 2;
+    bool& attr_set = attr_set_dev[dev_id & 63][variant * 2 + (ip1 ? 1 : 0)];
+    auto kern = variant == 0 ? (ip1 ? xattn_fused_kernel<320, true, 2> : xattn_fused_kernel<320, false, 2>)
+              : variant == 1 ? (ip1 ? xattn_fused_kernel<640, true, 2> : xattn_fused_kernel<640, false, 2>)
+                             : (ip1 ? xattn_fused_kernel<640, true, 1> : xattn_fused_kernel<640, false, 1>);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)p.batch * p.nq / 128)), dim3(256), SMEM, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(M / rows)), dim3(256), SMEM, (hipStream_t)stream, p);
     return PV_CHECK_LAUNCH();
 }

@@ -416,10 +416,12 @@ class Recorder:
         self._add(self.lib.pv_cross_attention, p, tag=("pv_cross_attention", 4.0 * batch * nq * (nt + nip) * heads * d, 2.0 * 2 * batch * nq * heads * d))
         return out, p
 
-    # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual), C = 320 / d = 40 layers ----
+    # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual): C = 320 / d = 40 and C = 640 / d = 80 layers ----
+    XFUSED_WIDTHS = tuple(int(w) for w in os.environ.get("PV_XFUSED_WIDTHS", "320,640").split(",") if w)   # A/B switch
+
     @staticmethod
     def xattn_fused_supported(C: int, heads: int, nq: int, nt: int, nip: int) -> bool:
-        return C == 320 and heads == 8 and nq % 128 == 0 and 64 < nt <= 80 and 0 < nip <= 16
+        return C in Recorder.XFUSED_WIDTHS and heads == 8 and nq % 128 == 0 and 64 < nt <= 80 and 0 < nip <= 16
 
     def pack_wo_for_fused(self, wo: torch.Tensor) -> torch.Tensor:
         """to_out[0].weight [C][C] with its columns in the fused kernel's context-slot order (pv_xattn_fused_wo_slot)."""
@@ -430,7 +432,7 @@ class Recorder:
     def xattn_pack_kv(self, kt, vt, kip, vip, *, batch, heads, d, nt, nip, vnorm=None):
         """K / V images of the fused kernel (once per conditioning) + to_v_ip_norm."""
         C = heads * d
-        kimg = self.empty((batch * heads * 96 * 64,), torch.float16)
+        kimg = self.empty((batch * heads * 96 * (64 if d == 40 else 128),), torch.float16)   # 64 / 128 contraction slots per key row
         vimg = self.empty((batch * (C // 80) * 96 * 80,), torch.float16)
         self.keep.extend(t for t in (kt, vt, kip, vip, vnorm) if t is not None)
         self._add(self.lib.pv_xattn_pack_kv, _ptr(kt), _ptr(vt), _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0],
@@ -455,7 +457,7 @@ class Recorder:
         self.keep.extend(t for t in (hs, wq, q_bias, wo_packed, bias_o, kimg, vimg, fusion, out) if t is not None)
         M = batch * nq
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)
-        self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<320, %s>" % ("true" if nip == 1 else "false"), flops, 2.0 * (3 * M * C + 2 * C * C)))
+        self._add(self.lib.pv_cross_attention_fused, p, tag=("xattn_fused_kernel<%d, %s>" % (C, "true" if nip == 1 else "false"), flops, 2.0 * (3 * M * C + 2 * C * C)))
         return out, p
 
     # ---- LayerNorm + Linear (+ GEGLU) of the K = 320 transformer layers as one row-owning launch (pv_rowgemm.hip) ----

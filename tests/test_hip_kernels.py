@@ -309,13 +309,15 @@ def test_cross_attention_dual_branch(rec_cls, d, n, p, wt, wi):
     torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
 
 
-@pytest.mark.parametrize("n,p,wt,wi,ln,fus", [(4096, 1, 1.0, 1.0, True, False), (128, 5, 1.0, 1.0, True, False), (256, 6, 2.0, 0.0, False, False),
-                                             (128, 16, 0.0, 2.0, True, True)])
-def test_cross_attention_fused_branch(rec_cls, n, p, wt, wi, ln, fus):
-    """pv_cross_attention_fused (norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual in ONE launch, C = 320 / d = 40)
-    vs an fp32 torch reference on the same fp16-rounded operands, and vs the four-launch path it replaces."""
+@pytest.mark.parametrize("d,n,p,wt,wi,ln,fus", [(40, 4096, 1, 1.0, 1.0, True, False), (40, 128, 5, 1.0, 1.0, True, False),
+                                               (40, 256, 6, 2.0, 0.0, False, False), (40, 128, 16, 0.0, 2.0, True, True),
+                                               (80, 1024, 1, 1.0, 1.0, True, False), (80, 128, 5, 1.0, 1.0, True, False),
+                                               (80, 256, 6, 2.0, 0.0, False, False), (80, 128, 16, 0.0, 2.0, True, True)])
+def test_cross_attention_fused_branch(rec_cls, d, n, p, wt, wi, ln, fus):
+    """pv_cross_attention_fused (norm2 -> to_q -> dual-branch SDPA -> to_out + bias + residual in ONE launch; the C = 320 / d = 40 and
+    C = 640 / d = 80 instantiations) vs an fp32 torch reference on the same fp16-rounded operands, and vs the four-launch path it replaces."""
     from photoverse_amd import ops
-    B, H, d, NT = 2, 8, 40, 77
+    B, H, NT = 2, 8, 77
     C = H * d
     hs = h16(B * n, C, seed=40)
     hs[:, ::7] += 1.5                                   # non-zero row means: LayerNorm has something to remove

@@ -307,6 +307,7 @@ def test_bench_contract_line():
     assert d["ms_per_step_ranks"]["n"] == 1 and d["ms_per_step_ranks"]["max"] == pytest.approx(d["ms_per_step"], rel=1e-3)
     xa = d["xattn_fused"]
     assert set(xa["levels"]) == {"320", "640", "1280"} and xa["levels"]["320"]["fused"] and xa["levels"]["320"]["launches_per_layer"] == 1
+    assert xa["levels"]["640"]["fused"] and xa["levels"]["640"]["launches_per_layer"] == 1 and not xa["levels"]["1280"]["fused"]
     assert xa["all_layers"]["layers_per_step"] == 32 and 0.02 < xa["all_layers"]["frac"] < 1.0 and xa["north_star_target_frac"] == 0.40
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
                          "--no-train-forward"], capture_output=True, text=True, timeout=600, cwd=root)

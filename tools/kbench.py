@@ -79,11 +79,11 @@ def xattn(name, d, n, p=1):
     cases.append((name, f))
 
 
-def xfused(name, n, p=1, fused=True):
-    """attn2 branch at C = 320: the fused launch, or the four launches it replaces (LayerNorm, to_q, dual SDPA, to_out + residual)."""
+def xfused(name, n, p=1, fused=True, d=40):
+    """attn2 branch at C = 320 / 640: the fused launch, or the four launches it replaces (LayerNorm, to_q, dual SDPA, to_out + residual)."""
     def f():
         rec = Recorder(dev)
-        C, d = 320, 40
+        C = 8 * d
         hs, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
         wq, wo, bo = h16(C, C, scale=0.05), h16(C, C, scale=0.05), torch.zeros(C, device=dev)
         g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
@@ -268,6 +268,9 @@ xattn("xattn d80 n1024", 80, 1024)
 xfused("attn2 branch C320 n4096 FUSED", 4096)
 xfused("attn2 branch C320 n4096 4 launches", 4096, fused=False)
 xfused("attn2 branch C320 n4096 P5 FUSED", 4096, p=5)
+xfused("attn2 branch C640 n1024 FUSED", 1024, d=80)
+xfused("attn2 branch C640 n1024 4 launches", 1024, fused=False, d=80)
+xfused("attn2 branch C640 n1024 P5 FUSED", 1024, p=5, d=80)
 conv_out("conv_out 320->4 @64", 320, 4, 64)
 conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)
