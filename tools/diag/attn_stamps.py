@@ -10,7 +10,7 @@ import photoverse_amd.build as b  # noqa: E402
 ABL = os.environ.get("XA_ABLATE", "")
 s = open(os.path.join(b.CSRC, "pv_attn.hip")).read()
 s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long at_stamps[16];\n'
-              '#define STAMP(i) do { if (D == 40 && blockIdx.x == 1000 && threadIdx.x == 0 && t == 20) at_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
+              '#define STAMP(i) do { if (D == 40 && blockIdx.x == 1000 && threadIdx.x == 0 && (t == 20 || t == 21)) at_stamps[i + 8 * (t - 20)] = __builtin_amdgcn_s_memtime(); } while (0)'
               % os.path.join(b.CSRC, "pv_common.h"))
 rep = [("            if ((t & 1) == 0) {\n                // ONE barrier per PAIR of tiles", "            STAMP(0);\n            if ((t & 1) == 0) {\n                // ONE barrier per PAIR of tiles"),
        ("            const bool need_mask = p.causal || (t + 1) * KB > p.nk;\n            tile(t, t & 3, need_mask, t == 0);\n", "            STAMP(1);\n            const bool need_mask = p.causal || (t + 1) * KB > p.nk;\n            tile(t, t & 3, need_mask, t == 0);\n            STAMP(5);\n"),
@@ -20,6 +20,10 @@ rep = [("            if ((t & 1) == 0) {\n                // ONE barrier per PAI
 for a, c in rep:
     assert a in s, a[:60]
     s = s.replace(a, c, 1)
+if ABL == "nobar":      # timing only (wrong results): the DMA ring without its workgroup barrier
+    a = '                __builtin_amdgcn_s_barrier();\n                asm volatile("" ::: "memory");\n                if (t + 2 < ntiles) issue_tile(t + 2);'
+    assert a in s
+    s = s.replace(a, a.replace("__builtin_amdgcn_s_barrier();", ""), 1)
 s += '\nextern "C" int pv_at_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(at_stamps), 16 * 8); }\n'
 src, lib = "/tmp/pv_attn_stamps.hip", "/tmp/libpv_diag_attn.so"
 open(src, "w").write(s)
@@ -52,10 +56,11 @@ out = (ctypes.c_ulonglong * 16)()
 fn = rec.lib.pv_at_stamps
 fn.restype = ctypes.c_int
 assert fn(out) == 0
-t = list(out)[:6]
-t = [t[0], t[1], t[1], t[3], t[4], t[5]]
 names = ["wait + barrier + DMA issue (even tile)", "-", "QK^T (32 MFMA + reads)", "softmax (VALU)", "P.V (24 MFMA + tr reads)"]
-print(f"ablate={ABL or '-'}  launch {e0.elapsed_time(e1) / 5 * 1e3:.1f} us;  tile 20 of workgroup 2000, wave 0:")
-for i in range(5):
-    print(f"  {names[i]:34s} {t[i + 1] - t[i]:6d} cycles")
-print(f"  {'tile total':34s} {t[5] - t[0]:6d} cycles")
+print(f"ablate={ABL or '-'}  launch {e0.elapsed_time(e1) / 5 * 1e3:.1f} us;  tiles 20 / 21 of workgroup 1000, wave 0:")
+for k in range(2):
+    t = list(out)[8 * k:8 * k + 6]
+    t = [t[0], t[1], t[1], t[3], t[4], t[5]]
+    for i in range(5):
+        print(f"  tile {20 + k}: {names[i]:34s} {t[i + 1] - t[i]:6d} cycles")
+    print(f"  tile {20 + k}: {'total':34s} {t[5] - t[0]:6d} cycles")
