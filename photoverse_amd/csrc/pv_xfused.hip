@@ -168,6 +168,22 @@ __device__ __forceinline__ void xf_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef PV_XF_S640
+#define PV_XF_S640 8
+#endif
+constexpr int xf_ring_slots(int C, int NQ) { return C == 640 && NQ == 1 ? PV_XF_S640 : 4; }
+
+// wave-uniform count -> immediate
+__device__ __forceinline__ void xf_wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define XF_W(N) case N: xf_wait_vmcnt<N>(); break;
+        XF_W(0) XF_W(1) XF_W(2) XF_W(3) XF_W(4) XF_W(5) XF_W(6) XF_W(7) XF_W(8) XF_W(9) XF_W(10) XF_W(11) XF_W(12) XF_W(13) XF_W(14) XF_W(15) XF_W(16)
+        XF_W(17) XF_W(18) XF_W(19) XF_W(20) XF_W(21) XF_W(22) XF_W(23) XF_W(24) XF_W(25) XF_W(26) XF_W(27) XF_W(28) XF_W(29) XF_W(30) XF_W(31) XF_W(32)
+#undef XF_W
+        default: xf_wait_vmcnt<0>(); break;     // a smaller count only waits longer
+    }
+}
+
 struct pv_xfused_params_dev : pv_xattn_fused_params {
     uint32_t w_bytes, kimg_bytes, vimg_bytes;
 };
@@ -189,7 +205,11 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
     constexpr int KK = C / 32;        // 32-deep contraction steps over C: 10
     constexpr int KT = C / 64;        // 64-deep ring stages per 80-row weight chunk: 5
     constexpr int NT = NG * KT;       // ring stages per GEMM phase: 20
-    constexpr int S = 4;              // ring slots: two stages being read + two in flight (one workgroup barrier per PAIR of stages)
+    // ring slots: two stages being read + 2 LEAD in flight (one workgroup barrier per PAIR of stages).  The 64-row form has ONE workgroup per CU
+    // (256 workgroups) and all of the CU's LDS: a deeper ring keeps three pairs of stages in flight instead of one - with one pair the weight
+    // stream of a lone workgroup is bound by the L2 round trip, not by its MFMAs
+    constexpr int S = xf_ring_slots(C, NQ);
+    constexpr int LEAD = S / 2 - 1;   // pairs of stages in flight behind the pair being read
     constexpr int TILE_BYTES = GF * 128;                   // one stage: 80 weight rows x 64 k = 10 KiB
     constexpr int KIMG_BYTES = XK * KROW;                  // one head
     constexpr int VIMG_BYTES = XK * GF * 2;
@@ -255,21 +275,7 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
     // vmcnt bookkeeping in units of "this wave's pieces": ring stage = 3 (waves 0,1) or 2; K/V group = 10 (waves 0-2) or 9
     auto wait_except = [&](int stages, int groups) {       // wait for everything but the youngest `stages` ring stages + `groups` K/V groups
         const int n = stages * (wave < 2 ? 3 : 2) + groups * (wave < 3 ? 10 : 9);
-        switch (n) {   // wave-uniform; the counts that occur
-            case 0: xf_wait_vmcnt<0>(); break;
-            case 2: xf_wait_vmcnt<2>(); break;
-            case 3: xf_wait_vmcnt<3>(); break;
-            case 4: xf_wait_vmcnt<4>(); break;
-            case 6: xf_wait_vmcnt<6>(); break;
-            case 12: xf_wait_vmcnt<12>(); break;
-            case 9: xf_wait_vmcnt<9>(); break;
-            case 10: xf_wait_vmcnt<10>(); break;
-            case 13: xf_wait_vmcnt<13>(); break;   // 2 stages (waves 2,3: 4) + group (wave 3: 9)
-            case 14: xf_wait_vmcnt<14>(); break;   // waves 2: 4 + 10
-            case 15: xf_wait_vmcnt<15>(); break;   // 2 stages x 3 (waves 0,1) + ... not reached; kept for safety
-            case 16: xf_wait_vmcnt<16>(); break;   // waves 0,1: 6 + 10
-            default: xf_wait_vmcnt<0>(); break;
-        }
+        xf_wait_vmcnt_dyn(n);
     };
     auto wg_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads are retired
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
         for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rh, off, kk * 64, 0));
     }
     issue_group(0, buf1);                 // K/V of group 0 waits in buffer 1 while the Wq ring runs in buffer 0
-    issue_stage(rq, buf0, 0);
-    issue_stage(rq, buf0, 1);
+#pragma unroll
+    for (int t = 0; t < 2 * LEAD; ++t) issue_stage(rq, buf0, t);
     if (p.ln) {
         // LayerNorm WITHOUT its affine part (the caller folds gamma into the columns of wq and beta into q_bias):
         // x^ = x * rstd - mean * rstd, one mixed-precision FMA per element (fp16 in, fp32 math, fp16 out).  Statistics: the row sum
@@ -352,10 +358,10 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             if ((t & 1) == 0) {
                 // ONE barrier per pair of stages: stages t and t+1 were issued two stages ago right behind that barrier and nothing younger
                 // is in flight, so "landed" is vmcnt(0); behind the barrier the slots of stages t-2 / t-1 are read out by every wave
-                if (t >= 2) wait_except(0, 0);
+                if (t >= 2) wait_except(min(2 * (LEAD - 1), max(NT - (t + 2), 0)), 0);     // stages t, t+1 landed; younger pairs may be in flight
                 wg_barrier();
-                if (t + 2 < NT) issue_stage(rq, buf0, t + 2);
-                if (t + 3 < NT) issue_stage(rq, buf0, t + 3);
+                if (t + 2 * LEAD < NT) issue_stage(rq, buf0, t + 2 * LEAD);
+                if (t + 2 * LEAD + 1 < NT) issue_stage(rq, buf0, t + 2 * LEAD + 1);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
         // group grp landed; in flight behind it: group grp+1 (grp < 3); at grp == 3 additionally the three Wo stages issued after group 2
         if (grp == 0) wait_except(0, 1);
         else if (grp < NG - 1) { wait_except(0, 1); }
-        else wait_except(2, 0);
+        else wait_except(2 * LEAD, 0);
         wg_barrier();
         const char* sbuf = ((grp + 1) & 1) ? buf1 : buf0;
         const half_t* sV = reinterpret_cast<const half_t*>(sbuf + 2 * KIMG_BYTES);
@@ -604,8 +610,8 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             issue_group(grp + 2, ((grp + 1) & 1) ? buf1 : buf0);
         } else if (grp == NG - 2) {
             wg_barrier();                  // buffer 1 (group 2) is free: the Wo ring starts there while group 3 computes out of buffer 0
-            issue_stage(ro, buf1, 0);
-            issue_stage(ro, buf1, 1);
+#pragma unroll
+            for (int t = 0; t < 2 * LEAD; ++t) issue_stage(ro, buf1, t);
         }
     }
 
@@ -628,22 +634,21 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
                 // started there (the bias loads are not counted: a smaller count only waits longer).  Counting them exactly keeps the HBM
                 // write latency of a chunk's stores out of the next stages' critical path.
                 constexpr int RES = 3 * NQ, STO = 3 * NQ;
+                // vmcnt retires in order: everything this wave issued AFTER the DMA of stages t, t+1 may stay in flight - the younger ring stages
+                // and the residual loads / output stores of the chunks that started / ended in the last 2 LEAD stages
                 int younger = 0;
-                if (t >= 2) {
-                    if ((t - 2) % KT == 0) younger += RES;
-                    if ((t - 2) % KT == KT - 1) younger += STO;
-                    if ((t - 1) % KT == 0) younger += RES;
-                    if ((t - 1) % KT == KT - 1) younger += STO;
+#pragma unroll
+                for (int j = t - 2 * LEAD; j < t; ++j) {
+                    if (j < 0) continue;
+                    if (j % KT == 0) younger += RES;
+                    if (j % KT == KT - 1) younger += STO;
                 }
-                switch (younger) {
-                    case 3: xf_wait_vmcnt<3>(); break;
-                    case 6: xf_wait_vmcnt<6>(); break;
-                    case 12: xf_wait_vmcnt<12>(); break;
-                    default: xf_wait_vmcnt<0>(); break;
-                }
+                younger += (t >= 2 ? min(2 * (LEAD - 1), max(NT - (t + 2), 0)) : 2 * LEAD - 2) * (wave < 2 ? 3 : 2);
+                if (t >= 2) xf_wait_vmcnt_dyn(younger);
+                else xf_wait_vmcnt<0>();
                 wg_barrier();
-                if (t + 2 < NT) issue_stage(ro, buf1, t + 2);
-                if (t + 3 < NT) issue_stage(ro, buf1, t + 3);
+                if (t + 2 * LEAD < NT) issue_stage(ro, buf1, t + 2 * LEAD);
+                if (t + 2 * LEAD + 1 < NT) issue_stage(ro, buf1, t + 2 * LEAD + 1);
             }
             if (kt == 0) {
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
@@ -741,7 +746,6 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     if (kb >= (1ull << 31) || vb >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
-    constexpr int SMEM = 2 * 4 * GF * 128;   // two 40-KiB buffers (4-slot weight ring / one 39-KiB K/V group each): two workgroups per CU
     // rows per workgroup: 128 (a wave owns two 16-row tiles: every weight fragment read from LDS feeds two MFMAs) or 64.  The C = 640 levels
     // have 16 x 1024 rows = 128 workgroups of 128 - half of the 256 CUs; 64-row workgroups fill the chip (PV_XF_ROWS=64/128 overrides).
     static const int rows_env = [] { const char* e = getenv("PV_XF_ROWS"); return e ? atoi(e) : 0; }();
@@ -757,6 +761,8 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     auto kern = variant == 0 ? (ip1 ? xattn_fused_kernel<320, true, 2> : xattn_fused_kernel<320, false, 2>)
               : variant == 1 ? (ip1 ? xattn_fused_kernel<640, true, 2> : xattn_fused_kernel<640, false, 2>)
                              : (ip1 ? xattn_fused_kernel<640, true, 1> : xattn_fused_kernel<640, false, 1>);
+    // two buffers of one weight ring (or one 39-KiB K/V group) each: 2 x 40 KiB = two workgroups per CU; the 64-row form 2 x 80 KiB = the whole CU
+    const int SMEM = 2 * xf_ring_slots(C, rows == 64 ? 1 : 2) * GF * 128;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;

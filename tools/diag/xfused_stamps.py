@@ -21,9 +21,9 @@ def stamped_source():
     if "nobar" in ABL:      # no workgroup barriers at all
         s = s.replace("        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n    };", "        asm volatile(\"\" ::: \"memory\");\n    };")
     s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long xf_stamps[16];\n'
-                  '#define STAMP(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) xf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
+                  '#define STAMP(i) do { if (blockIdx.x == 100 && threadIdx.x == 0) xf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
                   % os.path.join(b.CSRC, "pv_common.h"))
-    marks = ["    half8_t xf[KK][2];\n    int mrow[2];", "    issue_group(0, buf1);", "    // The register loads above made the compiler wait;",
+    marks = ["    half8_t xf[KK][NQ];\n    int mrow[NQ];", "    issue_group(0, buf1);", "    // The register loads above made the compiler wait;",
              "    // ---- phase 1: Q^T = Wq", "    // ---- phase 2: dual-branch attention, one", "    // ---- phase 3: out^T = Wo'"]
     for i, m in enumerate(marks):
         assert m in s, m
@@ -50,7 +50,8 @@ _lib.LIB = lib
 from photoverse_amd.ops import Recorder  # noqa: E402
 
 dev = torch.device("cuda")
-B, n, C, d, p = 16, 4096, 320, 40, 1
+C = int(os.environ.get("XF_C", "320"))          # 320 (n = 4096) or 640 (n = 1024)
+B, n, d, p = 16, 4096 * 320 * 320 // (C * C), C // 8, 1
 h16 = lambda *s, scale=1.0: (torch.randn(*s, device=dev) * scale).half()
 hs, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
 wq, wo, bo = h16(C, C, scale=0.05), h16(C, C, scale=0.05), torch.zeros(C, device=dev)
@@ -69,4 +70,4 @@ names = ["", "issue X loads", "issue DMA + LayerNorm (waits for X)", "drain", "p
 t = list(out)[:7]
 for i in range(1, 7):
     print(f"{names[i]:40s} {t[i] - t[i - 1]:8d} shader cycles")
-print(f"{'total (wave 0 of workgroup 300)':40s} {t[6] - t[0]:8d} shader cycles (s_memtime)")
+print(f"{'total (wave 0 of workgroup 100)':40s} {t[6] - t[0]:8d} shader cycles (s_memtime)")

@@ -10,3 +10,4 @@ python3 bench.py > gpurun_out/round/bench_default.json 2> gpurun_out/round/bench
 tail -3 gpurun_out/prof_bench_stdout.txt; tail -1 gpurun_out/round/bench_default.json | cut -c1-400
 python3 tools/pmc.py "attn2 branch C320 n4096 FUSED" xattn_fused > gpurun_out/round/pmc_xfused.txt 2>&1
 python3 tools/kbench.py > gpurun_out/round/kbench.txt 2>&1
+python3 tools/pmc.py "attn2 branch C640 n1024 FUSED" xattn_fused > gpurun_out/round/pmc_xfused640.txt 2>&1
