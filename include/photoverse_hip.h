@@ -247,7 +247,7 @@ typedef struct pv_xattn_params {
 int pv_cross_attention(const pv_xattn_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * The whole attn2 branch of a BasicTransformerBlock as ONE launch (C = heads*d = 320, d = 40):
+ * The whole attn2 branch of a BasicTransformerBlock as ONE launch (heads = 8; C = heads*d = 320 / d = 40 or C = 640 / d = 80):
  *   out = hs + to_out( w_text*softmax(q Kt^T/sqrt(d)) Vt + w_ip*softmax(q Kip^T/sqrt(d)) Vip ) + bias_o,
  *   q = to_q(LayerNorm(hs))
  * = BasicTransformerBlock.norm2 [EXT diffusers] -> PhotoVerseAttnProcessor2_0.__call__
@@ -256,7 +256,7 @@ int pv_cross_attention(const pv_xattn_params* p, void* stream);
  * pv_cross_attention + pv_gemm_conv.  nq % 128 == 0, 64 < nt <= 80, nip <= 16.
  *
  * pv_xattn_pack_kv (once per conditioning) turns the projected text / image-token K,V rows into
- * the kernel's K / V images (kimg: batch*heads*96*64 halfs, vimg: batch*(C/80)*96*80 halfs) and
+ * the kernel's K / V images (kimg: batch*heads*96*64 halfs at d = 40, *128 at d = 80; vimg: batch*(C/80)*96*80 halfs) and
  * emits to_v_ip_norm (:397).  wo is to_out[0].weight with its COLUMNS reordered: column slot s of
  * the packed matrix holds natural column pv_xattn_fused_wo_slot(s).
  */

@@ -219,6 +219,10 @@ def save_samples(args, global_step, batch, tokenizer, image_encoder, text_encode
     n = min(args.num_of_samples_to_save, batch["pixel_values"].shape[0])
     unet.repack()                                           # the inference engines bake fp16 copies of the weights: rebuild from the trained ones
     example = {k: (v[:n] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    if args.use_random_prompts:                             # the grid is generated from the plain prompt, not the batch's random templates (train.py:558-560)
+        pe = prompt_example(tokenizer, "a photo of {}", "*")
+        example["text_input_ids"] = pe["text_input_ids"].unsqueeze(0).expand(n, -1).contiguous().to(example["text_input_ids"].device)
+        example["concept_placeholder_idx"] = pe["concept_placeholder_idx"].unsqueeze(0).expand(n, -1).contiguous().to(example["concept_placeholder_idx"].device)
     with torch.no_grad():
         gen = run_inference(example, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae, noise_scheduler, device,
                             args.image_encoder_layers_idx, latent_size=args.resolution // 8, guidance_scale=args.guidance_scale,
