@@ -29,7 +29,6 @@ constexpr int RG_SMEM = RG_SLOTS * RG_TILE;      // 80 KiB -> two workgroups per
 
 struct pv_rowgemm_params_dev : pv_row_gemm_params {
     uint32_t w_bytes;
-    int32_t skew;          // s_sleep units (64 cycles) the workgroup in the ODD wave slot of its SIMDs waits before it starts
 };
 
 template <int N>
@@ -79,20 +78,6 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-
-    // Two workgroups share a CU (two waves per SIMD) and run the same program: started together they reach their MFMA phases together and
-    // their VALU-heavy chunk epilogues (GEGLU: ~20 VALU ops per output) together, and neither overlaps.  The workgroup sitting in the odd
-    // wave slot of its SIMDs starts half a chunk period late, so one workgroup's epilogue runs beside the other's MFMAs.
-    if (p.skew > 0) {
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_REG_HW_ID[3:0] = wave slot on the SIMD
-        int* flag = reinterpret_cast<int*>(smem);
-        if (threadIdx.x == 0) *flag = (int)(slot & 1u);
-        __syncthreads();
-        const int late = *flag;                                               // every wave of the workgroup takes wave 0's decision
-        __syncthreads();
-        if (late)
-            for (int i = 0; i < p.skew; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
 
     // ---- rows into registers (the MFMA-B layout: lane = row, 8 consecutive channels per k-group) ---------------------------------------
     half8_t xf[KK][2];
@@ -233,11 +218,6 @@ extern "C" int pv_row_gemm(const pv_row_gemm_params* pp, void* stream) {
         return (int)hipErrorInvalidValue;
     if ((size_t)p.N * RG_K * 2 >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.w_bytes = (uint32_t)p.N * RG_K * 2;
-    {
-        static int skew_env = -2;
-        if (skew_env == -2) { const char* e = getenv("PV_RG_SKEW"); skew_env = e ? atoi(e) : -1; }
-        p.skew = skew_env >= 0 ? skew_env : (p.geglu ? 128 : 0);
-    }
     static bool attr_set_dev[64][2] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
