@@ -40,7 +40,8 @@ def conv(name, cin, cout, hw, c1=0, stride=1, ups=0):
         x1 = h16(B * hw * hw, c1) if c1 else None
         w = h16(cout, 9 * (cin + c1), scale=0.02)
         ho = hw * 2 if ups else hw // stride
-        rec.gemm(x, w, a1=x1, bias=torch.zeros(cout, device=dev), conv=dict(batch=B, hin=hw, win=hw, hout=ho, wout=ho, stride=stride, upsample=ups))
+        rec.gemm(x, w, a1=x1, bias=torch.zeros(cout, device=dev), conv=dict(batch=B, hin=hw, win=hw, hout=ho, wout=ho, stride=stride, upsample=ups),
+                 colstats=bool(os.environ.get("PV_KBENCH_COLSTATS")))     # the instantiation whose epilogue leaves GroupNorm statistics behind
         return rec, 2.0 * B * ho * ho * cout * 9 * (cin + c1), 0
     cases.append((name, f))
 
