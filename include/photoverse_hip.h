@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 9
+#define PV_ABI_VERSION 10
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -358,7 +358,9 @@ int pv_reduce_sumsq(const float* a, int64_t n, float scale, float* partial, int3
  * Overflow guard (fp16 gradients under a static loss scale): when any group norm is not finite, pv_clip_coef_groups writes -1 into every
  * out[2g] and adds 1 to counters[1]; otherwise it adds 1 to counters[0] (applied steps).  pv_adamw_multi skips tensors whose gscale is
  * negative and, given counters, takes its bias-correction step from counters[0] instead of `step` - the behaviour of torch's GradScaler,
- * without a host synchronisation.  counters may be NULL (no guard bookkeeping; `step` is used). */
+ * without a host synchronisation.  counters may be NULL (no guard bookkeeping; `step` is used).  `out` holds groups + 1 rows of two floats: the
+ * extra row [groups] = {base, 0}, or {-1, 0} on overflow, is the gscale of tensors in NO clip group (skipped with the rest); with counters[0] == 0
+ * (nothing applied yet) pv_adamw_multi leaves everything untouched (ABI 10). */
 int pv_sumsq_multi(const int64_t* entries, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t n_blocks, int32_t chunk, float* partial, void* stream);
 int pv_clip_coef_groups(const float* partial, const int32_t* group_start, int32_t groups, float max_norm, float base, float* out, int32_t* counters,
                         void* stream);

@@ -172,3 +172,153 @@ def reference_arcface():
             return ns["ArcFaceResNet18"](pretrained=False)
 
     return ns["ArcFaceResNet18"], FaceLossNoDownload
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# models/infer.py:7-123 and models/modeling_utils.py:13-95: the orchestration code of the hot path (pure Python over duck-typed objects)
+# ---------------------------------------------------------------------------------------------------------------------------------
+STAND_INS.update({
+    "infer.DPMSolverMultistepScheduler": "[EXT] diffusers sampler (infer.py:1,39-40): bound to SchedulerStandIn, a thin adapter over "
+                                         "oracle.scheduler_ref.DPMSolverMultistepRef exposing exactly what run_inference touches (from_config, "
+                                         "set_timesteps, timesteps, init_noise_sigma, scale_model_input, step(...).prev_sample, add_noise); the "
+                                         "adapter holds no arithmetic of its own and logs every call so the fixture can assert the call sequence",
+    "infer.tqdm": "the installed tqdm package itself (4.67) - not a stand-in",
+    "infer arguments": "unet / vae / image_encoder / text_encoder are the oracle's tiny [EXT] restatements with the REFERENCE processor class "
+                       "installed by the REFERENCE set_visual_cross_attention_adapter; adapters are the real models.adapters.PhotoVerseAdapter; "
+                       "tokenizer is a recording stub returning fixed ids (the real CLIPTokenizer has no vocabulary offline)",
+    "modeling_utils.LoraConfig": "[EXT] peft.LoraConfig (modeling_utils.py:2,17,46): bound to LoraConfigStandIn, a dataclass with the fields "
+                                 "train.py:348-354 sets and peft's to_dict(); carries no arithmetic",
+    "modeling_utils.inject_adapter_in_model": "[EXT] peft (modeling_utils.py:18,88): bound to oracle.lora_ref.inject_adapter_in_model_ref (independent "
+                                              "restatement of peft's published wrapper layout: base_layer / lora_A.default / lora_B.default)",
+    "modeling_utils.accelerator": "save_progress only calls accelerator.unwrap_model(m) (:30-33): the fixture passes an object whose unwrap_model "
+                                  "strips a DDP-like `.module` wrapper, which is what accelerate's does",
+    "modeling_utils.*.from_pretrained": "load_models (:55-60) downloads six [EXT] models; each class is bound to a recording factory whose "
+                                        "from_pretrained(path, subfolder=) returns the oracle's tiny restatement of that model; PhotoVerseAdapter is the real "
+                                        "class, set_visual_cross_attention_adapter the reference's own function, patch_clip_text_transformer an identity "
+                                        "that records the call (the by-class-name patch of clip.py:115-119 targets a transformers-4.40 class)",
+})
+
+
+class SchedulerStandIn:
+    """Plays ``diffusers.DPMSolverMultistepScheduler`` for ``models/infer.py``; every method forwards to ``DPMSolverMultistepRef``."""
+    log: list = []                       # class-level call log, cleared by the fixture generator before each reference call
+
+    def __init__(self, config):
+        from oracle.scheduler_ref import DPMSolverMultistepRef
+        cfg = config if isinstance(config, dict) else dict(getattr(config, "__dict__", {}))
+        self._ref = DPMSolverMultistepRef(cfg.get("num_train_timesteps", 1000), cfg.get("beta_start", 0.00085), cfg.get("beta_end", 0.012),
+                                          cfg.get("steps_offset", 1))
+        self.config = config
+
+    @classmethod
+    def from_config(cls, config):
+        cls.log.append(("from_config",))
+        return cls(config)
+
+    def set_timesteps(self, n):
+        type(self).log.append(("set_timesteps", int(n)))
+        self._ref.set_timesteps(n)
+
+    @property
+    def timesteps(self):
+        return self._ref.timesteps
+
+    @property
+    def init_noise_sigma(self):
+        return self._ref.init_noise_sigma
+
+    def scale_model_input(self, sample, t):
+        type(self).log.append(("scale_model_input", int(t)))
+        return self._ref.scale_model_input(sample, t)
+
+    def step(self, model_output, t, sample):
+        from types import SimpleNamespace
+        type(self).log.append(("step", int(t)))
+        return SimpleNamespace(prev_sample=self._ref.step(model_output, t, sample))
+
+    def add_noise(self, original_samples, noise, timesteps):
+        type(self).log.append(("add_noise", [int(v) for v in timesteps]))
+        return self._ref.add_noise(original_samples, noise, timesteps)
+
+
+def reference_run_inference():
+    """``run_inference`` exactly as ``models/infer.py:7-123`` defines it (module-level names bound per STAND_INS)."""
+    import torch
+    from tqdm import tqdm
+    ns = {"torch": torch, "tqdm": tqdm, "DPMSolverMultistepScheduler": SchedulerStandIn}
+    load_reference_defs("models/infer.py", ["run_inference"], ns)
+    return ns["run_inference"]
+
+
+def LoraConfigStandIn(**kw):
+    """peft.LoraConfig stand-in: the fields the reference sets (train.py:348-354) + ``to_dict`` (modeling_utils.py:46)."""
+    from dataclasses import asdict, dataclass, field
+    from typing import List as _List
+
+    @dataclass
+    class LoraConfig:
+        r: int = 8
+        lora_alpha: int = 8
+        target_modules: _List[str] = field(default_factory=lambda: ["attn2.to_q", "attn2.to_k", "attn2.to_v"])
+        lora_dropout: float = 0.0
+        init_lora_weights: str = "gaussian"
+        bias: str = "none"                      # train.py:352 passes bias="none"
+
+        def to_dict(self):
+            return asdict(self)
+
+    return LoraConfig(**kw)
+
+
+def _inject_stand_in(lora_config, model):
+    from oracle.lora_ref import inject_adapter_in_model_ref
+    return inject_adapter_in_model_ref(model, lora_config.r, lora_config.lora_alpha, lora_config.target_modules, lora_config.lora_dropout)
+
+
+class AcceleratorStandIn:
+    @staticmethod
+    def unwrap_model(m):
+        return getattr(m, "module", m) if type(m).__name__ == "DDPLike" else m
+
+
+def reference_checkpoint_functions():
+    """``load_photoverse_model`` / ``save_progress`` exactly as ``models/modeling_utils.py:13-50`` defines them."""
+    import torch
+    ns = {"torch": torch, "os": os, "LoraConfig": LoraConfigStandIn, "inject_adapter_in_model": _inject_stand_in}
+    load_reference_defs("models/modeling_utils.py", ["load_photoverse_model", "save_progress"], ns)
+    return ns["load_photoverse_model"], ns["save_progress"]
+
+
+def reference_load_models(factories: Dict[str, object], call_log: list):
+    """``load_models`` (``models/modeling_utils.py:53-95``) with the six ``from_pretrained`` classes bound to recording factories.
+    ``factories``: class name -> zero-argument callable building the oracle's tiny restatement of that model."""
+    import sys
+
+    import torch
+    sys.path.insert(0, REF_ROOT)
+    try:
+        from models.adapters import PhotoVerseAdapter          # the real class (imports without diffusers)
+    finally:
+        sys.path.pop(0)
+    set_adapter, _ = reference_unet_helpers()
+
+    def recording(name):
+        class _Factory:
+            @staticmethod
+            def from_pretrained(path, subfolder=None):
+                call_log.append((name, path, subfolder))
+                return factories[name]()
+        _Factory.__name__ = name
+        return _Factory
+
+    def patch_identity(text_encoder):
+        call_log.append(("patch_clip_text_transformer", type(text_encoder).__name__, None))
+        return text_encoder
+
+    ns = {"torch": torch, "os": os, "LoraConfig": LoraConfigStandIn, "inject_adapter_in_model": _inject_stand_in,
+          "PhotoVerseAdapter": PhotoVerseAdapter, "patch_clip_text_transformer": patch_identity,
+          "set_visual_cross_attention_adapter": set_adapter}
+    for name in ("CLIPTokenizer", "CLIPTextModel", "AutoencoderKL", "UNet2DConditionModel", "CLIPVisionModel", "DDPMScheduler"):
+        ns[name] = recording(name)
+    load_reference_defs("models/modeling_utils.py", ["load_photoverse_model", "save_progress", "load_models"], ns)
+    return ns["load_models"]

@@ -77,6 +77,18 @@ class DPMSolverMultistepRef:
         self.step_index += 1
         return prev
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """``infer.py:65`` / ``train.py:484``.  [EXT] diffusers 0.27.2 ``DPMSolverMultistepScheduler.add_noise``: the sigma of each
+        timestep's position in the CURRENT schedule (``index_for_timestep``: the first match of a unique schedule), then
+        ``alpha_t * x0 + sigma_t * noise`` with ``alpha_t = 1 / sqrt(sigma^2 + 1)``, ``sigma_t = sigma * alpha_t``."""
+        sched = self.timesteps.tolist()
+        idx = [sched.index(int(t)) for t in timesteps]
+        sigma = torch.from_numpy(self.sigmas[idx]).to(original_samples.dtype)
+        alpha_t = 1.0 / torch.sqrt(sigma * sigma + 1.0)
+        sigma_t = sigma * alpha_t
+        shape = (-1, *([1] * (original_samples.dim() - 1)))
+        return alpha_t.view(shape) * original_samples + sigma_t.view(shape) * noise
+
 
 class DDIMRef:
     """Stepwise DDIM (eta = 0, epsilon prediction, "leading" spacing, steps_offset 1, set_alpha_to_one False) - the sampler

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const MtEntry* e, cons
 // OVERFLOW GUARD (gradients are fp16 with a static loss scale; the fp32 reference cannot overflow there): if ANY group's norm is not finite
 // the whole optimizer step is skipped, as torch's GradScaler does - every coefficient becomes -1 (pv_adamw_multi leaves parameters, moments
 // and the bias-correction step untouched) and counters[1] counts the skipped step; otherwise counters[0], the number of APPLIED steps, advances.
+// out has groups + 1 rows: row [groups] = {base, 0} (or {-1, 0} on overflow) is the scale of tensors that belong to NO clip group, so that they
+// are skipped together with the grouped ones.
 __global__ __launch_bounds__(256) void clip_coef_groups_kernel(const float* partial, const int* start, int groups, float max_norm, float base, float* out, int* counters) {
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
@@ -248,7 +250,11 @@ __global__ __launch_bounds__(256) void clip_coef_groups_kernel(const float* part
     __syncthreads();
     if (bad)
         for (int g = threadIdx.x; g < groups; g += 256) out[2 * g] = -1.f;
-    if (threadIdx.x == 0 && counters) counters[bad ? 1 : 0] += 1;
+    if (threadIdx.x == 0) {
+        out[2 * groups] = bad ? -1.f : base;
+        out[2 * groups + 1] = 0.f;
+        if (counters) counters[bad ? 1 : 0] += 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const MtEntry* e, const int* blk_tensor, const int* blk_chunk, int chunk, float lr, float b1, float b2,
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const MtEntry* e, cons
     const float gs = t.gs ? t.gs[0] : 1.f;
     if (gs < 0.f) return;                                // overflow in this step's gradients: skipped (clip_coef_groups_kernel)
     const int tstep = counters ? counters[0] : step;     // bias correction counts APPLIED steps
+    if (tstep <= 0) return;                              // no applied step yet (1 - b1^0 = 0 would divide by zero)
     const float bc1 = 1.f - powf(b1, (float)tstep), bc2_sqrt = sqrtf(1.f - powf(b2, (float)tstep));
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
         const float gi = t.g[i] * gs;

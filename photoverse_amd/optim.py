@@ -6,8 +6,9 @@ are computed ON THE DEVICE (``pv_sumsq_multi`` -> ``pv_clip_coef_groups`` -> rea
 ~220 parameter tensors, fixed summation order), so a step needs no host synchronisation.  State (exp_avg, exp_avg_sq) is fp32; parameters must be fp32 CUDA tensors.
 
 Overflow guard: the training plans carry fp16 gradients under a static loss scale; the fp32 reference cannot overflow there.  When a
-clip group's gradient norm is not finite the WHOLE step is skipped on the device (parameters, moments and the bias-correction step stay
-untouched), as ``torch.cuda.amp.GradScaler`` does; ``skipped_steps`` / ``applied_steps`` read the device counters.
+clip group's gradient norm is not finite the WHOLE step is skipped on the device (parameters - grouped or not -, moments and the
+bias-correction step stay untouched), as ``torch.cuda.amp.GradScaler`` does; ``skipped_steps`` / ``applied_steps`` read the device counters.
+The guard needs at least one clip group (the norm is what detects the overflow); a step without groups is unguarded.
 """
 from __future__ import annotations
 
@@ -107,14 +108,21 @@ class AdamW:
         slot = {g: i for i, g in enumerate(used)}                               # groups without gradients are skipped
         key = (tuple((id(p), g.data_ptr()) for p, g in zip(active, grads)), tuple(gid.get(id(p), -1) for p in active), float(grad_scale))
         if getattr(self, "_mt_key", None) != key:
-            coef = torch.zeros((max(len(used), 1), 2), dtype=torch.float32, device=dev)
+            # one {coefficient, norm} row per clip group + one trailing row for tensors in NO group: pv_clip_coef_groups sets it to 1 / grad_scale,
+            # or to -1 when any group overflowed, so that ungrouped tensors are skipped together with the grouped ones
+            coef = torch.zeros((len(used) + 1, 2), dtype=torch.float32, device=dev)
             plain = torch.full((1,), 1.0 / grad_scale, dtype=torch.float32, device=dev)
             entries = np.zeros((len(active), 6), dtype=np.int64)
             blk_t, blk_c, starts = [], [], [0] * (len(used) + 1)
             n_grouped = 0
             for t, (p, g) in enumerate(zip(active, grads)):
                 m, v = self.state[id(p)]
-                gs = coef.data_ptr() + 8 * slot[gid[id(p)]] if id(p) in gid else (plain.data_ptr() if grad_scale != 1.0 else 0)
+                if id(p) in gid:
+                    gs = coef.data_ptr() + 8 * slot[gid[id(p)]]
+                elif used:
+                    gs = coef.data_ptr() + 8 * len(used)                       # guarded step: the shared "ungrouped" row
+                else:
+                    gs = plain.data_ptr() if grad_scale != 1.0 else 0
                 entries[t] = (p.data.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), gs, p.numel())
                 nb = (p.numel() + self.CHUNK - 1) // self.CHUNK
                 blk_t += [t] * nb
@@ -130,6 +138,9 @@ class AdamW:
         mt["grads"] = grads                                                    # keep the gradient buffers alive until the launches ran
         rec = Recorder(dev)
         if used:
+            if not self._guarded:
+                # first guarded step: the device counter takes over the bias-correction count - start it from the steps applied so far
+                self._counters[0] = self.step_count - 1
             rec._add(rec.lib.pv_sumsq_multi, _ptr(mt["entries"]), _ptr(mt["blk_t"]), _ptr(mt["blk_c"]), mt["n_grouped"], self.CHUNK, _ptr(mt["partial"]))
             rec._add(rec.lib.pv_clip_coef_groups, _ptr(mt["partial"]), _ptr(mt["starts"]), len(used), float(max_norm), 1.0 / grad_scale, _ptr(mt["coef"]),
                      _ptr(self._counters))

@@ -382,6 +382,53 @@ def test_adamw_skips_a_step_whose_gradients_overflowed():
     assert int(o_hip.state_dict()["state"][0]["step"]) == 3             # the checkpoint carries the applied count (torch's bias correction)
 
 
+@pytest.mark.gpu
+def test_adamw_guard_covers_ungrouped_tensors_and_a_poisoned_first_step():
+    """A parameter in NO clip group must be skipped together with the grouped ones when a group overflows (it used to be updated, and with a
+    skipped FIRST step its bias correction divided by 1 - beta^0 = 0); and a run that starts without clip groups and adds them later keeps
+    its bias-correction count (moments carry N steps of history)."""
+    from photoverse_amd.optim import AdamW
+    g = torch.Generator().manual_seed(19)
+    shapes = [(40, 24), (24,), (17, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    o_hip = AdamW(mine, lr=1e-2, weight_decay=1e-2)
+    for step, poison in enumerate((float("inf"), None, float("nan"), None)):         # parameter 2 is in no group; the FIRST step is poisoned
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone()
+            q.grad = (gr * 64.0).cuda()
+        before = [q.detach().clone() for q in mine]
+        if poison is not None:
+            mine[0].grad[5, 7] = poison
+        else:
+            torch.nn.utils.clip_grad_norm_([ref[0], ref[1]], 1.0)
+            o_ref.step()
+        o_hip.step(clip_groups=[[mine[0], mine[1]]], max_norm=1.0, grad_scale=64.0)
+        for b, q, p in zip(before, mine, ref):
+            assert torch.isfinite(q).all(), step
+            if poison is not None:
+                assert torch.equal(q.detach(), b), step                            # grouped AND ungrouped tensors untouched
+            assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
+    assert o_hip.skipped_steps == 2 and o_hip.applied_steps == 2
+    # unguarded -> guarded transition: two plain steps, then a step with clip groups continues at step 3 of the bias correction
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref, o_hip = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2), AdamW(mine, lr=1e-2, weight_decay=1e-2)
+    for step in range(4):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad, q.grad = gr.clone(), gr.cuda()
+        if step >= 2:
+            torch.nn.utils.clip_grad_norm_([ref[0], ref[1]], 1.0)
+        o_ref.step()
+        o_hip.step(clip_groups=[[mine[0], mine[1]]] if step >= 2 else ())
+        for q, p in zip(mine, ref):
+            assert rel_l2(q.detach().cpu(), p.detach()) < 2e-6, step
+    assert o_hip.applied_steps == 4
+
+
 @pytest.mark.parametrize("p_drop,hw", [(0.0, 16), (0.1, 16), (0.0, 20)])
 def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     """The whole backward of a training step (train.py:495-536 without the optional face loss) on the HIP plans: gradient of

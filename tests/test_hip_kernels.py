@@ -395,6 +395,40 @@ def test_row_gemm_layernorm_linear_geglu(rec_cls, M, N, geglu, ln, bias):
     assert rel_l2(out, ref) < 1e-3 and rel_l2(two, ref) < 1e-3 and rel_l2(out, two) < 1e-3
 
 
+@pytest.mark.parametrize("M", [1000, 4096 + 37])
+def test_row_gemm_strides_guard_rows_and_replay_determinism(rec_cls, M):
+    """The ABI advertises ld_x / ld_out and M tails through buffer descriptors: feed a column slice of a wider buffer (ld_x = 448 > 320), write
+    into a column slice of a wider output whose padding columns and guard rows past M must stay untouched bit for bit, and replay the launch
+    several times - the hand-counted vmcnt bookkeeping of the weight ring must give bitwise identical results run to run."""
+    K, N = 320, 960
+    xw = h16(M, 448, seed=70)
+    xw[:, ::5] += 1.0
+    w = h16(N, K, scale=K ** -0.5, seed=71)
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(72))
+    beta = 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(73))
+    rec = rec_cls("cuda")
+    dxw = xw.cuda()
+    x_view = dxw[:, 64:64 + K]                                  # ld_x = 448, offset 64 columns
+    GUARD, PAD = 64, 32
+    sentinel = 12345.0
+    big = torch.full((M + GUARD, N + 2 * PAD), sentinel, dtype=torch.float16, device="cuda")
+    out_view = big[:M, PAD:PAD + N]                             # ld_out = N + 64
+    got = rec.row_gemm(x_view, w.cuda(), ln_gamma=gamma.cuda(), ln_beta=beta.cuda(), out=out_view)
+    assert got.data_ptr() == out_view.data_ptr()
+    rec.run()
+    torch.cuda.synchronize()
+    first = big.clone()
+    xs = xw[:, 64:64 + K].float()
+    ref = F.layer_norm(xs, (K,), gamma, beta, 1e-5) @ w.float().t()
+    assert rel_l2(first[:M, PAD:PAD + N], ref) < 1e-3
+    assert (first[M:] == sentinel).all(), "rows past M were written"
+    assert (first[:, :PAD] == sentinel).all() and (first[:, PAD + N:] == sentinel).all(), "columns outside the output slice were written"
+    for _ in range(5):
+        rec.run()
+        torch.cuda.synchronize()
+        assert torch.equal(big, first), "replay differs bitwise"
+
+
 def test_conv_in_out_timestep(rec_cls):
     B, h = 2, 16
     x = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(30))

@@ -209,3 +209,277 @@ def test_adapter_configs4_shape_matches_reference_class(golden_dir):
             out = ad(embs, token_index=ti)
             assert out.shape == g["outs"][key].shape == ((2, 6, 768) if ti is None else (2, 1, 768))
             torch.testing.assert_close(out, g["outs"][key], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# rows A11 / L: models/infer.py:7-123 and models/modeling_utils.py:13-95 EXECUTED (oracle/ref_exec.py: reference_run_inference,
+# reference_checkpoint_functions, reference_load_models) vs the oracle restatement / the product's host logic
+# ------------------------------------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def infer_fixture(golden_dir):
+    from oracle import infer_case as ic
+    g = _load(golden_dir, "ref_infer_golden.pt")
+    m = ic.oracle_models()
+    for k, mod in m.items():
+        _check_sums(mod, g["checksums"][k])              # oracle twins hold the numbers the reference run used (same state-dict names too)
+    return g, m
+
+
+def _expected_scheduler_log(kw, n_steps_ts):
+    log = [("from_config",), ("set_timesteps", kw["timesteps"])]
+    if kw.get("from_noised_image"):
+        log.append(("add_noise", [n_steps_ts[0]] * 2))
+    for t in n_steps_ts:
+        log += [("scale_model_input", t), ("step", t)]
+    return log
+
+
+@pytest.mark.parametrize("name", ["default_guidance1", "cfg7.5_full_neg", "global_generator", "from_noised_image", "training_mode"])
+def test_run_inference_restatement_matches_reference_function(infer_fixture, name):
+    """``oracle.infer_ref.run_inference_ref`` vs the reference's ``run_inference`` executed over the same models: default guidance 1 /
+    token 0 / tokenizer-made negative ids; guidance 7.5 / 'full' / given negative ids; seed=None (global generator) with an integer token
+    index; from_noised_image; training_mode (last step in grad mode -> the processors' random branch fusion from the global generator)."""
+    from types import SimpleNamespace
+
+    from oracle import infer_case as ic
+    from oracle.infer_ref import run_inference_ref
+    from oracle.scheduler_ref import DPMSolverMultistepRef
+    g, m = infer_fixture
+    case, exp = ic.CASES[name], g["cases"][name]
+    kw = case["kw"]
+    tok = ic.TokenizerStub()
+
+    class Rec:
+        def __init__(self, vae):
+            self._v, self.config, self.decoded = vae, vae.config, None
+
+        def encode(self, x):
+            return self._v.encode(x)
+
+        def decode(self, z):
+            self.decoded = z.detach().clone()
+            return self._v.decode(z)
+
+    vae = Rec(m["vae"])
+    if "global_seed" in case:
+        torch.manual_seed(case["global_seed"])
+    with torch.no_grad():
+        images = run_inference_ref(ic.example(case["negative"]), tok, m["image_encoder"], m["text_encoder"], m["unet"], m["text_adapter"],
+                                   m["image_adapter"], vae, SimpleNamespace(config={}), "cpu", ic.LAYERS_IDX, **kw)
+    e_lat, e_img = _rel(vae.decoded, exp["decode_input"]), _rel(images, exp["images"])
+    print(f"run_inference_ref [{name}]: latents rel-L2 {e_lat:.2e}, images {e_img:.2e} vs the reference function")
+    assert e_lat < 2e-5 and e_img < 2e-5
+    assert images.min() >= -1 and images.max() <= 1 and (images.abs() < 1).float().mean() > 0.5      # clamp present, not saturated
+    # the call protocol the reference follows (what a drop-in scheduler / tokenizer must serve)
+    sch = DPMSolverMultistepRef(); sch.set_timesteps(kw["timesteps"])
+    assert exp["scheduler_log"] == _expected_scheduler_log(kw, [int(t) for t in sch.timesteps])
+    if case["negative"]:
+        assert exp["tokenizer_calls"] == [] and tok.calls == []
+    else:
+        assert exp["tokenizer_calls"] == [([""] * ic.BATCH, "max_length", 77, "pt")] == tok.calls
+    assert exp["encoded_pixel_values"] == bool(kw.get("from_noised_image"))
+    if kw.get("training_mode"):
+        u = exp["fusion_draws"]
+        assert len(u) == 2 * g["n_attn2"] and any(v < 1 / 3 for v in u) and any(v > 2 / 3 for v in u)     # the case exercises both 2x branches
+
+
+def test_training_mode_differs_from_plain_mode_only_through_the_last_step(infer_fixture):
+    """infer.py:99: grad mode is enabled for the LAST step only - with the same arguments but training_mode=False the reference result differs."""
+    from types import SimpleNamespace
+
+    from oracle import infer_case as ic
+    from oracle.infer_ref import run_inference_ref
+    g, m = infer_fixture
+    case = ic.CASES["training_mode"]
+    kw = dict(case["kw"], training_mode=False)
+    with torch.no_grad():
+        plain = run_inference_ref(ic.example(case["negative"]), ic.TokenizerStub(), m["image_encoder"], m["text_encoder"], m["unet"],
+                                  m["text_adapter"], m["image_adapter"], m["vae"], SimpleNamespace(config={}), "cpu", ic.LAYERS_IDX, **kw)
+    assert _rel(plain, g["cases"]["training_mode"]["images"]) > 1e-3
+
+
+def _product_ckpt_models(lora, seeds, g):
+    from oracle.unet_ref import TINY_CONFIG
+    from photoverse_amd.adapters import PhotoVerseAdapter
+    from photoverse_amd.lora import LoraConfig, inject_adapter_in_model
+    from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    torch.manual_seed(0)
+    unet = UNet2DConditionModel(**TINY_CONFIG)
+    unet.requires_grad_(False)
+    set_visual_cross_attention_adapter(unet, num_tokens=(2,))
+    if lora:
+        inject_adapter_in_model(LoraConfig(**{k: v for k, v in g["lora"].items() if k in LoraConfig.__dataclass_fields__}), unet)
+    ia, ta = PhotoVerseAdapter(64, 768, 2), PhotoVerseAdapter(64, 768, 2)
+    fill_state_(unet, seeds["unet"]); fill_state_(ia, seeds["image_adapter"]); fill_state_(ta, seeds["text_adapter"])
+    return unet, ia, ta
+
+
+class _DDPLike(torch.nn.Module):
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class _Accel:
+    @staticmethod
+    def unwrap_model(m):
+        return m.module if isinstance(m, _DDPLike) else m
+
+
+def _inventory(sd):
+    return {k: (tuple(v.shape), v.double().sum().item(), (v.double() ** 2).sum().item()) for k, v in sd.items()}
+
+
+def test_save_progress_writes_what_the_reference_function_writes(golden_dir, tmp_path):
+    """Row L: the product's ``save_progress`` over the product's modules vs the inventory of the files the REFERENCE's ``save_progress``
+    (modeling_utils.py:29-50, executed) wrote for the same seeded models: file names, top-level key order, every section's key list, shapes and
+    per-tensor checksums - without LoRA (final save) and with LoRA + optimizer + a DDP-like wrapper (periodic save)."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import save_progress
+    g = _load(golden_dir, "ref_checkpoint_golden.pt")
+    unet, ia, ta = _product_ckpt_models(False, g["seeds"], g)
+    save_progress(ia, ta, unet, _Accel, str(tmp_path))
+    unet_l, ia_l, ta_l = _product_ckpt_models(True, g["seeds"], g)
+    assert [n for n, p in unet_l.named_parameters() if p.requires_grad] == g["trainable_unet_names_lora"]
+    trainable = [p for p in unet_l.parameters() if p.requires_grad] + list(ia_l.parameters()) + list(ta_l.parameters())
+    opt = torch.optim.AdamW(trainable, lr=1e-4)
+    lcfg = LoraConfig(**{k: v for k, v in g["lora"].items() if k in LoraConfig.__dataclass_fields__})
+    save_progress(_DDPLike(ia_l), _DDPLike(ta_l), _DDPLike(unet_l), _Accel, str(tmp_path), step=7, lora_config=lcfg, optimizer=opt)
+    assert sorted(os.listdir(tmp_path)) == g["listdir"] == ["photoverse.pt", "photoverse_000007.pt"]
+    for fname, exp in g["files"].items():
+        sd = torch.load(os.path.join(tmp_path, fname), map_location="cpu", weights_only=False)
+        assert list(sd.keys()) == exp["top_level_keys"]
+        for sec in ("image_adapter", "text_adapter", "cross_attention_adapter"):
+            got = _inventory(sd[sec])
+            assert list(got) == list(exp[sec]), (fname, sec)                       # same keys in the same order
+            for k, (shape, s1, s2) in exp[sec].items():
+                assert got[k][0] == shape and got[k][1] == pytest.approx(s1, rel=1e-9, abs=1e-9) and got[k][2] == pytest.approx(s2, rel=1e-9), k
+        if "lora_config" in exp:
+            for k in ("r", "lora_alpha", "lora_dropout", "target_modules"):       # the fields load_photoverse_model feeds back into LoraConfig (:17)
+                assert sd["lora_config"][k] == exp["lora_config"][k]
+        if "optimizer_keys" in exp:
+            assert sorted(sd["optimizer"].keys()) == exp["optimizer_keys"]
+
+
+def test_load_photoverse_model_restores_what_the_reference_loader_restores(golden_dir, tmp_path):
+    """modeling_utils.py:13-26 executed: a checkpoint carrying ``lora_config`` makes the loader inject LoRA into a plain UNet BEFORE loading
+    (returned config != None, same wrapped module names, same state-dict key list afterwards); without it the UNet keeps its structure."""
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_photoverse_model, save_progress
+    g = _load(golden_dir, "ref_checkpoint_golden.pt")
+    unet_l, ia_l, ta_l = _product_ckpt_models(True, g["seeds"], g)
+    lcfg = LoraConfig(**{k: v for k, v in g["lora"].items() if k in LoraConfig.__dataclass_fields__})
+    save_progress(ia_l, ta_l, unet_l, None, str(tmp_path), step=7, lora_config=lcfg)
+    other = {k: g["seeds"]["other"] for k in g["seeds"]}
+    unet2, ia2, ta2 = _product_ckpt_models(False, other, g)
+    ia3, ta3, unet3, cfg = load_photoverse_model(os.path.join(tmp_path, "photoverse_000007.pt"), ia2, ta2, unet2)
+    assert ia3 is ia2 and ta3 is ta2 and unet3 is unet2
+    exp = g["load"]
+    for k in ("r", "lora_alpha", "lora_dropout", "target_modules"):
+        assert cfg.to_dict()[k] == exp["returned_lora_config"][k]
+    assert sorted(n for n, m in unet3.named_modules() if hasattr(m, "lora_A")) == exp["lora_modules"]
+    assert list(unet3.state_dict().keys()) == exp["unet_state_keys_after_load"]
+    saved = torch.load(os.path.join(tmp_path, "photoverse_000007.pt"), weights_only=False)
+    for k, v in saved["cross_attention_adapter"].items():
+        assert torch.equal(unet3.state_dict()[k], v)
+    for k, v in ia_l.state_dict().items():
+        assert torch.equal(ia3.state_dict()[k], v)
+    # a file without lora_config: returned config None, no LoRA modules (fixture: the reference loader on its own photoverse.pt)
+    unet, ia, ta = _product_ckpt_models(False, g["seeds"], g)
+    save_progress(ia, ta, unet, None, str(tmp_path))
+    unet4, ia4, ta4 = _product_ckpt_models(False, other, g)
+    _, _, unet5, none_cfg = load_photoverse_model(os.path.join(tmp_path, "photoverse.pt"), ia4, ta4, unet4)
+    assert none_cfg is None is g["load_nolora"]["returned_lora_config"]
+    assert [n for n, m in unet5.named_modules() if hasattr(m, "lora_A")] == g["load_nolora"]["lora_modules"] == []
+
+
+def test_load_models_follows_the_reference_function(golden_dir, tmp_path):
+    """modeling_utils.py:53-95 executed with recording ``from_pretrained`` stand-ins vs the product's ``load_models`` (random-init form): what
+    is frozen, which UNet parameters are trainable (processors added AFTER the freeze, LoRA factors), adapter sizes (extra_num_tokens + 1
+    mapping pairs), the processors installed per attention layer, the LoRA assertion text, the 9-tuple order, and the photoverse_path branch
+    overriding ``lora_config``."""
+    from oracle import infer_case as ic
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_models, save_progress
+    g = _load(golden_dir, "ref_load_models_golden.pt")
+    # the reference's download order (:55-60) - documentation of the seam; the product builds the same six objects locally
+    assert [c[0] for c in g["runs"]["extra1"]["call_log"]] == ["CLIPTokenizer", "CLIPTextModel", "AutoencoderKL", "UNet2DConditionModel",
+                                                                "CLIPVisionModel", "DDPMScheduler", "patch_clip_text_transformer"]
+    assert [c[2] for c in g["runs"]["extra1"]["call_log"][:6]] == ["tokenizer", "text_encoder", "vae", "unet", None, "scheduler"]
+    kw = dict(unet_config=ic.TINY_CONFIG, vision_config=ic.VIS, text_config=ic.TXT, vae_config=ic.VAE)
+    lcfg = LoraConfig(r=4, lora_alpha=8, target_modules=["attn2.to_k", "attn2.to_v", "attn2.to_q"])
+
+    def check(ret, exp):
+        tokenizer, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, lora_config = ret
+        # 9-tuple order by role (modeling_utils.py:95): the reference's type names vs what sits in each slot here
+        assert [t.replace("Ref", "").replace("Decoder", "").replace("Stub", "") for t in exp["tuple_types"][:7]] == \
+            ["Tokenizer", "CLIPTextModel", "AutoencoderKL", "UNet2DConditionModel", "CLIPVisionModel", "PhotoVerseAdapter", "PhotoVerseAdapter"]
+        assert callable(tokenizer) and hasattr(tokenizer, "model_max_length") and hasattr(scheduler, "config")
+        assert type(text_encoder).__name__ == "CLIPTextModel" and type(vae).__name__ == "AutoencoderKL" and type(unet).__name__ == "UNet2DConditionModel"
+        assert type(image_encoder).__name__ == "CLIPVisionModel" and type(image_adapter).__name__ == type(text_adapter).__name__ == "PhotoVerseAdapter"
+        assert [n for n, p in unet.named_parameters() if p.requires_grad] == exp["unet_trainable"]
+        assert len(list(unet.named_parameters())) == exp["unet_n_params"]
+        got_frozen = {k: not any(p.requires_grad for p in m.parameters()) for k, m in (("vae", vae), ("text_encoder", text_encoder), ("image_encoder", image_encoder))}
+        assert got_frozen == exp["frozen"] == {"vae": True, "text_encoder": True, "image_encoder": True}
+        assert all(p.requires_grad for a in (image_adapter, text_adapter) for p in a.parameters()) and exp["adapters_trainable"]
+        assert list(image_adapter.state_dict().keys()) == exp["image_adapter_keys"] and list(text_adapter.state_dict().keys()) == exp["text_adapter_keys"]
+        assert image_adapter.mapping_0[0].in_features == exp["adapter_in_features"] and image_adapter.mapping_0[6].out_features == exp["adapter_out_features"]
+        got_procs = {n: tuple(getattr(p, "num_tokens", ()) or ()) for n, p in unet.attn_processors.items()}
+        assert got_procs == {n: nt for n, (_cls, nt) in exp["processors"].items()}
+        if exp["lora_config"] is None:
+            assert lora_config is None
+        else:
+            for k in ("r", "lora_alpha", "lora_dropout", "target_modules"):
+                assert lora_config.to_dict()[k] == exp["lora_config"][k]
+
+    check(load_models(None, 1, **kw), g["runs"]["extra1"])
+    ret = load_models(None, 4, use_lora=True, lora_config=lcfg, **kw)
+    check(ret, g["runs"]["extra4_lora"])
+    with pytest.raises(AssertionError, match=g["lora_assert"]):
+        load_models(None, 1, use_lora=True, **kw)
+    ret = load_models(None, 1, use_lora=True, lora_config=lcfg, **kw)
+    save_progress(ret[5], ret[6], ret[3], None, str(tmp_path), lora_config=lcfg)
+    check(load_models(None, 1, photoverse_path=os.path.join(tmp_path, "photoverse.pt"), **kw), g["runs"]["extra1_from_checkpoint"])
+
+
+@pytest.mark.parametrize("P", [1, 5])
+def test_processor_c640_matches_reference_call(golden_dir, P):
+    """The oracle processor at C = 640 / d = 80, N = 128 vs the reference class executed (the fixture the C = 640 fused HIP kernel meets on the GPU)."""
+    from oracle.unet_ref import AttentionRef, PhotoVerseAttnProcessor2_0Ref
+    g = _load(golden_dir, "ref_processor640_golden.pt")
+    C, heads = g["C"], g["heads"]
+    attn = AttentionRef(C, cross_attention_dim=768, heads=heads, dim_head=C // heads).eval()
+    fill_state_(attn, g["attn_seed"])
+    _check_sums(attn, g["attn_checksums"])
+    proc = PhotoVerseAttnProcessor2_0Ref(hidden_size=C, cross_attention_dim=768, num_tokens=(P,))
+    fill_state_(proc, g["proc_seed"])
+    c = g["cases"][P]
+    hs, text, ip = c["hs"].float(), c["text"].float(), c["ip"].float()
+    with torch.no_grad():
+        torch.testing.assert_close(proc(attn, hs, encoder_hidden_states=(text, ip))[:, ::2], c["nograd"], rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(proc.to_v_ip_norm, c["vnorm"], rtol=1e-5, atol=1e-5)
+        normed = torch.nn.functional.layer_norm(hs, (C,), c["gamma"], c["beta"], 1e-5)
+        torch.testing.assert_close(proc(attn, normed, encoder_hidden_states=(text, ip))[:, ::2], c["nograd_on_normed"], rtol=2e-5, atol=2e-5)
+    for region in ("text", "ip"):
+        if "grad_" + region in c:
+            proc.forced_fusion_seed = c["grad_" + region]["u"]
+            with torch.enable_grad():
+                torch.testing.assert_close(proc(attn, hs, encoder_hidden_states=(text, ip)).detach()[:, ::2], c["grad_" + region]["out"],
+                                           rtol=2e-5, atol=2e-5)
+
+
+def test_unet32_matches_reference_installed_processors(golden_dir):
+    from oracle.unet_ref import TINY_CONFIG, UNet2DConditionModelRef, get_visual_cross_attention_values_norm_ref, set_visual_cross_attention_adapter_ref
+    g = _load(golden_dir, "ref_unet32_golden.pt")
+    unet = UNet2DConditionModelRef(**TINY_CONFIG).eval()
+    set_visual_cross_attention_adapter_ref(unet, (1,))
+    fill_state_(unet, g["weights_seed"])
+    _check_sums(unet, g["checksums"])
+    with torch.no_grad():
+        eps = unet(g["x"], torch.tensor(g["t"]), encoder_hidden_states=(g["text"].float(), g["ip"])).sample
+    torch.testing.assert_close(eps, g["eps"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(get_visual_cross_attention_values_norm_ref(unet), g["vnorm"], rtol=1e-5, atol=1e-5)

@@ -160,9 +160,10 @@ def test_arcface_loss_matches_reference_classes(need_gpu, golden_dir):
     lmin = fl(g["x"].cuda(), g["x_gen"].cuda(), maximize=False)
     print(f"face loss {loss.item():.5f} vs reference code {g['loss'].item():.5f}; minimize {float(lmin):.5f} vs {g['loss_minimize'].item():.5f}; "
           f"d x_gen rel-L2 {rel_l2(dimg, g['d_x_gen']):.3e}")
-    assert loss.item() == pytest.approx(g["loss"].item(), rel=3e-2, abs=5e-4)
+    # measured: loss to 5 digits, image gradient 4e-2 (PReLU / max-pool kinks under an fp16 forward) - bounds at 1.5x the measured values
+    assert loss.item() == pytest.approx(g["loss"].item(), rel=1e-3, abs=5e-5)
     assert float(lmin) == pytest.approx(g["loss_minimize"].item(), rel=1e-3)
-    assert rel_l2(dimg, g["d_x_gen"]) < 1e-1
+    assert rel_l2(dimg, g["d_x_gen"]) < 6e-2
 
 
 def test_adapter_configs4_shape_matches_reference_class(need_gpu, golden_dir):
@@ -181,3 +182,171 @@ def test_adapter_configs4_shape_matches_reference_class(need_gpu, golden_dir):
         err = rel_l2(out, g["outs"][key])
         print(f"17-mapping adapter token_index={ti}: rel-L2 vs reference class {err:.3e}")
         assert out.shape == g["outs"][key].shape and err < 3e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# row A11: ``photoverse_amd.infer.run_inference`` (HIP, graph-captured loop) vs the REFERENCE's ``run_inference`` executed in the build
+# container over the same seeded tiny models (tests/golden/ref_infer_golden.pt; CPU counterpart in tests/test_reference_pins.py)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def infer_models(need_gpu, golden_dir):
+    from oracle import infer_case as ic
+    from photoverse_amd.modeling_utils import load_models
+    g = _load(golden_dir, "ref_infer_golden.pt")
+    tok, text_encoder, vae, unet, image_encoder, image_adapter, text_adapter, scheduler, _ = load_models(
+        None, ic.NUM_TOKENS - 1, unet_config=ic.TINY_CONFIG, vision_config=ic.VIS, text_config=ic.TXT, vae_config=ic.VAE, seed=3)
+    m = dict(unet=unet, image_encoder=image_encoder, text_encoder=text_encoder, image_adapter=image_adapter, text_adapter=text_adapter, vae=vae)
+    ic.fill_all_(**m)
+    for k, mod in m.items():
+        _check_sums(mod, g["checksums"][k])           # the HIP models hold the numbers the reference run used
+    for mod in m.values():
+        mod.to("cuda")
+    return g, m, scheduler
+
+
+@pytest.mark.parametrize("name", ["default_guidance1", "cfg7.5_full_neg", "global_generator", "from_noised_image", "training_mode"])
+def test_run_inference_matches_reference_function(infer_models, name):
+    """Images (VAE decode + clamp, infer.py:121-123) and final latents (``vae=None`` form) of the product's ``run_inference`` vs the
+    reference function's: guidance 1 / 7.5 / 3, token_index 0 / 1 / 'full', tokenizer-made and given negative ids, explicit seed and the
+    global generator, from_noised_image (posterior variance forced to ~0 in the fixture: the draw itself is platform-specific), and
+    training_mode with the reference's recorded per-layer fusion draws imposed on the device-side draw."""
+    from oracle import infer_case as ic
+    from photoverse_amd.infer import run_inference
+    g, m, scheduler = infer_models
+    case, exp = ic.CASES[name], g["cases"][name]
+    kw = dict(case["kw"])
+    sf = m["vae"].config.scaling_factor
+
+    def call(vae):
+        tok = ic.TokenizerStub()
+        if "global_seed" in case:
+            torch.manual_seed(case["global_seed"])
+        with torch.no_grad():
+            out = run_inference(ic.example(case["negative"]), tok, m["image_encoder"], m["text_encoder"], m["unet"], m["text_adapter"],
+                                m["image_adapter"], vae, scheduler, "cuda", ic.LAYERS_IDX, **kw)
+        assert tok.calls == exp["tokenizer_calls"]                     # same tokenizer protocol as the reference (infer.py:43-49)
+        return out
+
+    if kw.get("training_mode"):
+        # build the loop, then impose the draws the reference's processors made (attention_processor.py:414: uncond forward's attn2 layers in
+        # call order, then the cond forward's) on the device-side generator; the cached loop serves the following calls
+        call(None)
+        loop = next(reversed(m["unet"].__dict__["_denoise_loops"].values()))
+        n = g["n_attn2"]
+        (eu,), (ec,) = loop.engines_u, loop.engines_c
+        assert len(eu.fusion_names) == len(ec.fusion_names) == n
+        eu.fusion_forced.copy_(torch.tensor(exp["fusion_draws"][:n]))
+        ec.fusion_forced.copy_(torch.tensor(exp["fusion_draws"][n:]))
+    if kw.get("from_noised_image"):
+        latents = None                                                 # the vae=None form cannot encode; images carry the check
+    else:
+        latents = call(None)
+    images = call(m["vae"])
+    e_img = rel_l2(images, exp["images"])
+    msg = f"run_inference [{name}]: images rel-L2 {e_img:.3e}"
+    if latents is not None:
+        e_lat = rel_l2(latents / sf, exp["decode_input"])
+        msg += f", latents {e_lat:.3e}"
+        assert e_lat < 3e-3
+    print(msg + " vs the reference function (executed)")
+    assert images.shape == exp["images"].shape and images.dtype == torch.float32
+    assert images.min() >= -1 and images.max() <= 1
+    assert e_img < 5e-3
+
+
+def test_checkpoint_loaded_by_the_product_drives_the_hip_unet_like_the_reference_loaded_one(need_gpu, golden_dir, tmp_path):
+    """Row L on the device: the reference's ``load_photoverse_model`` (modeling_utils.py:13-26, executed) injected LoRA from the file's
+    ``lora_config`` into a plain tiny UNet and loaded the attn2 subset; the fixture holds that UNet's eps on a probe.  The product writes the same
+    checkpoint (same seeded numbers, inventory checked on the CPU in tests/test_reference_pins.py), loads it with ITS loader into a plain HIP
+    UNet, and must produce that eps (LoRA merged into the packed fp16 weights here, un-merged in the reference-loaded model)."""
+    from test_reference_pins import _product_ckpt_models
+    from photoverse_amd.lora import LoraConfig
+    from photoverse_amd.modeling_utils import load_photoverse_model, save_progress
+    g = _load(golden_dir, "ref_checkpoint_golden.pt")
+    unet_l, ia_l, ta_l = _product_ckpt_models(True, g["seeds"], g)
+    lcfg = LoraConfig(**{k: v for k, v in g["lora"].items() if k in LoraConfig.__dataclass_fields__})
+    save_progress(ia_l, ta_l, unet_l, None, str(tmp_path), step=7, lora_config=lcfg)
+    other = {k: g["seeds"]["other"] for k in g["seeds"]}
+    unet2, ia2, ta2 = _product_ckpt_models(False, other, g)
+    _, _, unet3, cfg = load_photoverse_model(os.path.join(tmp_path, "photoverse_000007.pt"), ia2, ta2, unet2)
+    assert cfg is not None
+    unet3.to("cuda")
+    p = g["probe"]
+    with torch.no_grad():
+        eps = unet3(p["x"].cuda(), torch.tensor(p["t"]), encoder_hidden_states=(p["text"].cuda(), p["ip"].cuda())).sample
+    e_loaded, e_source = rel_l2(eps, g["load"]["eps_loaded"]), rel_l2(eps, g["load"]["eps_source"])
+    print(f"HIP UNet after load_photoverse_model: eps rel-L2 {e_loaded:.3e} vs the reference-loaded UNet ({e_source:.2e} vs the UNet the file was saved from)")
+    assert e_loaded < 2.5e-3 and e_source > 10 * e_loaded
+
+
+@pytest.mark.parametrize("P", [1, 5])
+def test_fused_attn2_kernel_c640_matches_reference_processor(need_gpu, golden_dir, P):
+    """X1 at C = 640 / d = 80: ``pv_cross_attention_fused`` (ONE launch: norm2 -> to_q -> text + image-token SDPA -> fusion -> to_out + bias +
+    residual) vs ``PhotoVerseAttnProcessor2_0.__call__`` EXECUTED from the reference source at N = 128: out - hs must equal the processor's
+    output - without LayerNorm (the processor protocol's own input), with the block's norm2 in front (the fixture applied F.layer_norm before
+    calling the reference processor), and for the two grad-mode 2x branches (attention_processor.py:415-418)."""
+    from photoverse_amd import ops
+    g = _load(golden_dir, "ref_processor640_golden.pt")
+    C, H, N, NT, B = g["C"], g["heads"], g["N"], 77, 2
+    d = C // H
+    from oracle.unet_ref import AttentionRef
+    attn = AttentionRef(C, cross_attention_dim=768, heads=H, dim_head=d)
+    fill_state_(attn, g["attn_seed"])
+    _check_sums(attn, g["attn_checksums"])
+    from photoverse_amd.attention_processor import PhotoVerseAttnProcessor2_0
+    proc = PhotoVerseAttnProcessor2_0(hidden_size=C, cross_attention_dim=768, num_tokens=(P,))
+    fill_state_(proc, g["proc_seed"])
+    c = g["cases"][P]
+    assert ops.Recorder.xattn_fused_supported(C, H, N, NT, P)
+    f16 = lambda t: t.detach().half().cuda().contiguous()
+    hs = c["hs"].reshape(B * N, C).cuda()
+    wkv = torch.cat([f16(attn.to_k.weight), f16(attn.to_v.weight)], 0).contiguous()
+    wkvip = torch.cat([f16(proc.to_k_ip[0].weight), f16(proc.to_v_ip[0].weight)], 0).contiguous()
+    wq, wo, bo = f16(attn.to_q.weight), f16(attn.to_out[0].weight), attn.to_out[0].bias.detach().float().cuda()
+
+    def run(ln, w_text, w_ip):
+        rec = ops.Recorder("cuda")
+        kvt = rec.gemm(c["text"].reshape(B * NT, 768).cuda(), wkv, rows_per_image=NT)
+        kvip = rec.gemm(c["ip"].half().reshape(B * P, 768).cuda(), wkvip, rows_per_image=P)
+        vn = torch.zeros(B, H, P, device="cuda")
+        kimg, vimg = rec.xattn_pack_kv(kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=B, heads=H, d=d, nt=NT, nip=P, vnorm=vn)
+        out, _ = rec.cross_attention_fused(hs, wq, rec.pack_wo_for_fused(wo), bo, kimg, vimg, batch=B, nq=N, heads=H, d=d, nt=NT, nip=P,
+                                           ln_gamma=c["gamma"].cuda() if ln else None, ln_beta=c["beta"].cuda() if ln else None,
+                                           w_text=w_text, w_ip=w_ip)
+        rec.run()
+        torch.cuda.synchronize()
+        branch = (out.float() - hs.float()).view(B, N, C)[:, ::2]
+        return branch, vn
+
+    for key, (ln, wt, wi) in {"nograd": (False, 1.0, 1.0), "nograd_on_normed": (True, 1.0, 1.0), "grad_text": (False, 2.0, 0.0),
+                              "grad_ip": (False, 0.0, 2.0)}.items():
+        if key not in c:
+            continue
+        exp = c[key]["out"] if isinstance(c[key], dict) else c[key]
+        got, vn = run(ln, wt, wi)
+        err = rel_l2(got, exp)
+        print(f"fused attn2 C=640 P={P} [{key}]: branch rel-L2 vs reference processor {err:.3e}")
+        # the residual is added in fp16 storage: the branch is recovered from out - hs, so its error carries the output rounding of (hs + branch)
+        assert err < 4e-3
+        torch.testing.assert_close(vn.cpu().unsqueeze(-1), c["vnorm"], rtol=2e-3, atol=2e-3)
+
+
+def test_unet32_reaches_the_c640_fused_kernel_and_matches_reference_functions(need_gpu, golden_dir):
+    """models/unet.py:8-47 executed on the tiny UNet at a 32x32 latent: the 640-wide mid-block attention has 256 rows, so the HIP engine runs
+    its attn2 branch on the C = 640 fused kernel (asserted from the launch tags), the 320-wide levels on the C = 320 one."""
+    from oracle.unet_ref import TINY_CONFIG
+    from photoverse_amd.unet import UNet2DConditionModel, get_visual_cross_attention_values_norm, set_visual_cross_attention_adapter
+    g = _load(golden_dir, "ref_unet32_golden.pt")
+    hip = UNet2DConditionModel(**TINY_CONFIG)
+    set_visual_cross_attention_adapter(hip, (1,))
+    fill_state_(hip, g["weights_seed"])
+    _check_sums(hip, g["checksums"])
+    hip.to("cuda")
+    with torch.no_grad():
+        eps = hip(g["x"].cuda(), torch.tensor(g["t"]), encoder_hidden_states=(g["text"].cuda(), g["ip"].cuda())).sample
+        vn = get_visual_cross_attention_values_norm(hip)
+    tags = [t[0] for eng in hip._engines.values() for t in eng.rec.tags]
+    assert any(t.startswith("xattn_fused_kernel<640") for t in tags) and any(t.startswith("xattn_fused_kernel<320") for t in tags), set(tags)
+    err = rel_l2(eps, g["eps"])
+    print(f"tiny UNet @32x32 (C=640 fused attn2 in the mid block): eps rel-L2 {err:.3e}, vnorm {rel_l2(vn, g['vnorm']):.3e} vs reference functions")
+    assert err < 2.5e-3 and rel_l2(vn, g["vnorm"]) < 1e-3

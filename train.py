@@ -84,6 +84,9 @@ def parse_args():
     p.add_argument("--synthetic_data", action="store_true", help="random images instead of --data_root_path")
     p.add_argument("--arcface_weights", type=str, default=None, help="local state dict of the ArcFace IR-ResNet18")
     p.add_argument("--grad_scale", type=float, default=4096.0, help="static loss scale of the fp16 gradient storage")
+    p.add_argument("--max_consecutive_skipped_steps", type=int, default=8,
+                   help="abort when this many optimizer steps in a row were skipped for non-finite gradients (the loss scale is static: "
+                        "a persistent overflow would otherwise train nothing while the LR schedule and the checkpoints advance)")
     args = p.parse_args()
     if len(args.image_encoder_layers_idx) != args.extra_num_tokens:           # train.py:291-292
         p.error("--image_encoder_layers_idx must have --extra_num_tokens entries")
@@ -324,6 +327,7 @@ def main():
     # noise / timestep draws: one stream per rank (weights and the fusion-draw seed are the same on every rank, the data and the noise are not)
     gen = torch.Generator().manual_seed(args.seed + rank) if args.seed is not None else None
     global_step, micro = 0, 0
+    last_skipped, consecutive_skips = 0, 0
     acc_n = args.gradient_accumulation_steps
     for epoch in range(args.num_train_epochs):
         if sampler is not None:
@@ -342,15 +346,34 @@ def main():
                 logs["loss_face"] = float(out["face_loss"])
             if main_process:
                 print(f"step {global_step}: " + ", ".join(f"{k}={v:.6g}" for k, v in logs.items()), flush=True)
-            if not all(math.isfinite(v) for v in logs.values()):
-                # fp16 activations / gradients under a static loss scale can overflow where the fp32 reference cannot; the optimizer skips
-                # steps whose gradient norm is not finite (optim.AdamW), a non-finite LOSS means the forward itself overflowed: stop
-                raise SystemExit(f"non-finite loss at step {global_step} ({logs}); optimizer skipped {optimizer.skipped_steps} step(s) so far - "
-                                 "lower --grad_scale or the learning rate")
+            # fp16 activations / gradients under a static loss scale can overflow where the fp32 reference cannot.  The optimizer skips steps
+            # whose gradient norm is not finite (optim.AdamW; the gradients are all-reduced, so every rank takes the same decision); a
+            # non-finite LOSS means the forward itself overflowed.  Losses are rank-local: agree on the flag first, so that every rank leaves
+            # together instead of one rank exiting and the others hanging in the next all-reduce until the RCCL timeout.
+            bad = not all(math.isfinite(v) for v in logs.values())
+            if world > 1:
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if bad else 0.0], device="cpu" if dist.get_backend() == "gloo" else device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                bad = bool(flag.item())
+            skipped = optimizer.skipped_steps
+            consecutive_skips = consecutive_skips + 1 if skipped > last_skipped else 0
+            last_skipped = skipped
+            if main_process and consecutive_skips:
+                print(f"step {global_step}: optimizer step SKIPPED (non-finite gradients under --grad_scale {args.grad_scale:g}); "
+                      f"{skipped} skipped so far, {consecutive_skips} in a row", flush=True)
+            too_many = consecutive_skips >= args.max_consecutive_skipped_steps
+            if bad or too_many:
+                if world > 1:
+                    dist.destroy_process_group()
+                why = (f"non-finite loss at step {global_step} on at least one rank (this rank: {logs})" if bad else
+                       f"{consecutive_skips} optimizer steps in a row skipped for non-finite gradients at step {global_step}")
+                raise SystemExit(f"{why}; optimizer skipped {skipped} step(s) so far - lower --grad_scale or the learning rate")
             if main_process and args.samples_save_steps and global_step % args.samples_save_steps == 0:                            # train.py:555-596
                 save_samples(args, global_step, batch, tokenizer, image_encoder, text_encoder, unet, text_adapter, image_adapter, vae,
                              noise_scheduler, device, face)
             if main_process and global_step % args.checkpoint_save_steps == 0:
+                print(f"checkpoint at step {global_step}: {optimizer.applied_steps} optimizer steps applied, {skipped} skipped", flush=True)
                 save_progress(image_adapter, text_adapter, unet, None, args.output_dir, step=global_step, lora_config=lora_config, optimizer=optimizer)
             if global_step >= args.max_train_steps:
                 break
