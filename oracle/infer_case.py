@@ -5,11 +5,12 @@ import torch
 
 from oracle.seeded import fill_state_
 from oracle.unet_ref import TINY_CONFIG
-from oracle.vae_ref import TINY_VAE_CONFIG
 
 VIS = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3, image_size=56, patch_size=14)
 TXT = dict(vocab_size=1000, hidden_size=768, num_attention_heads=12, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=77)
-VAE = dict(TINY_VAE_CONFIG, with_encoder=True)
+#: channel counts the HIP conv kernels tile (multiples of 128); one 2x level
+VAE = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256), layers_per_block=1, norm_num_groups=32, scaling_factor=0.18215,
+           with_encoder=True)
 SEEDS = dict(unet=157, vision=158, text=159, image_adapter=160, text_adapter=161, vae=162)
 LATENT, BATCH, NUM_TOKENS = 16, 2, 2
 #: 9 >= the tiny ViT's 4 hidden states: dropped by the ``i < len(image_features[2])`` filter of infer.py:80-84

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libphotoverse_hip.so")
-SOURCES = ["pv_gemm.hip", "pv_norm.hip", "pv_attn.hip", "pv_misc.hip", "pv_xfused.hip", "pv_rowgemm.hip", "pv_backward.hip", "pv_train.hip"]
+SOURCES = ["pv_gemm.hip", "pv_convbig.hip", "pv_norm.hip", "pv_attn.hip", "pv_misc.hip", "pv_xfused.hip", "pv_rowgemm.hip", "pv_backward.hip", "pv_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 #: per-source extra flags.  The attention kernels keep MFMA results in VGPRs (the softmax VALU work reads them directly;
 #: AGPR-form costs ~200 v_accvgpr moves per tile); the 256-row GEMM variant needs the AGPR half for its accumulators.
@@ -43,7 +43,7 @@ def _stale(out: str, deps) -> bool:
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "pv_common.h"), os.path.join(os.path.dirname(HERE), "include", "photoverse_hip.h"), __file__]
+    headers = [os.path.join(CSRC, "pv_common.h"), os.path.join(CSRC, "pv_gemm_dev.h"), os.path.join(os.path.dirname(HERE), "include", "photoverse_hip.h"), __file__]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

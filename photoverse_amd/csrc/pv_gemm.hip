@@ -19,17 +19,12 @@
 //
 // Larger tiles (256-row / one wave per SIMD, 256 x 160 x 32 with three stages) were built and measured in round 1 and lost
 // to this kernel on every UNet shape; that code and its timing ablations live in tools/r01_experiments/ (DESIGN.md section 4).
-#include "pv_common.h"
+#include "pv_gemm_dev.h"
 
 namespace {
 
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
-
-// kernel-side parameter block: the C-ABI struct + byte extents of the three buffer descriptors
-struct pv_gemm_params_dev : pv_gemm_params {
-    uint32_t a0_bytes, a1_bytes, w_bytes;
-};
 
 // 128-row tile, wave tile 64 x BN/2, 2 LDS stages, 2 workgroups / CU (two waves per SIMD)
 template <int NF, int MIV = 4>
@@ -615,6 +610,10 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
         return dispatch<4, false, true>(p, stream);
     }
     const bool conv = p.taps == 9;
+    if (conv) {                                          // 64 x 64 level: the 256 x 320 tile (pv_convbig.hip) where the launch fills the chip with it
+        const int rc = pv_conv_big_launch(p, stream);
+        if (rc >= 0) return rc;
+    }
     if (p.N % 160 == 0) return conv ? dispatch<5, true, false>(p, stream) : dispatch<5, false, false>(p, stream);
     if (p.N % 128 == 0) return conv ? dispatch<4, true, false>(p, stream) : dispatch<4, false, false>(p, stream);
     return (int)hipErrorInvalidValue;

@@ -191,6 +191,11 @@ class Recorder:
         mi = 2 if (conv is None and not geglu and cs is None and splitk == 1 and ((M + 127) // 128) * (N // (nf * 32)) < 512) else 4
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
                 f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
+        # pv_convbig.hip's 256 x 320 tile (pv_conv_big_launch's rule): stride-1 / pad-1 3x3 convs whose launch has >= PV_CONV_BIG (256) such tiles
+        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
+        if (conv is not None and big_min > 0 and geo[5] == 1 and not geo[6] and geo[7] == 1 and geo[1:3] == geo[3:5] and N % 320 == 0 and not out_f32
+                and splitk == 1 and ((M + 255) // 256) * (N // 320) >= big_min):
+            name = f"conv_big_kernel<{'true' if cs is not None else 'false'}>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 

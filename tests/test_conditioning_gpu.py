@@ -574,7 +574,9 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     # first AdamW step moves every weight by ~lr * sign(g): compare the updates
     upd_h = torch.cat([(h_params[n].detach().cpu() - before[n].cpu()).flatten() for n in train_names])
     upd_r = torch.cat([(r_params[n].detach() - before[n].cpu()).flatten() for n in train_names])
-    assert rel_l2(upd_h, upd_r) < 0.15          # sign flips of near-zero gradient entries dominate: each flips a full +-lr step
+    upd_err = rel_l2(upd_h, upd_r)
+    print(f"first AdamW update vs torch.optim.AdamW on the oracle gradients: rel-L2 {upd_err:.3e}")
+    assert upd_err < 0.15          # sign flips of near-zero gradient entries dominate: each flips a full +-lr step
 
 
 @pytest.mark.parametrize("smooth_face", [False, True])
@@ -725,7 +727,8 @@ def test_training_step_with_face_loss_matches_oracle_autograd(need_gpu, smooth_f
     # with the branch dominating the gradient (FW = 2) every group inherits part of the ArcFace trunk's PReLU / max-pool kink noise
     # (6-8e-2 on the image gradient in isolation, tests/test_loss_gpu.py); with FW = 0.01 the same run gives 1.4e-3 ... 1.2e-2
     # measured: 2.2-2.6e-2 (real trunk, branch = 23 % of the gradient); 2.3e-3 ... 1.2e-2 (smooth trunk, branch = 8 %)
-    assert max(errs.values()) < (2e-2 if smooth_face else 6e-2), errs
+    # round 4 box: 3.3e-2 max (real trunk), 1.24e-2 max (smooth trunk) - bounds at ~1.5x
+    assert max(errs.values()) < (1.9e-2 if smooth_face else 5e-2), errs
     # the branch's own contribution must be far above those errors, or the comparison would not see it
     tot = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in plist])
     mo = torch.cat([(gm if gm is not None else torch.zeros_like(p)).flatten() for gm, p in zip(main_only, plist)])
@@ -955,7 +958,9 @@ def test_full_size_identity_loss_branch_matches_oracle_autograd(need_gpu, full_w
                   text_adapter=list(zip(text_adapter.parameters(), r_ta.parameters())))
     errs = {k: group_err(v) for k, v in groups.items()}
     print("full-size training step + face loss, gradient rel-L2 per group:", errs)
-    assert max(errs.values()) < 8e-2, errs
+    # measured (round 4): ip 2.4e-2, LoRA 1.0-1.4e-2, image adapter 2.9e-2, text adapter 1.3e-2 - the ArcFace trunk's PReLU / max-pool kinks
+    # under an fp16 forward (6-8e-2 on the image gradient in isolation) dominate every group; bound at ~1.6x the largest
+    assert max(errs.values()) < 4.8e-2, errs
 
 
 @pytest.mark.parametrize("face", [False, True])

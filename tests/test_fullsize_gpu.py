@@ -204,7 +204,10 @@ def test_full_size_training_gradients(full_weights, golden_dir):
     # term, whose gradient is +-0.01 / N per concept element: one element of 3840 whose sign differs between the fp16 device path and
     # the fp32 oracle moves the group by ~2e-2 (measured 1.0e-2 .. 2.2e-2) - a kink of the loss, not of the kernels ...
     assert max(res["ip"][0], res["lora_A"][0], res["lora_B"][0]) < 3e-3, res
-    assert res["image_adapter"][0] < 8e-3 and res["text_adapter"][0] < 6e-2, res
+    # the kinked text-adapter value is REPORTED (1.0e-2 .. 2.2e-2 over the boxes seen) with a sanity bound only; the asserted bound for that
+    # chain is the smooth variant's below
+    print(f"text adapter WITH the |concept| kink term: rel-L2 {res['text_adapter'][0]:.3e} (reported; the smooth variant below is the asserted one)")
+    assert res["image_adapter"][0] < 4e-3 and res["text_adapter"][0] < 3.5e-2, res
     assert all(abs(r - 1.0) < 5e-3 for _, r in res.values()), res
     # ... so the text-adapter chain (adapter MLPs <- injected 12-layer text encoder <- K / V of 16 cross-attention layers) is pinned on the
     # same step without that term (loss_weights = (1, 0, 0.001)), where it is smooth
@@ -219,4 +222,4 @@ def test_full_size_training_gradients(full_weights, golden_dir):
     e_smooth, r_smooth = group([(p_, exp["text_adapter_smooth"][n]) for n, p_ in text_adapter.named_parameters()])
     print(f"text adapter without the |concept| term: rel-L2 {e_smooth:.3e}, norm ratio {r_smooth:.4f}")
     # measured 8.0e-3 (fp16 gradients through the 12-layer text encoder and the adapter's LeakyReLU / LayerNorm kinks; norm ratio 1.0003)
-    assert e_smooth < 1.5e-2 and abs(r_smooth - 1.0) < 5e-3
+    assert e_smooth < 1.2e-2 and abs(r_smooth - 1.0) < 2e-3

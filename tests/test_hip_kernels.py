@@ -175,6 +175,48 @@ def test_conv3x3_dual_source_big_tile(rec_cls):
     assert rel_l2(out, ref) < 1e-3
 
 
+@pytest.mark.parametrize("B,c0,c1,cout,h,extras", [(16, 64, 0, 320, 64, True), (16, 128, 64, 320, 64, False), (8, 64, 0, 640, 64, True), (1, 64, 0, 320, 24, True)])
+def test_conv3x3_256x320_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeypatch, B, c0, c1, cout, h, extras):
+    """pv_convbig.hip (256 x 320 x 64 tile, one 8-wave workgroup per CU: the 3x3 convs of the 64 x 64 level) against fp32 torch AND, bit for bit,
+    against the 128 x 160 kernel it replaces (same MFMA, same K order, same rounding points): single and dual source, N = 320 / 640,
+    bias + time-embedding row + residual + SiLU epilogue, GroupNorm column statistics, and an M tail (one 24 x 24 image: 576 rows = 2.25 tiles, run on
+    the big tile by lowering its minimum tile count)."""
+    from photoverse_amd.ops import ACT_SILU
+    x0 = h16(B, c0, h, h, seed=81)
+    x1 = h16(B, c1, h, h, seed=82) if c1 else None
+    w = h16(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5, seed=83)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(84))
+    temb = torch.randn(B, cout, generator=torch.Generator().manual_seed(85))
+    res = h16(B * h * h, cout, seed=86)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * h * h, -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    kw = dict(bias=bias.cuda(), conv=dict(batch=B, hin=h, win=h, hout=h, wout=h), colstats=True)
+    if extras:
+        kw.update(rowadd=temb.cuda(), rowadd_ld=cout, residual=res.cuda(), act=ACT_SILU)
+    outs, stats = {}, {}
+    for name, env in (("big", "1"), ("small", "0")):
+        monkeypatch.setenv("PV_CONV_BIG", env)
+        rec = rec_cls("cuda")
+        outs[name] = rec.gemm(rows(x0), wp, a1=rows(x1) if c1 else None, **kw)
+        stats[name] = rec.colstats.get((outs[name].data_ptr(), B * h * h, cout))
+        rec.run()
+        torch.cuda.synchronize()
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    ref = F.conv2d(xin, w.float(), bias, padding=1)
+    if extras:
+        ref = F.silu(ref + temb[:, :, None, None])
+    ref = ref.permute(0, 2, 3, 1).reshape(B * h * h, cout)
+    if extras:
+        ref = ref + res.float()
+    assert rel_l2(outs["big"], ref) < 1e-3
+    assert torch.equal(outs["big"], outs["small"])
+    assert stats["big"] is not None and torch.equal(stats["big"], stats["small"])
+    # the statistics are those of the stored (rounded) values: per 64-row block column sums
+    blk = outs["big"].float().view(-1, 64, cout)
+    torch.testing.assert_close(stats["big"].view(-1, 2, cout)[:, 0], blk.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(stats["big"].view(-1, 2, cout)[:, 1], (blk * blk).sum(1), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("c0,c1,hw,act", [(320, 0, 64 * 64, 1), (640, 320, 16 * 16, 1), (1280, 1280, 64, 0), (2560, 0, 64, 1), (64, 0, 25, 0)])
 def test_groupnorm(rec_cls, c0, c1, hw, act):
     B = 2

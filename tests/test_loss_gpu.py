@@ -75,7 +75,8 @@ def test_face_loss_value_and_image_gradient(pair, smooth_pair, H, normalize, max
     loss, dimg = hip.loss_and_grad(x.cuda(), xg.cuda(), maximize=maximize, normalize=normalize)
     torch.cuda.synchronize()
     print(f"face loss H={H} smooth={smooth}: {loss.item():.5f} vs {want.item():.5f}; grad rel-L2 {rel_l2(dimg, xr.grad):.3e}")
-    assert loss.item() == pytest.approx(want.item(), rel=2e-2, abs=2e-3)
+    # measured: loss to 4 digits; image gradient 6.4-7.7e-2 (real trunk: PReLU / max-pool kinks under an fp16 forward), 1.8-3.7e-2 (smooth)
+    assert loss.item() == pytest.approx(want.item(), rel=2e-3, abs=2e-4)
     assert rel_l2(dimg, xr.grad) < (5e-2 if smooth else 1e-1)
     assert float(hip(x.cuda(), xg.cuda(), maximize=maximize, normalize=normalize)) == pytest.approx(loss.item())
 

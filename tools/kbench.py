@@ -238,6 +238,7 @@ def wgrad(name, M, K, N):
 
 conv("conv3 320->320 @64", 320, 320, 64)
 conv("conv3 640+320->320 @64 (dual)", 640, 320, 64, c1=320)
+conv("conv3 320+320->320 @64 (dual)", 320, 320, 64, c1=320)
 conv("conv3 320->320 @64 s2", 320, 320, 64, stride=2)
 conv("conv3 640->640 @32", 640, 640, 32)
 conv("conv3 320->640 @32", 320, 640, 32)
