@@ -1,35 +1,46 @@
-// pv_convbig: the 3x3 convolutions of the 64 x 64 level (M = B * 4096 output pixels, N = 320 / 640) on a 256 x 320 x 64 tile.
+// pv_convbig: the 3x3 convolutions of the 64 x 64 level (M = B * 4096 output pixels, N = 320 / 640) on a 256 x 320 tile.
 //
 // Why a second conv kernel.  The 128 x 160 tile of pv_gemm.hip runs its main loop at the L2 -> LDS gather floor of the tile (DMA-only
-// build 94 us of 132 us, EXPERIMENTS.md) and under the package power cap: what moves it is bytes staged and read per flop.  This tile
-// stages (256 + 320) * 128 B per 2 * 256 * 320 * 64 flop = 142 flop / B (128 x 160: 71) and reads 26 fragments per 80 MFMAs per wave
-// (128 x 160: 18 per 40).  Price: 144 KiB of LDS -> ONE 8-wave workgroup per CU, so the two waves of a SIMD belong to the same
-// workgroup and run in lock-step - nothing hides a wave's DMA issue, LDS latency or epilogue but its own instruction stream.  Hence:
+// build 94 us of 132 us, EXPERIMENTS.md): what moves it is bytes staged and read per flop.  This tile stages (256 + 320) rows per
+// 2 * 256 * 320 flop per k = 142 flop / B (128 x 160: 71) and reads 26 fragments per 80 MFMAs per wave (128 x 160: 18 per 40).
+// Price: 144 KiB of LDS -> ONE 8-wave workgroup per CU, so the two waves of a SIMD belong to the same workgroup and run in lock-step -
+// nothing hides a wave's DMA issue, LDS latency or epilogue but its own instruction stream, and nothing hides the L2 latency of the
+// staging but the depth of the LDS ring.  (Round 4, first form: 64-deep stages in two buffers = ONE stage in flight; in-kernel stamps
+// showed every K-step waiting ~1700 of its 4500 cycles for that stage to land, profiles/r04_convbig_v1_stamps.txt.)  Hence:
 //
-//   * a K-step (64 deep) is EIGHT phases of 10 MFMAs (two row fragments x five column fragments of one 32-deep half); the fragment
-//     reads of phase p+1 are issued in front of the MFMAs of phase p (A fragments double-buffered per phase, W fragments per half);
-//   * ONE barrier per K-step, behind phase 6: by then every wave has read the last fragments of the buffer (phase 7's, issued in phase 6),
-//     so the buffer is free for stage g+2; its nine LDS-DMA pieces per wave are issued three at a time BETWEEN the MFMAs of phases
-//     7, 0 and 1 (a DMA issue costs 60 - 180 cycles of the wave's stream; nine in a row would idle the matrix pipe of a lock-stepped pair);
-//   * the stage needed next (g+1) was issued a whole K-step (>= 2560 MFMA cycles per SIMD) before the wait that retires it.
+//   * stages are 32 deep (A 16 KiB + W 20 KiB = 36 KiB) in a FOUR-buffer ring: up to three stages (108 KiB) are in flight behind a counted
+//     vmcnt while the fourth is read;
+//   * the two waves of a SIMD (waves w and w + 4: the two 128-row halves of the tile) run STAGGERED by one barrier interval.  A wave
+//     alternates LOAD segments (the 13 fragment reads of a stage + its share of the LDS-DMA issue) with MFMA segments (40 MFMAs: eight
+//     row fragments x five column fragments), a barrier between segments; waves 4-7 execute one extra barrier up front, so that while one
+//     half of the workgroup holds the matrix pipes the other half reads LDS and issues DMA (MI355X_MICROARCH.md "Two waves per SIMD";
+//     the first ring form ran both halves in phase - matrix || matrix then load || load - at 65 % matrix-pipe use);
+//   * per stage and wave: LOAD(s) (13 fragment reads, the wave's 4 - 5 LDS-DMA pieces of stage s+3) | barrier | MFMA(s) | barrier;
+//     a stage's buffer is free once waves 4-7 finished LOAD(s), i.e. before anybody's LOAD(s+1), where the refill (stage s+4) starts
+//     (20-MFMA segments, four barriers per stage, measured 2200 cycles per stage against 1280 of matrix-pipe time: barrier skew per segment);
+//   * the K order is pv_gemm.hip's: 64-channel chunk major, filter tap minor, the two 32-deep halves of a (chunk, tap) in sequence - so
+//     every accumulator sees the same products in the same order and the results are BIT-IDENTICAL to the 128-row kernel's.
 //
-// Operand roles, LDS image (8-row x 128-B pieces, 16-B chunk ^= row & 7 on the source offset and on the ds_read_b128 side), K order
-// (channel-chunk major / tap minor), zero padding by out-of-range buffer offsets, the epilogue (bias, time-embedding row, activation,
-// residual, fp16 stores widened by v_permlane16_swap, GroupNorm column statistics per 64-row block) are those of pv_gemm.hip - results
-// are bit-identical to the 128-row kernel (same MFMA, same K order, same rounding points).
+// LDS image of a stage: [rows][64 B], one LDS-DMA wave-instruction = 16 rows x 64 B; bank-conflict swizzle on the 16-B chunk index,
+// chunk ^= F[(row >> 2) & 3], F = {0, 2, 3, 1}, applied to the per-lane SOURCE offset and again on the ds_read_b128 side (with 64-B rows a
+// 256-B bank row holds four rows; F sends the four row-quads a ds_read_b128 lane group touches to four different chunk columns).
+// Operand roles, zero padding by out-of-range buffer offsets and the epilogue (bias, time-embedding row, activation, residual, fp16 stores
+// widened by v_permlane16_swap, GroupNorm column statistics per 64-row block) are those of pv_gemm.hip.
 #include "pv_gemm_dev.h"
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int ROW_BYTES = BK * 2;
+constexpr int BK = 32;
+constexpr int ROW_BYTES = BK * 2;                   // 64 B per LDS row
 constexpr int BM = 256, BN = 320, NW = 8;
 constexpr int MI = 8, NF = 5;                       // per wave: 128 rows x 80 columns = 8 x 5 fragments of 16 x 16
-constexpr int AP = BM / 8 / NW;                     // 4 activation pieces per wave and stage
-constexpr int BP = BN / 8 / NW;                     // 5 weight pieces per wave and stage
+constexpr int NBUF = 4;                             // ring: three stages in flight, one being read
+constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;   // 16-row LDS-DMA pieces per stage: 16 + 20
+constexpr int AP = A_PIECES / NW;                   // 2 activation pieces per wave and stage
+constexpr int BP = (B_PIECES + NW - 1) / NW;        // 3 weight pieces for waves 0-3, 2 for waves 4-7
 constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;      // 72 KiB
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;         // 144 KiB: one workgroup per CU
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;      // 36 KiB
+constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;      // 144 KiB: one workgroup per CU
 
 __device__ __forceinline__ float epi_act(float x, int act) {
     if (act == PV_ACT_SILU) return pv_silu(x);
@@ -38,9 +49,8 @@ __device__ __forceinline__ float epi_act(float x, int act) {
     return x;
 }
 
-__device__ __forceinline__ half8_t lds_frag(const char* base, int row, int chunk) {
-    return *reinterpret_cast<const half8_t*>(base + row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
-}
+// chunk swizzle of the 64-B-row image: F[(row >> 2) & 3], F = {0, 2, 3, 1}
+__device__ __forceinline__ int swz(int rq) { return (0x78 >> (2 * rq)) & 3; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -68,11 +78,11 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int cin = p.c0 + p.c1;
     const int K = 9 * cin;
-    const int nk = K / BK;
+    const int ns = K / BK;                           // stages: two per (64-channel chunk, tap)
 
-    // ---- staging geometry (pv_gemm.hip, fast conv path: stride 1, pad 1, hin == hout) ----
-    const int lrow = lane >> 3;
-    const int lane_cc2 = ((lane & 7) ^ lrow) * 16;
+    // ---- staging geometry (pv_gemm.hip's fast conv path: stride 1, pad 1, hin == hout) ----
+    const int prow = lane >> 2;                      // row inside a 16-row piece
+    const int lane_cc2 = ((lane & 3) ^ swz((lane >> 4) & 3)) * 16;   // swizzled source chunk: byte offset inside the 32-channel slab
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     unsigned a_off0[AP], a_off1[AP], a_mask[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + (wave + i * NW) * 8 + lrow;
+        const int m = m0 + (wave + i * NW) * 16 + prow;
         const bool ok = m < p.M;
         const int b = m / hw_out;
         const int rem = m - b * hw_out;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            if (ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win) mask |= 1u << t;
+            mask |= (ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win) ? 1u << t : 0u;
         }
         a_mask[i] = mask;
         const unsigned pix = (unsigned)((b * p.hin + y) * p.win + x);
@@ -99,30 +109,45 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     }
     unsigned w_off[BP];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) w_off[i] = (unsigned)(n0 + (wave + i * NW) * 8 + lrow) * (unsigned)(K * 2) + lane_cc2;
+    for (int i = 0; i < BP; ++i) w_off[i] = (unsigned)(n0 + min(wave + i * NW, B_PIECES - 1) * 16 + prow) * (unsigned)(K * 2) + lane_cc2;
+    const bool b_full = wave + (BP - 1) * NW < B_PIECES;          // waves 0-3 (wm == 0) issue a third weight piece
+    static_assert(B_PIECES - (BP - 1) * NW == NW / 2, "the vmcnt bookkeeping below assumes b_full <=> wave < 4 <=> wm == 0");
 
-    // pieces [J0, J1) of stage g (K-step g) into buffer g & 1; piece j < AP: activation piece j, else weight piece j - AP
-    auto issue = [&](int g, auto j0c, auto j1c) {
+    // K position of a stage: s -> (64-channel chunk, filter tap, 32-deep half), advanced incrementally in the loop (the closed form costs
+    // two divisions by constants = a dozen dependent scalar multiplies per stage in front of every LDS-DMA issue)
+    struct KPos { int s, chunk, tap, ky, kx; };
+    auto kpos_of = [&](int s) {
+        const int g = s >> 1, chunk = g / 9, tap = g - chunk * 9, ky = tap / 3;
+        return KPos{s, chunk, tap, ky, tap - ky * 3};
+    };
+    auto kpos_next = [&](KPos& k) {
+        if (k.s & 1) {                                 // second half done: next tap (kx fastest), then next chunk
+            ++k.tap; ++k.kx;
+            if (k.kx == 3) { k.kx = 0; ++k.ky; }
+            if (k.tap == 9) { k.tap = 0; k.ky = 0; ++k.chunk; }
+        }
+        ++k.s;
+    };
+    // pieces [J0, J1) of the stage at K position k into buffer k.s & 3; piece j < AP: activation piece j, else weight piece j - AP
+    auto issue = [&](const KPos& k, auto j0c, auto j1c) {
         constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-        char* sa = smem + (g & 1) * STAGE_BYTES;
+        char* sa = smem + (k.s & (NBUF - 1)) * STAGE_BYTES;
         char* sb = sa + A_BYTES;
-        const int chunk = g / 9;
-        const int tap = g - chunk * 9;
-        const int c = chunk * BK;
+        const int c = k.chunk * 64 + (k.s & 1) * BK;
         const bool first = c < p.c0;
         const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
         const int ld2 = (first ? p.lda0 : p.lda1) * 2;
         const int sc2 = (first ? c : c - p.c0) * 2;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int tap_delta = ((ky - 1) * p.win + (kx - 1)) * ld2 + sc2;
-        const unsigned wk2 = (unsigned)(tap * cin + c) * 2u;
+        const int tap_delta = ((k.ky - 1) * p.win + (k.kx - 1)) * ld2 + sc2;
+        const unsigned wk2 = (unsigned)(k.tap * cin + c) * 2u;
+        const unsigned tap_bit = 1u << k.tap;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
             if (j < AP) {
-                const unsigned off = ((a_mask[j] >> tap) & 1u) ? (first ? a_off0[j] : a_off1[j]) + (unsigned)tap_delta : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + j * NW) * 8 * ROW_BYTES), 16, (int)off, 0, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + (j - AP) * NW) * 8 * ROW_BYTES), 16, (int)(w_off[j - AP] + wk2), 0, 0, 0);
+                const unsigned off = (a_mask[j] & tap_bit) ? (first ? a_off0[j] : a_off1[j]) + (unsigned)tap_delta : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
+            } else if (j - AP < BP - 1 || b_full) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + (j - AP) * NW) * 16 * ROW_BYTES), 16, (int)(w_off[j - AP] + wk2), 0, 0, 0);
             }
         }
     };
@@ -137,91 +162,58 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     const int fr = lane & 15, fq = lane >> 4;
     const int arow = wm * (MI * 16) + fr;            // + mi * 16
     const int brow = wn * (NF * 16) + fr;            // + ni * 16
+    const int frag_off = fr * ROW_BYTES + ((fq ^ swz((fr >> 2) & 3)) << 4);   // fragment row bases are multiples of 16: the swizzle only sees fr
 
-    half8_t wb[2][NF], xa[2][2];
-    auto read_a = [&](half8_t (&dst)[2], int g, int ks, int grp) {
-        const char* sa = smem + (g & 1) * STAGE_BYTES;
-        dst[0] = lds_frag(sa, arow + (2 * grp) * 16, ks * 4 + fq);
-        dst[1] = lds_frag(sa, arow + (2 * grp + 1) * 16, ks * 4 + fq);
-    };
-    auto read_b = [&](half8_t& dst, int g, int ks, int ni) {
-        const char* sb = smem + (g & 1) * STAGE_BYTES + A_BYTES;
-        dst = lds_frag(sb, brow + ni * 16, ks * 4 + fq);
-    };
-
-    // ---- prologue: stage 0 whole, the first three pieces of stage 1 (the loop issues the rest), fragments of phase 0 ----
-    issue(0, IC<0>{}, IC<AP + BP>{});
-    if (nk > 1) {
-        issue(1, IC<0>{}, IC<3>{});
-        wait_vmcnt<3>();
-    } else {
-        wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_a(xa[0], 0, 0, 0);
+    half8_t wb[NF], xa[MI];
+    auto read_frags = [&](int s) {                   // all 13 fragments of stage s: 5 column (W) + 8 row (A)
+        const char* sa = smem + (s & (NBUF - 1)) * STAGE_BYTES + wm * (MI * 16) * ROW_BYTES + frag_off;
+        const char* sb = smem + (s & (NBUF - 1)) * STAGE_BYTES + A_BYTES + wn * (NF * 16) * ROW_BYTES + frag_off;
 #pragma unroll
-    for (int ni = 0; ni < NF; ++ni) read_b(wb[0][ni], 0, 0, ni);
-
-    for (int g = 0; g < nk; ++g) {
-        auto phase = [&](auto pc) {
-            constexpr int P = decltype(pc)::value;
-            constexpr int ks = P >> 2, grp = P & 3;
-            // ---- fragment reads of the next phase ----
-            if constexpr (P < 7) {
-                read_a(xa[(P + 1) & 1], g, (P + 1) >> 2, (P + 1) & 3);
-                if constexpr (P == 0) { read_b(wb[1][0], g, 1, 0); read_b(wb[1][1], g, 1, 1); }
-                if constexpr (P == 1) read_b(wb[1][2], g, 1, 2);
-                if constexpr (P == 2) read_b(wb[1][3], g, 1, 3);
-                if constexpr (P == 3) read_b(wb[1][4], g, 1, 4);
-            } else {
-                if (g + 1 < nk) {
-                    read_a(xa[0], g + 1, 0, 0);
+        for (int ni = 0; ni < NF; ++ni) wb[ni] = *reinterpret_cast<const half8_t*>(sb + ni * 16 * ROW_BYTES);
 #pragma unroll
-                    for (int ni = 0; ni < NF; ++ni) read_b(wb[0][ni], g + 1, 0, ni);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- 10 MFMAs, with this phase's share of the LDS-DMA issue between them ----
-            auto mma = [&](int t, int ni) {
-                acc[ni][2 * grp + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks][ni], xa[P & 1][t], acc[ni][2 * grp + t], 0, 0, 0);
-            };
-            constexpr bool DMA = (P == 7 || P == 0 || P == 1);
-            const int sg = (P == 7) ? g + 2 : g + 1;            // stage whose pieces this phase issues
-            const bool dma_on = DMA && sg < nk;
-            constexpr int J = (P == 7) ? 0 : (P == 0 ? 3 : 6);
-            mma(0, 0); mma(0, 1); mma(0, 2);
-            if constexpr (DMA) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (dma_on) issue(sg, IC<J>{}, IC<J + 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mma(0, 3); mma(0, 4); mma(1, 0);
-            if constexpr (DMA) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (dma_on) issue(sg, IC<J + 1>{}, IC<J + 2>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mma(1, 1); mma(1, 2);
-            if constexpr (DMA) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (dma_on) issue(sg, IC<J + 2>{}, IC<J + 3>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mma(1, 3); mma(1, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (P == 6) {
-                if (g + 1 < nk) {
-                    wait_vmcnt<0>();                                       // stage g+1 (issued a K-step ago) has landed
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last reads of buffer g & 1 (phase 7's fragments) are retired
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-            }
-        };
-        phase(IC<0>{}); phase(IC<1>{}); phase(IC<2>{}); phase(IC<3>{});
-        phase(IC<4>{}); phase(IC<5>{}); phase(IC<6>{}); phase(IC<7>{});
+        for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const half8_t*>(sa + mi * 16 * ROW_BYTES);
+    };
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // "stage s+1 landed" <=> at most the pieces of the two younger issued stages (s+2, s+3) are outstanding.  A wave counts its own pieces:
+    // AP + BP = 5 per stage for waves 0-3 (b_full <=> wm == 0), 4 for waves 4-7.  The last stages (nothing younger in flight) drain fully.
+    // ---- prologue: stages 0, 1, 2 (the LOAD segment of stage s issues stage s+3) ----
+    {
+        const int pre = min(ns, 3);
+        for (int s = 0; s < pre; ++s) issue(kpos_of(s), IC<0>{}, IC<AP + BP>{});
+        if (pre == 3) { if (b_full) wait_vmcnt<2 * (AP + BP)>(); else wait_vmcnt<2 * (AP + BP - 1)>(); }   // stage 0 landed
+        else wait_vmcnt<0>();
     }
+    seg_barrier();
+    if (wm == 1) seg_barrier();                      // the stagger: waves 4-7 run one barrier interval behind waves 0-3
+
+    KPos kn = kpos_of(3);                            // the stage the next LOAD segment issues
+    for (int s = 0; s < ns; ++s) {
+        // ---- LOAD(s): waves 0-3 in interval 2s, waves 4-7 in interval 2s+1 (after which buffer s & 3 is free: stage s+4 goes there) ----
+        read_frags(s);
+        if (s + 3 < ns) issue(kn, IC<0>{}, IC<AP + BP>{});
+        kpos_next(kn);
+        if (wm == 1) {                                           // waves 4-7: interval 2s+1 is the one in front of waves 0-3's LOAD(s+1)
+            if (s + 3 < ns) wait_vmcnt<2 * (AP + BP - 1)>(); else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers BEFORE the barrier: the buffer's reads are retired when it is refilled
+        seg_barrier();
+        // ---- MFMA(s): 40 MFMAs ----
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        if (wm == 0) {                                           // waves 0-3: stage s+1 is read right behind the next barrier
+            if (s + 3 < ns) wait_vmcnt<2 * (AP + BP)>(); else wait_vmcnt<0>();
+        }
+        seg_barrier();
+    }
+    if (wm == 0) seg_barrier();                      // waves 0-3 execute as many barriers as waves 4-7
 
     // ---- epilogue (pv_gemm.hip's, one 64-row block of the wave's 128 rows at a time) ----
     const int nbase = n0 + wn * (NF * 16) + fq * 4;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: shader-clock stamps of one workgroup of pv_convbig.hip's 256 x 320 kernel (stamped COPY, private library):
-entry | prologue | main loop | epilogue, the eight phases of one K-step (GC_STEP, default 20) with the wait + barrier behind phase 6,
+entry | prologue | main loop | epilogue, the eight phases of one 64-deep K-step (GC_STEP, default 20) with the wait + barrier of its two stages,
 and the in-kernel clock (s_memtime / s_memrealtime).  conv 320 -> 320 @ 64x64, B = 16."""
 import ctypes, os, subprocess, sys
 import torch
@@ -13,23 +13,26 @@ s = s.replace('#include "pv_gemm_dev.h"', '#include "%s"\n__device__ unsigned lo
               '#define STAMP(i) do { if (blockIdx.x == %s && (threadIdx.x & 255) == 0) gc_stamps[(i) + 32 * (threadIdx.x >> 8)] = __builtin_amdgcn_s_memtime(); } while (0)\n'
               '#define RSTAMP(i) do { if (blockIdx.x == %s && threadIdx.x == 0) gc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)'
               % (os.path.join(b.CSRC, "pv_gemm_dev.h"), os.environ.get("GC_BLOCK", "100"), os.environ.get("GC_BLOCK", "100")), 1)
-marks = [("    const int lane = pv_lane_id();\n    const int wave = pv_wave_id();\n    const int bid = pv_xcd_remap", "    STAMP(0); RSTAMP(30);\n", True),
-         ("    for (int g = 0; g < nk; ++g) {\n", "    STAMP(1);\n", True),
-         ("    // ---- epilogue (pv_gemm.hip's", "    STAMP(2); RSTAMP(31);\n", True),
-         ("            constexpr int ks = P >> 2, grp = P & 3;\n", "            if (g == %s) STAMP(4 + P);\n" % STEP, False),
-         ("                    wait_vmcnt<0>();                                       // stage g+1", "                    if (g == %s) STAMP(12);\n" % STEP, True),
-         ("                    __builtin_amdgcn_s_barrier();\n                    asm volatile(\"\" ::: \"memory\");\n                }\n            }\n        };",
-          None, None)]
-for m, ins, before in marks[:5]:
-    assert s.count(m) == 1, (m, s.count(m))
-    s = s.replace(m, (ins + m) if before else (m + ins), 1)
-m = marks[5][0]
-assert s.count(m) == 1
-s = s.replace(m, m.replace("asm volatile(\"\" ::: \"memory\");\n", "asm volatile(\"\" ::: \"memory\");\n                    if (g == %s) STAMP(13);\n" % STEP), 1)
-# end of kernel: the closing brace of the hb loop is followed by the kernel's closing brace
+def sub1(s, old, new):
+    assert s.count(old) == 1, (old, s.count(old))
+    return s.replace(old, new, 1)
+
+
+s = sub1(s, "    const int lane = pv_lane_id();\n    const int wave = pv_wave_id();\n    const int bid = pv_xcd_remap", "    STAMP(0); RSTAMP(30);\n    const int lane = pv_lane_id();\n    const int wave = pv_wave_id();\n    const int bid = pv_xcd_remap")
+s = sub1(s, "    KPos kn = kpos_of(3);", "    STAMP(1);\n    KPos kn = kpos_of(3);")
+s = sub1(s, "        read_frags(s);\n", "        if (s == %s) STAMP(4);\n        read_frags(s);\n" % STEP)
+s = sub1(s, "    // ---- epilogue (pv_gemm.hip's", "    STAMP(2); RSTAMP(31);\n    // ---- epilogue (pv_gemm.hip's")
+# the four segment barriers of the loop body: stamp in front of and behind each
+body0, body1 = s.index("        if (s == %s) STAMP(4);" % STEP), s.index("    if (wm == 0) seg_barrier();")
+body = s[body0:body1]
+assert body.count("        seg_barrier();\n") == 2
+parts = body.split("        seg_barrier();\n")
+out = parts[0]
+for i in range(2):
+    out += "        if (s == %s) STAMP(%d);\n        seg_barrier();\n        if (s == %s) STAMP(%d);\n" % (STEP, 5 + 2 * i, STEP, 6 + 2 * i) + parts[i + 1]
+s = s[:body0] + out + s[body1:]
 tail = "                    *reinterpret_cast<float4_t*>(dst + p.N + ni * 16) = cq[ni];\n                }\n            }\n        }\n    }\n}"
-assert s.count(tail) == 1
-s = s.replace(tail, tail[:-1] + "    STAMP(3);\n}", 1)
+s = sub1(s, tail, tail[:-1] + "    STAMP(3);\n}")
 s += '\nextern "C" int pv_gc_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_stamps), 64 * 8); }\n'
 src, lib = "/tmp/pv_convbig_stamps.hip", "/tmp/libpv_diag_convbig.so"
 open(src, "w").write(s)
@@ -69,6 +72,5 @@ clk = (t[2] - t[0]) / max(t[31] - t[30], 1) * 100.0
 print(f"launch {e0.elapsed_time(e1) / 20 * 1e3:.1f} us (colstats={cs}); workgroup {os.environ.get('GC_BLOCK', '100')}; in-kernel clock {clk:.0f} MHz; shader cycles:")
 for half, label in ((0, "wave 0"), (32, "wave 4")):
     u = t[half:half + 32]
-    print(f" {label}: prologue {u[1] - u[0]:6d} | main loop (45 K-steps) {u[2] - u[1]:7d} = {(u[2] - u[1]) / 45:.0f} per K-step | epilogue {u[3] - u[2]:6d}")
-    ph = [u[4 + i + 1] - u[4 + i] for i in range(6)]
-    print(f"   K-step {STEP}: phases 0-5 {ph}, phase 6 MFMAs {u[12] - u[10]}, wait + barrier {u[13] - u[12]}, (phase 6 start -> phase 7 start {u[11] - u[10]})")
+    print(f" {label}: prologue {u[1] - u[0]:6d} | main loop (90 stages) {u[2] - u[1]:7d} = {(u[2] - u[1]) / 90:.0f} per stage | epilogue {u[3] - u[2]:6d}")
+    print(f"   stage {STEP}: LOAD {u[5] - u[4]} (+ barrier wait {u[6] - u[5]}) | MFMA {u[7] - u[6]} (+{u[8] - u[7]}) = {u[8] - u[4]} per 32-deep stage")
