@@ -1,4 +1,5 @@
-// pv_convbig: the 3x3 convolutions of the 64 x 64 level (M = B * 4096 output pixels, N = 320 / 640) on a 256 x 320 tile.
+// pv_convbig: the 3x3 convolutions whose launch fills the chip with 256 x 320 tiles - the 64 x 64 level (M = B * 4096 output pixels,
+// N = 320 / 640) and the two x2-upsampling convs (640 -> 640 onto 64 x 64, 1280 -> 1280 onto 32 x 32).
 //
 // Why a second conv kernel.  The 128 x 160 tile of pv_gemm.hip runs its main loop at the L2 -> LDS gather floor of the tile (DMA-only
 // build 94 us of 132 us, EXPERIMENTS.md): what moves it is bytes staged and read per flop.  This tile stages (256 + 320) rows per
@@ -68,7 +69,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <bool CS>
+template <bool CS, bool UPS>
 __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = pv_lane_id();
@@ -78,9 +79,15 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int cin = p.c0 + p.c1;
     const int K = 9 * cin;
-    const int ns = K / BK;                           // stages: two per (64-channel chunk, tap)
+    // split-K (pv_gemm.hip's partition: blockIdx.y owns the 64-deep K-steps [kb, kb + nk_per), fp32 partial slab, fixed-order reduce launch)
+    const int nk64 = K / 64;
+    const int nk_per = (nk64 + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb = (int)blockIdx.y * nk_per;
+    const int ns = 2 * max(0, min(nk64, kb + nk_per) - kb);   // stages of this workgroup: two per (64-channel chunk, tap); stage index s is relative to kb
 
-    // ---- staging geometry (pv_gemm.hip's fast conv path: stride 1, pad 1, hin == hout) ----
+    // ---- staging geometry: stride 1, pad 1; UPS: the logical input is the x2 nearest upsample of (hin, win), i.e. tap (ky, kx) of output
+    // pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1) - relative to the centre's source pixel (y >> 1, x >> 1) that is
+    // a row step of -1 / 0 (even y) or 0 / +1 (odd y) for ky = 0 / 2, likewise in x: the per-lane offset is the centre's plus two selects ----
     const int prow = lane >> 2;                      // row inside a 16-row piece
     const int lane_cc2 = ((lane & 3) ^ swz((lane >> 4) & 3)) * 16;   // swizzled source chunk: byte offset inside the 32-channel slab
     constexpr unsigned OOB = 0x80000000u;
@@ -96,14 +103,16 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
         const int b = m / hw_out;
         const int rem = m - b * hw_out;
         const int y = rem / p.wout, x = rem - y * p.wout;
+        const int hl = UPS ? 2 * p.hin : p.hin, wl = UPS ? 2 * p.win : p.win;       // logical input extent
         unsigned mask = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            mask |= (ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win) ? 1u << t : 0u;
+            mask |= (ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl) ? 1u << t : 0u;
         }
+        if (UPS) mask |= (unsigned)(y & 1) << 9 | (unsigned)(x & 1) << 10;          // parities select the tap's source step
         a_mask[i] = mask;
-        const unsigned pix = (unsigned)((b * p.hin + y) * p.win + x);
+        const unsigned pix = UPS ? (unsigned)((b * p.hin + (y >> 1)) * p.win + (x >> 1)) : (unsigned)((b * p.hin + y) * p.win + x);
         a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
         a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
     }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     // two divisions by constants = a dozen dependent scalar multiplies per stage in front of every LDS-DMA issue)
     struct KPos { int s, chunk, tap, ky, kx; };
     auto kpos_of = [&](int s) {
-        const int g = s >> 1, chunk = g / 9, tap = g - chunk * 9, ky = tap / 3;
+        const int g = kb + (s >> 1), chunk = g / 9, tap = g - chunk * 9, ky = tap / 3;
         return KPos{s, chunk, tap, ky, tap - ky * 3};
     };
     auto kpos_next = [&](KPos& k) {
@@ -139,12 +148,18 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
         const int ld2 = (first ? p.lda0 : p.lda1) * 2;
         const int sc2 = (first ? c : c - p.c0) * 2;
         const int tap_delta = ((k.ky - 1) * p.win + (k.kx - 1)) * ld2 + sc2;
+        // UPS: source step of this tap for even / odd output coordinates
+        const int oy_even = (k.ky == 0 ? -p.win : 0) * ld2, oy_odd = (k.ky == 2 ? p.win : 0) * ld2;
+        const int ox_even = (k.kx == 0 ? -1 : 0) * ld2, ox_odd = (k.kx == 2 ? 1 : 0) * ld2;
         const unsigned wk2 = (unsigned)(k.tap * cin + c) * 2u;
         const unsigned tap_bit = 1u << k.tap;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
             if (j < AP) {
-                const unsigned off = (a_mask[j] & tap_bit) ? (first ? a_off0[j] : a_off1[j]) + (unsigned)tap_delta : OOB;
+                unsigned off = first ? a_off0[j] : a_off1[j];
+                if (UPS) off += (unsigned)(((a_mask[j] >> 9) & 1u ? oy_odd : oy_even) + ((a_mask[j] >> 10) & 1u ? ox_odd : ox_even) + sc2);
+                else off += (unsigned)tap_delta;
+                off = (a_mask[j] & tap_bit) ? off : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
             } else if (j - AP < BP - 1 || b_full) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + (j - AP) * NW) * 16 * ROW_BYTES), 16, (int)(w_off[j - AP] + wk2), 0, 0, 0);
@@ -215,8 +230,19 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     }
     if (wm == 0) seg_barrier();                      // waves 0-3 execute as many barriers as waves 4-7
 
-    // ---- epilogue (pv_gemm.hip's, one 64-row block of the wave's 128 rows at a time) ----
     const int nbase = n0 + wn * (NF * 16) + fq * 4;
+    if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
+        float* slab = p.splitk_ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + arow + mi * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + nbase + ni * 16) = acc[ni][mi];
+        }
+        return;
+    }
+    // ---- epilogue (pv_gemm.hip's, one 64-row block of the wave's 128 rows at a time) ----
     float4_t bias_v[NF];
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni)
@@ -301,20 +327,22 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     }
 }
 
-template <bool CS>
+template <bool CS, bool UPS>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = conv_big_kernel<CS>;
+    auto kern = conv_big_kernel<CS, UPS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NW * 64), SMEM_BYTES, stream, p, tiles_n, tiles_m * tiles_n);
+    const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, splits), dim3(NW * 64), SMEM_BYTES, stream, p, tiles_n, tiles_m * tiles_n);
+    if (splits > 1) return pv_gemm_splitk_reduce_launch(p, splits, stream);
     return PV_CHECK_LAUNCH();
 }
 
@@ -326,10 +354,15 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     const char* env = getenv("PV_CONV_BIG");
     const int min_tiles = env ? atoi(env) : 256;
     if (min_tiles <= 0) return -1;
-    const bool shape_ok = p.taps == 9 && p.stride == 1 && !p.upsample && p.pad == 1 && p.hin == p.hout && p.win == p.wout && (p.N % BN) == 0 &&
-                          !p.out_f32 && !p.geglu && !(p.splitk > 1 && p.splitk_ws);
+    const int up = p.upsample ? 2 : 1;
+    const bool shape_ok = p.taps == 9 && p.stride == 1 && p.pad == 1 && p.hin * up == p.hout && p.win * up == p.wout && (p.N % BN) == 0 &&
+                          !p.geglu;
     if (!shape_ok) return -1;
-    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
-    if (tiles < min_tiles) return -1;
-    return p.colstats ? launch_big<true>(p, stream) : launch_big<false>(p, stream);
+    const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
+    if (splits == 1 && p.out_f32) return -1;                    // fp32 outputs exist only behind the reduce launch here
+    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN) * splits;   // workgroups: split-K launches (16 x 16 level) count their K slices
+    if (tiles < min_tiles || (splits > 1 && (9 * (p.c0 + p.c1) / 64) / splits < 8)) return -1;
+    const bool cs = p.colstats && splits == 1;                  // with split-K the reduce launch produces the column statistics
+    if (p.upsample) return cs ? launch_big<true, true>(p, stream) : launch_big<false, true>(p, stream);
+    return cs ? launch_big<true, false>(p, stream) : launch_big<false, false>(p, stream);
 }

@@ -539,8 +539,7 @@ int launch(const pv_gemm_params_dev& p, hipStream_t stream, int tpw = 1) {
     const int m_fast = order_env >= 0 ? order_env : ((wbytes > (3u << 20)) && tiles_n >= 8 ? 1 : 0);
     const int splits = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     hipLaunchKernelGGL(kern, dim3(nblk / tpw, splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, stream, p, tiles_n / tpw, nblk / tpw, m_fast, tpw);
-    if (splits > 1)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, stream, p, splits);
+    if (splits > 1) return pv_gemm_splitk_reduce_launch(p, splits, stream);
     return PV_CHECK_LAUNCH();
 }
 
@@ -585,6 +584,10 @@ int dispatch(const pv_gemm_params_dev& p, hipStream_t stream) {
 
 }  // namespace
 
+int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStream_t stream) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, stream, p, splits);
+    return PV_CHECK_LAUNCH();
+}
 
 extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     pv_gemm_params_dev p;

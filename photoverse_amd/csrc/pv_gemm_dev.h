@@ -7,6 +7,9 @@ struct pv_gemm_params_dev : pv_gemm_params {
     uint32_t a0_bytes, a1_bytes, w_bytes;
 };
 
-// pv_convbig.hip: 256 x 320 x 64 tile, one 8-wave workgroup per CU, for the 3x3 convs of the 64 x 64 level (stride 1, pad 1, no upsample,
-// no split-K, fp16 output).  Returns -1 when the shape is not one it takes (the caller falls back to the 128-row kernel), else a hipError_t.
+// pv_convbig.hip: 256 x 320 tile, one 8-wave workgroup per CU, for the stride-1 / pad-1 3x3 convs (optionally x2-upsampling) whose launch has
+// >= 256 such tiles (no split-K, fp16 output).  Returns -1 when the shape is not one it takes (the caller falls back to the 128-row kernel), else a hipError_t.
 int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream);
+
+// pv_gemm.hip: the fixed-order reduction of split-K slabs + GEMM epilogue (+ column statistics) as its own launch
+int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStream_t stream);

@@ -25,6 +25,8 @@ import os as _os
 #: split-K heuristic: split until about SPLITK_TARGET workgroups exist (2 per CU), at most SPLITK_MAX ways
 SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "4"))      # same-box sweep (bench, two branches): 4 -> 28.09, 8 -> 27.76, 3 -> 27.91, 2 -> 27.41 steps/s
 SPLITK_TARGET = int(_os.environ.get("PV_SPLITK_TARGET", "512"))
+#: K slices of a 3x3 conv that reaches one 256 x 320 tile per CU only with split-K (16 x 16 level: 64 tiles); 0 / 1 = keep the 128-row kernel there
+BIG_SPLITK = int(_os.environ.get("PV_CONV_BIG_SPLITK", "4"))
 
 
 class HipLaunchError(RuntimeError):
@@ -170,7 +172,17 @@ class Recorder:
         kdim = taps * (c0 + c1)
         bn = 128 if (geglu or N % 160) else 160
         tiles = ((M + 127) // 128) * (N // bn)
+        auto_splitk = splitk is None
         splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
+        # pv_convbig.hip's 256 x 320 tile on the 16 x 16 level: 64 tiles x BIG_SPLITK K-slices = one workgroup per CU (the 128-row kernel runs
+        # these convs as 256 tiles x 2 slices)
+        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
+        up = 2 if (conv is not None and geo[6]) else 1
+        big_shape = (conv is not None and big_min > 0 and geo[5] == 1 and geo[7] == 1 and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
+        tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
+        if (big_shape and auto_splitk and BIG_SPLITK > 1 and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
+                and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
+            splitk = BIG_SPLITK
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)
@@ -192,10 +204,8 @@ class Recorder:
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
                 f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
         # pv_convbig.hip's 256 x 320 tile (pv_conv_big_launch's rule): stride-1 / pad-1 3x3 convs whose launch has >= PV_CONV_BIG (256) such tiles
-        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
-        if (conv is not None and big_min > 0 and geo[5] == 1 and not geo[6] and geo[7] == 1 and geo[1:3] == geo[3:5] and N % 320 == 0 and not out_f32
-                and splitk == 1 and ((M + 255) // 256) * (N // 320) >= big_min):
-            name = f"conv_big_kernel<{'true' if cs is not None else 'false'}>"
+        if big_shape and not (out_f32 and splitk == 1) and tiles256 * splitk >= big_min and (splitk == 1 or (kdim // 64) // splitk >= 8):
+            name = f"conv_big_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 

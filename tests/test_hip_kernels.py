@@ -175,6 +175,38 @@ def test_conv3x3_dual_source_big_tile(rec_cls):
     assert rel_l2(out, ref) < 1e-3
 
 
+@pytest.mark.parametrize("B,c0,c1,cout,hin,splitk", [(4, 64, 0, 320, 32, None), (2, 64, 64, 640, 16, None), (8, 1280, 0, 1280, 16, 4), (2, 640, 640, 320, 16, 2)])
+def test_conv3x3_256x320_tile_upsample_and_splitk(rec_cls, monkeypatch, B, c0, c1, cout, hin, splitk):
+    """The x2-upsampling gather of pv_convbig.hip (source pixel of tap (ky, kx) = ((y + ky - 1) >> 1, (x + kx - 1) >> 1), selected per lane from the
+    output coordinate's parity) and its split-K form (fp32 slabs, pv_gemm.hip's K partition and reduce launch) vs fp32 torch and, bit for bit, vs
+    the 128-row kernel."""
+    ups = splitk is None
+    x0 = h16(B, c0, hin, hin, seed=91)
+    x1 = h16(B, c1, hin, hin, seed=92) if c1 else None
+    w = h16(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5, seed=93)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(94))
+    ho = hin * 2 if ups else hin
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * hin * hin, -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    outs, stats = {}, {}
+    for name, env in (("big", "1"), ("small", "0")):
+        monkeypatch.setenv("PV_CONV_BIG", env)
+        rec = rec_cls("cuda")
+        outs[name] = rec.gemm(rows(x0), wp, a1=rows(x1) if c1 else None, bias=bias.cuda(), colstats=True, splitk=splitk,
+                              conv=dict(batch=B, hin=hin, win=hin, hout=ho, wout=ho, upsample=int(ups)))
+        assert rec.tags[-1][0].startswith("conv_big_kernel" if name == "big" else "gemm_conv_kernel"), rec.tags[-1]
+        stats[name] = rec.colstats.get((outs[name].data_ptr(), B * ho * ho, cout))
+        rec.run()
+        torch.cuda.synchronize()
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(B * ho * ho, cout)
+    assert rel_l2(outs["big"], ref) < 1e-3
+    assert torch.equal(outs["big"], outs["small"])
+    assert stats["big"] is not None and torch.equal(stats["big"], stats["small"])
+
+
 @pytest.mark.parametrize("B,c0,c1,cout,h,extras", [(16, 64, 0, 320, 64, True), (16, 128, 64, 320, 64, False), (8, 64, 0, 640, 64, True), (1, 64, 0, 320, 24, True)])
 def test_conv3x3_256x320_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeypatch, B, c0, c1, cout, h, extras):
     """pv_convbig.hip (256 x 320 x 64 tile, one 8-wave workgroup per CU: the 3x3 convs of the 64 x 64 level) against fp32 torch AND, bit for bit,

@@ -243,6 +243,7 @@ conv("conv3 320->320 @64 s2", 320, 320, 64, stride=2)
 conv("conv3 640->640 @32", 640, 640, 32)
 conv("conv3 320->640 @32", 320, 640, 32)
 conv("conv3 640->640 @32 up", 640, 640, 32, ups=1)
+conv("conv3 1280->1280 @16 up", 1280, 1280, 16, ups=1)
 conv("conv3 1280->1280 @16", 1280, 1280, 16)
 conv("conv3 1280+1280->1280 @16", 1280, 1280, 16, c1=1280)
 conv("conv3 1280->1280 @8", 1280, 1280, 8)
