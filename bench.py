@@ -21,12 +21,23 @@ if ROOT not in sys.path:
 # analytic algorithmic FLOPs of one SD-v1.5 UNet forward per sample at 64x64 latents, P=1
 UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-DOMINANT_KERNEL = "gemm_conv_kernel<5, true, false, true, false, 4>"   # as rocprofv3 prints it (tags in photoverse_amd/ops.py)
+#: committed PMC summary `roofline.traffic` is read from (tools/profile_bench.py writes it together with the git blob hashes of the
+#: kernel sources it was measured on; bench.py reports `traffic_stale` when those differ from the sources in the tree)
+PMC_TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"
+KERNEL_SOURCES = ("photoverse_amd/csrc/pv_gemm.hip", "photoverse_amd/csrc/pv_convbig.hip")
+
+
+def git_blob_sha1(path):
+    """`git hash-object` of a file without git (the GPU box has no .git): sha1(b"blob <len>\0" + content)."""
+    import hashlib
+    with open(path, "rb") as fh:
+        data = fh.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def cpu_baseline(seconds_budget=40.0):
     """The oracle (fp32 eager restatement of the reference path) timed on the host cores: B=1, one denoising step
-    (2 UNet forwards + CFG + scheduler step).  One untimed warm-up step, then up to 3 timed steps while the budget lasts;
+    (2 UNet forwards + CFG + scheduler step).  One untimed warm-up step, then 2 timed steps and a third while the budget lasts;
     the MEDIAN is reported in bs=16-equivalent steps/s (measured B=1 rate / 16)."""
     import statistics
     import torch
@@ -45,7 +56,7 @@ def cpu_baseline(seconds_budget=40.0):
     denoise_ref(unet, noise, cond, uncond, guidance_scale=7.5, timesteps=1)          # warm-up (allocator, thread pool)
     warm_s = time.time() - t0
     times = []
-    while len(times) < 3 and (not times or (time.time() - t_begin) + warm_s < seconds_budget):
+    while len(times) < 3 and (len(times) < 2 or (time.time() - t_begin) + warm_s < seconds_budget):      # never fewer than two timed samples
         t0 = time.time()
         denoise_ref(unet, noise, cond, uncond, guidance_scale=7.5, timesteps=1)
         times.append(time.time() - t0)
@@ -374,11 +385,17 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the implicit-GEMM 3x3 conv instantiation (160-column tile, GroupNorm column statistics in the
-        # epilogue: every 3x3 conv of the 64x64 / 32x32 levels); replay exactly its launches of one step and
-        # time them with HIP events on the launch stream
-        dom = DOMINANT_KERNEL
-        subs = [e.rec.subset(lambda t: t[0] == dom) for e in loop.engines_u + loop.engines_c]
+        # dominant kernel = the launch symbol with the largest share of one step's algorithmic flops (round 4: conv_big_kernel<true, false>,
+        # the 256 x 320-tile 3x3 conv with GroupNorm column statistics of the 64x64 level; the runner-up is the 128-row instantiation that
+        # runs the 32x32 level); replay exactly its launches of one step and time them with HIP events on the launch stream
+        engines = loop.all_engines
+        by_kernel = {}
+        for e in engines:
+            for t in e.rec.tags:
+                by_kernel[t[0]] = by_kernel.get(t[0], 0.0) + t[1]
+        ranked = sorted(by_kernel, key=by_kernel.get, reverse=True)
+        dom = ranked[0]                                   # the launch symbol with the largest share of a step's algorithmic flops
+        subs = [e.rec.subset(lambda t: t[0] == dom) for e in engines]
         nl = sum(len(s) for s in subs)
         flops = sum(t[1] for s in subs for t in s.tags)
         stream = torch.cuda.current_stream()
@@ -397,19 +414,44 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         # HBM traffic of this kernel from the rocprofv3 PMC passes of the same command (tools/profile_bench.py; counters are
         # collected in their own runs, so the number is read from the committed summary, not measured in this process)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as fh:
                 pmc = json.load(fh)
-            traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), "profiles/r03_pmc_traffic.json: " + pmc.get("note", "")
+            if pmc.get("dominant_kernel") == dom:
+                traffic, traffic_src = pmc.get("dominant_hbm_bytes_per_launch"), PMC_TRAFFIC_FILE + ": " + pmc.get("note", "")
+                now = {k: git_blob_sha1(os.path.join(ROOT, k)) for k in KERNEL_SOURCES}
+                traffic_stale = pmc.get("source_blobs") != now       # the kernel sources changed since the counters were collected
+            else:
+                traffic_src = f"{PMC_TRAFFIC_FILE} holds {pmc.get('dominant_kernel')!r}, not this kernel: no traffic figure"
         except (OSError, ValueError):
             pass
+        # runner-up (same measurement), so that both conv instantiations are on the line
+        second = None
+        if len(ranked) > 1:
+            subs2 = [e.rec.subset(lambda t: t[0] == ranked[1]) for e in engines]
+            nl2, fl2 = sum(len(s_) for s_ in subs2), sum(t[1] for s_ in subs2 for t in s_.tags)
+            for s_ in subs2:
+                s_.run()
+            torch.cuda.synchronize()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            for _ in range(reps):
+                for s_ in subs2:
+                    s_.run()
+            f1.record(stream)
+            torch.cuda.synchronize()
+            ms2 = f0.elapsed_time(f1) / reps
+            second = {"kernel": ranked[1], "launches_per_step": nl2, "avg_launch_us": round(ms2 * 1e3 / nl2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1),
+                      "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                      "share_of_step_flops": round(fl2 / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
         algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl
-        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "measured": "HIP events around a back-to-back replay of this kernel's launches of one step on one stream "
                                 "(in the timed loop the uncond/cond forwards are two overlapping graph branches, so rocprof "
                                 "per-dispatch durations of the default run include co-scheduling; `--one-stream` is the matching run)",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                    "runner_up": second,
                     "algorithmic_bytes_per_launch": algo_bytes, "launches_per_step": nl,
                     "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
                     "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3),
@@ -439,29 +481,30 @@ def main():
             return e0.elapsed_time(e1) / reps
         levels, tot_ms, tot_fl, tot_n = {}, 0.0, 0.0, 0
         for C_ in (320, 640, 1280):
-            subs = [e.rec.subset_role(f"attn2:{C_}") for e in loop.engines_u + loop.engines_c]
+            subs = [e.rec.subset_role(f"attn2:{C_}") for e in loop.all_engines]
             nl = sum(len(s_) for s_ in subs)
             if not nl:
                 continue
             flops = sum(t[1] for s_ in subs for t in s_.tags)
             kinds = sorted({t[0] for s_ in subs for t in s_.tags})
             ms = time_subs(subs)
-            layers = sum(1 for s_ in subs for t in s_.tags if t[0].startswith("xattn_fused_kernel") or t[0] == "pv_cross_attention")
+            layers = sum(1 for s_ in subs for t in s_.tags if t[0].startswith("xattn_fused_kernel") or t[0] in ("pv_cross_attention", "xattn_lnq_kernel"))
             levels[str(C_)] = {"layers_per_step": layers, "launches_per_step": nl, "launches_per_layer": nl // max(layers, 1), "ms_per_step": round(ms, 4),
                                "us_per_layer": round(ms * 1e3 / max(layers, 1), 2), "achieved": round(flops / (ms * 1e-3) / 1e12, 1),
                                "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "kernels": kinds,
-                               "fused": any(k.startswith("xattn_fused_kernel") for k in kinds)}
+                               "fused": any(k.startswith("xattn_fused_kernel") for k in kinds), "head_parallel": "xattn_lnq_kernel" in kinds}
             tot_ms, tot_fl, tot_n = tot_ms + ms, tot_fl + flops, tot_n + layers
         if levels:
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             xfused = {"what": "attn2 branch of every transformer block: norm2 -> to_q -> text + image-token SDPA (two softmaxes) -> to_out + bias + "
-                              "residual; ONE launch (pv_cross_attention_fused) at C = 320 / d = 40 and C = 640 / d = 80, four launches at C = 1280 "
-                              "(16 x 256 rows = 32 row-owning workgroups for 256 CUs)",
+                              "residual; ONE launch (pv_cross_attention_fused) at C = 320 / d = 40 and C = 640 / d = 80; TWO at C = 1280 / d = 160: "
+                              "norm2 + to_q + both SDPAs head-parallel (pv_cross_attention_lnq: 128 rows x one head per workgroup, 256 workgroups "
+                              "on the 16 x 16 level) and to_out + bias + residual as a GEMM (round 3: four launches)",
                       "levels": levels, "all_layers": {"layers_per_step": tot_n, "ms_per_step": round(tot_ms, 4), "achieved": round(ach, 1),
                                                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "weighting": "sum of algorithmic flops / sum of time"},
                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "north_star_target_frac": 0.40,
                       "flops_counted": "algorithmic: 4 M C^2 (to_q + to_out) + 4 M (77 + P) C (both SDPA products), M = B * H * W of the level",
-                      "pmc": "profiles/r03_pmc_xfused.txt (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_BUSY_CYCLES of the fused kernel)"}
+                      "phase_roofline": "profiles/r04_xfused_phase_roofline.md", "pmc": "profiles/r03_pmc_xfused.txt (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_BUSY_CYCLES of the fused kernel)"}
 
     # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
     # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.

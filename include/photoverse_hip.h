@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 10
+#define PV_ABI_VERSION 11
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -279,6 +279,32 @@ int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt,
                      int32_t ldkip, int32_t ldvip, void* kimg, void* vimg, float* vnorm, int32_t batch,
                      int32_t heads, int32_t d, int32_t nt, int32_t nip, void* stream);
 int pv_xattn_fused_wo_slot(int32_t slot);
+
+/* ------------------------------------------------------------------------------------------
+ * The C = 1280 / d = 160 attn2 layers (16x16 and 8x8 levels): norm2 -> to_q -> dual-branch SDPA + fusion in ONE head-parallel
+ * launch (one workgroup = 128 query rows of ONE head); attn.to_out[0] + bias + the block's residual add follow as one pv_gemm_conv.
+ * Replaces pv_layernorm + pv_gemm_conv (to_q, attention_processor.py:297) + pv_cross_attention (:307-322, :392-420) - two launches
+ * per layer instead of four (the one-launch pv_cross_attention_fused exists for C = 320 / 640).
+ *   ctx[b, m, h*d:(h+1)*d] = w_text*softmax(q Kt^T/sqrt(d)) Vt + w_ip*softmax(q Kip^T/sqrt(d)) Vip,  q = to_q(LayerNorm(hs))[:, head h]
+ * norm2 is folded algebraically so that the GEMM reads the raw rows: to_q(LN(x)) = rstd * (wq . x - mean * wq_rowsum) + q_bias with
+ * wq = to_q.weight x diag(gamma) (fp16), wq_rowsum[n] = sum_k wq[n][k] (of the fp16 values), q_bias = to_q.weight . beta.
+ * d == 160; nt <= 80, nip <= 16; K / V rows as for pv_cross_attention.  (ABI 11)
+ */
+typedef struct pv_xattn_lnq_params {
+    const void* hs; int32_t ld_hs;             /* fp16 [batch*nq][heads*d]: block input (pre-norm2) */
+    int32_t ln; float ln_eps;                  /* ln != 0: LayerNorm statistics over the row, affine part folded by the caller */
+    const void* wq;                            /* fp16 [C][C] */
+    const float* q_bias;                       /* fp32 [C] or NULL */
+    const float* wq_rowsum;                    /* fp32 [C]; required when ln */
+    const void* kt; const void* vt; int32_t ldkt, ldvt;       /* text K / V rows [batch*nt] */
+    const void* kip; const void* vip; int32_t ldkip, ldvip;   /* image-token K / V rows [batch*nip] */
+    void* out; int32_t ldo;                    /* fp16 ctx [batch*nq][C] */
+    float* vnorm;                              /* [batch][heads][nip] to_v_ip_norm (:397) or NULL */
+    int32_t batch, nq, heads, d, nt, nip;
+    float w_text, w_ip;
+    const float* fusion;                       /* optional DEVICE pair overriding (w_text, w_ip), see pv_fusion_draw */
+} pv_xattn_lnq_params;
+int pv_cross_attention_lnq(const pv_xattn_lnq_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * pv_row_gemm: LayerNorm + Linear (+ GEGLU gate) for the K = 320 layers of the 64x64-level transformer blocks as ONE row-owning

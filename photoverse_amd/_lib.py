@@ -70,6 +70,13 @@ class XAttnFusedParams(C.Structure):
                 ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
 
 
+class XAttnLnqParams(C.Structure):
+    _fields_ = [("hs", c_void_p), ("ld_hs", c_int), ("ln", c_int), ("ln_eps", c_float), ("wq", c_void_p), ("q_bias", c_void_p), ("wq_rowsum", c_void_p),
+                ("kt", c_void_p), ("vt", c_void_p), ("ldkt", c_int), ("ldvt", c_int), ("kip", c_void_p), ("vip", c_void_p), ("ldkip", c_int), ("ldvip", c_int),
+                ("out", c_void_p), ("ldo", c_int), ("vnorm", c_void_p), ("batch", c_int), ("nq", c_int), ("heads", c_int), ("d", c_int), ("nt", c_int),
+                ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
+
+
 class RowGemmParams(C.Structure):
     _fields_ = [("x", c_void_p), ("ld_x", c_int), ("M", c_int), ("K", c_int), ("N", c_int), ("w", c_void_p), ("bias", c_void_p),
                 ("ln", c_int), ("ln_eps", c_float), ("geglu", c_int), ("out", c_void_p), ("ld_out", c_int)]
@@ -101,6 +108,7 @@ SIGNATURES = {
     "pv_attention": (c_int, [C.POINTER(AttnParams), c_void_p]),
     "pv_cross_attention": (c_int, [C.POINTER(XAttnParams), c_void_p]),
     "pv_cross_attention_fused": (c_int, [C.POINTER(XAttnFusedParams), c_void_p]),
+    "pv_cross_attention_lnq": (c_int, [C.POINTER(XAttnLnqParams), c_void_p]),
     "pv_xattn_pack_kv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_xattn_fused_wo_slot": (c_int, [c_int]),
@@ -156,7 +164,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

@@ -33,15 +33,20 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int ROW_BYTES = BK * 2;                   // 64 B per LDS row
-constexpr int BM = 256, BN = 320, NW = 8;
-constexpr int MI = 8, NF = 5;                       // per wave: 128 rows x 80 columns = 8 x 5 fragments of 16 x 16
+constexpr int BN = 320, NW = 8;
+constexpr int NF = 5;                               // per wave: (16 MI) rows x 80 columns = MI x 5 fragments of 16 x 16; MI = 8: 256-row tile, MI = 4: 128-row tile
 constexpr int NBUF = 4;                             // ring: three stages in flight, one being read
-constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;   // 16-row LDS-DMA pieces per stage: 16 + 20
-constexpr int AP = A_PIECES / NW;                   // 2 activation pieces per wave and stage
+constexpr int B_PIECES = BN / 16;                   // 16-row LDS-DMA pieces of the weight tile per stage: 20
 constexpr int BP = (B_PIECES + NW - 1) / NW;        // 3 weight pieces for waves 0-3, 2 for waves 4-7
-constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;      // 36 KiB
-constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;      // 144 KiB: one workgroup per CU
+constexpr int B_BYTES = BN * ROW_BYTES;
+template <int MI>
+struct BigCfg {
+    static constexpr int BM = 2 * MI * 16;              // two wave rows
+    static constexpr int AP = BM / 16 / NW;             // activation pieces per wave and stage: 2 (256 rows) / 1 (128 rows)
+    static constexpr int A_BYTES = BM * ROW_BYTES;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 36 KiB / 28 KiB
+    static constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;   // 144 KiB / 112 KiB: one workgroup per CU either way
+};
 
 __device__ __forceinline__ float epi_act(float x, int act) {
     if (act == PV_ACT_SILU) return pv_silu(x);
@@ -69,8 +74,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <bool CS, bool UPS>
+template <bool CS, bool UPS, int MI>
 __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
+    using Cfg = BigCfg<MI>;
+    constexpr int BM = Cfg::BM, AP = Cfg::AP, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
@@ -242,98 +249,116 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
         }
         return;
     }
-    // ---- epilogue (pv_gemm.hip's, one 64-row block of the wave's 128 rows at a time) ----
-    float4_t bias_v[NF];
-#pragma unroll
-    for (int ni = 0; ni < NF; ++ni)
-        bias_v[ni] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + ni * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+    // ---- epilogue (pv_gemm.hip's arithmetic; walked per 64-row block and per COLUMN GROUP - the fragment pairs (0,1), (2,3) and fragment 4 -
+    // so that next to the 160 accumulators only one group's bias, residual rows and column statistics are live: no scratch) ----
     const bool want_cs = CS && p.colstats != nullptr;
+    auto group = [&](int hb, auto g0c, auto gnc) {
+        constexpr int G0 = decltype(g0c)::value, GN = decltype(gnc)::value;     // fragments G0 .. G0 + GN - 1
+        float4_t add_v[GN];
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        half4_t res[NF][2];                      // residual rows fetched two row-fragments at a time: the first block still holds all 160 accumulators
-        float4_t cs[NF], cq[NF];
+        for (int t = 0; t < GN; ++t)
+            add_v[t] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (G0 + t) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        // time-embedding row: one per IMAGE.  When the block's 64 rows lie inside one image (always, for hw_out % 64 == 0) it is loaded once
+        // (added AFTER the bias, per element, as pv_gemm.hip does: the results stay bit-identical)
+        const int mb0 = m0 + wm * (MI * 16) + hb * 64;
+        const bool one_image = p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);
+        float4_t radd_v[GN];
 #pragma unroll
-        for (int ni = 0; ni < NF; ++ni) cs[ni] = cq[ni] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < GN; ++t)
+            radd_v[t] = one_image ? *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(mb0 / hw_out) * p.rowadd_ld + nbase + (G0 + t) * 16)
+                                  : float4_t{0.f, 0.f, 0.f, 0.f};
+        half4_t res[4][GN];
+        if (p.residual) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mm = min(m0 + arow + (hb * 4 + q) * 16, p.M - 1);
+#pragma unroll
+                for (int t = 0; t < GN; ++t)
+                    res[q][t] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + (G0 + t) * 16);
+            }
+        }
+        float4_t cs[GN], cq[GN];
+#pragma unroll
+        for (int t = 0; t < GN; ++t) cs[t] = cq[t] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mi = hb * 4 + q;
-            if (p.residual && (q & 1) == 0) {
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int mm = min(m0 + arow + (mi + q2) * 16, p.M - 1);
-#pragma unroll
-                    for (int ni = 0; ni < NF; ++ni)
-                        res[ni][q2] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + ni * 16);
-                }
-            }
             const int m = m0 + arow + mi * 16;
             if (m >= p.M) continue;
-            const float* radd = p.rowadd ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
-            unsigned pk[NF][2];
+            const float* radd = (p.rowadd && !one_image) ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
+            unsigned pk[GN][2];
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni) {
-                float4_t v = acc[ni][mi] + bias_v[ni];
-                if (radd) v += *reinterpret_cast<const float4_t*>(radd + ni * 16);
+            for (int t = 0; t < GN; ++t) {
+                float4_t v = acc[G0 + t][mi] + add_v[t];
+                if (one_image) v += radd_v[t];
+                else if (radd) v += *reinterpret_cast<const float4_t*>(radd + (G0 + t) * 16);
                 if (p.act) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
                 }
                 if (p.residual) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)res[ni][q & 1][r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[q][t][r];
                 }
                 const half4_t hv = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                pk[ni][0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
-                pk[ni][1] = __builtin_bit_cast(unsigned, half2_t{hv[2], hv[3]});
+                pk[t][0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
+                pk[t][1] = __builtin_bit_cast(unsigned, half2_t{hv[2], hv[3]});
                 if (want_cs) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float f = (float)hv[r];
-                        cs[ni][r] += f;
-                        cq[ni][r] += f * f;
+                        cs[t][r] += f;
+                        cq[t][r] += f * f;
                     }
                 }
             }
             half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n0 + wn * (NF * 16);
-#pragma unroll
-            for (int h = 0; h < NF / 2; ++h) {
-                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * h][0], pk[2 * h + 1][0], false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * h][1], pk[2 * h + 1][1], false, false);
+            if constexpr (GN == 2) {      // 16-byte stores: v_permlane16_swap trades the even lane rows' second fragment against the odd lane rows' first
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                 const unsigned a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
-                const int col = (fq & 1) ? (2 * h + 1) * 16 + (fq - 1) * 4 : (2 * h) * 16 + fq * 4;
+                const int col = (fq & 1) ? (G0 + 1) * 16 + (fq - 1) * 4 : G0 * 16 + fq * 4;
                 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
                 *reinterpret_cast<uint4_t*>(orow + col) = uint4_t{a0, a1, b0, b1};
+            } else {
+                typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<uint2_t*>(orow + G0 * 16 + fq * 4) = uint2_t{pk[0][0], pk[0][1]};
             }
-            typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<uint2_t*>(orow + (NF - 1) * 16 + fq * 4) = uint2_t{pk[NF - 1][0], pk[NF - 1][1]};
         }
-        if (want_cs && m0 + wm * (MI * 16) + hb * 64 < p.M) {
+        if (want_cs && mb0 < p.M) {
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni)
+            for (int t = 0; t < GN; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    cs[ni][r] = row16_sum(cs[ni][r]);
-                    cq[ni][r] = row16_sum(cq[ni][r]);
+                    cs[t][r] = row16_sum(cs[t][r]);
+                    cq[t][r] = row16_sum(cq[t][r]);
                 }
             if (fr == 0) {
-                float* dst = p.colstats + ((size_t)(m0 / 64 + wm * 2 + hb) * 2) * p.N + nbase;
+                float* dst = p.colstats + ((size_t)(m0 / 64 + wm * (MI / 4) + hb) * 2) * p.N + nbase;
 #pragma unroll
-                for (int ni = 0; ni < NF; ++ni) {
-                    *reinterpret_cast<float4_t*>(dst + ni * 16) = cs[ni];
-                    *reinterpret_cast<float4_t*>(dst + p.N + ni * 16) = cq[ni];
+                for (int t = 0; t < GN; ++t) {
+                    *reinterpret_cast<float4_t*>(dst + (G0 + t) * 16) = cs[t];
+                    *reinterpret_cast<float4_t*>(dst + p.N + (G0 + t) * 16) = cq[t];
                 }
             }
         }
+    };
+#pragma unroll
+    for (int hb = 0; hb < MI / 4; ++hb) {
+        group(hb, IC<0>{}, IC<2>{});
+        group(hb, IC<2>{}, IC<2>{});
+        group(hb, IC<4>{}, IC<1>{});
     }
 }
 
-template <bool CS, bool UPS>
+template <bool CS, bool UPS, int MI>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
+    constexpr int BM = BigCfg<MI>::BM, SMEM_BYTES = BigCfg<MI>::SMEM_BYTES;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = conv_big_kernel<CS, UPS>;
+    auto kern = conv_big_kernel<CS, UPS, MI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -360,9 +385,13 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     if (!shape_ok) return -1;
     const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     if (splits == 1 && p.out_f32) return -1;                    // fp32 outputs exist only behind the reduce launch here
-    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN) * splits;   // workgroups: split-K launches (16 x 16 level) count their K slices
-    if (tiles < min_tiles || (splits > 1 && (9 * (p.c0 + p.c1) / 64) / splits < 8)) return -1;
+    if (splits > 1 && (9 * (p.c0 + p.c1) / 64) / splits < 8) return -1;
+    // workgroups: split-K launches (16 x 16 level) count their K slices.  (A 128-row form of this tile - MI = 4, 128 x 2 tiles on the 32 x 32 level -
+    // was built and measured in round 4: bit-identical, but 142 vs 127 us on conv 640 -> 640 @32 and -2.3 % in the loop: at 91 flop / B it is bound
+    // by the L2 -> LDS stream like the 128 x 160 kernel, without that kernel's two independent workgroups per CU.  EXPERIMENTS.md.)
+    const long tiles256 = (long)((p.M + 255) / 256) * (p.N / BN) * splits;
+    if (tiles256 < min_tiles) return -1;
     const bool cs = p.colstats && splits == 1;                  // with split-K the reduce launch produces the column statistics
-    if (p.upsample) return cs ? launch_big<true, true>(p, stream) : launch_big<false, true>(p, stream);
-    return cs ? launch_big<true, false>(p, stream) : launch_big<false, false>(p, stream);
+    if (p.upsample) return cs ? launch_big<true, true, 8>(p, stream) : launch_big<false, true, 8>(p, stream);
+    return cs ? launch_big<true, false, 8>(p, stream) : launch_big<false, false, 8>(p, stream);
 }

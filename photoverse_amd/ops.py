@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import (AttnBwdParams, AttnParams, GemmParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
-                   XAttnBwdParams, XAttnFusedParams, XAttnParams)
+                   XAttnBwdParams, XAttnFusedParams, XAttnLnqParams, XAttnParams)
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
@@ -121,6 +121,18 @@ class Recorder:
         r.roles, r.role = [self.roles[i] for i in sel], None
         return r
 
+    @staticmethod
+    def concat(*recs: "Recorder") -> "Recorder":
+        """A recorder that replays the calls of ``recs`` one after the other (shares their buffers): introspection / timing of a plan that was
+        recorded in several segments."""
+        r = recs[0].subset(lambda t: False)
+        r.keep = list(recs)
+        for x in recs:
+            r.calls += x.calls
+            r.tags += x.tags
+            r.roles += x.roles
+        return r
+
     def subset_role(self, role: str) -> "Recorder":
         """The calls recorded under ``self.role == role`` (e.g. the attn2 branch of one channel width), for per-branch timing."""
         r = self.subset(lambda t: True)
@@ -142,7 +154,7 @@ class Recorder:
     def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
              rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
              out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None,
-             colstats: bool = False) -> torch.Tensor:
+             colstats: bool = False, colstats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin].
         ``colstats``: the output feeds a GroupNorm - let the epilogue leave its per-column (sum, sum of squares) behind so that
         ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: fp32, GEGLU; with split-K the
@@ -180,14 +192,16 @@ class Recorder:
         up = 2 if (conv is not None and geo[6]) else 1
         big_shape = (conv is not None and big_min > 0 and geo[5] == 1 and geo[7] == 1 and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
         tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
-        if (big_shape and auto_splitk and BIG_SPLITK > 1 and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
+        if (big_shape and auto_splitk and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
                 and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
             splitk = BIG_SPLITK
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)
         if colstats and not geglu and not out_f32 and ldc == n_out and not _NO_COLSTATS:
-            cs = self.colstats[key] = self.empty(((M + 63) // 64, 2, N), torch.float32)
+            # ``colstats_out``: caller-owned statistics buffer (an output written in halves by two plans: pipeline.DenoiseLoop's low-resolution merge)
+            cs = self.colstats[key] = colstats_out if colstats_out is not None else self.empty(((M + 63) // 64, 2, N), torch.float32)
+            assert cs.shape == ((M + 63) // 64, 2, N) and cs.dtype == torch.float32 and cs.is_contiguous()
         else:
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
@@ -204,8 +218,9 @@ class Recorder:
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
                 f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
         # pv_convbig.hip's 256 x 320 tile (pv_conv_big_launch's rule): stride-1 / pad-1 3x3 convs whose launch has >= PV_CONV_BIG (256) such tiles
-        if big_shape and not (out_f32 and splitk == 1) and tiles256 * splitk >= big_min and (splitk == 1 or (kdim // 64) // splitk >= 8):
-            name = f"conv_big_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}>"
+        if big_shape and not (out_f32 and splitk == 1) and (splitk == 1 or (kdim // 64) // splitk >= 8):
+            if tiles256 * splitk >= big_min:
+                name = f"conv_big_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 
@@ -429,6 +444,37 @@ class Recorder:
                         _ptr(fusion))
         self.keep.extend(t for t in (q, kt, vt, kip, vip, out, vnorm, fusion) if t is not None)
         self._add(self.lib.pv_cross_attention, p, tag=("pv_cross_attention", 4.0 * batch * nq * (nt + nip) * heads * d, 2.0 * 2 * batch * nq * heads * d))
+        return out, p
+
+    # ---- attn2 branch of the C = 1280 / d = 160 layers: norm2 -> to_q -> dual-branch SDPA as ONE head-parallel launch (pv_xq.hip) ----
+    XLNQ = os.environ.get("PV_XLNQ", "1") != "0"          # A/B switch
+
+    @staticmethod
+    def xattn_lnq_supported(C: int, heads: int, nt: int, nip: int) -> bool:
+        return Recorder.XLNQ and heads * 160 == C and 0 < nt <= 80 and 0 <= nip <= 16
+
+    def cross_attention_lnq(self, hs, wq, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d=160, ln_gamma=None, ln_beta=None, ln_eps=1e-5,
+                            w_text=1.0, w_ip=1.0, vnorm=None, fusion=None, out=None):
+        """``ctx = SDPA_dual(to_q(LayerNorm(hs)), K, V)`` per head; ``wq``: to_q.weight fp16 [C][C].  norm2 is folded at plan-build time so
+        that the kernel's GEMM reads the raw rows: gamma scales the columns of wq, ``q_bias = wq . beta``, and the kernel corrects with the
+        row statistics it accumulates itself: ``rstd * (wq' . x - mean * rowsum(wq')) + q_bias``."""
+        C = heads * d
+        assert hs.shape[1] == C and wq.shape == (C, C) and wq.dtype == torch.float16
+        if out is None:
+            out = self.empty((batch * nq, C), torch.float16)
+        q_bias = rowsum = None
+        if ln_gamma is not None:
+            w32 = wq.float()
+            q_bias = (w32 @ ln_beta.float().to(wq.device)).contiguous()
+            wq = (w32 * ln_gamma.float().to(wq.device)[None, :]).to(torch.float16)
+            rowsum = wq.float().sum(1).contiguous()          # of the fp16 values the MFMAs see
+        wq = wq.contiguous()
+        p = XAttnLnqParams(_ptr(hs), _rows(hs)[0], int(ln_gamma is not None), float(ln_eps), _ptr(wq), _ptr(q_bias), _ptr(rowsum), _ptr(kt), _ptr(vt),
+                           _rows(kt)[0], _rows(vt)[0], _ptr(kip), _ptr(vip), _rows(kip)[0] if kip is not None else 0, _rows(vip)[0] if vip is not None else 0,
+                           _ptr(out), _rows(out)[0], _ptr(vnorm), batch, nq, heads, d, nt, nip, float(w_text), float(w_ip), _ptr(fusion))
+        self.keep.extend(t for t in (hs, wq, q_bias, rowsum, kt, vt, kip, vip, out, vnorm, fusion) if t is not None)
+        M = batch * nq
+        self._add(self.lib.pv_cross_attention_lnq, p, tag=("xattn_lnq_kernel", 2.0 * M * C * C + 4.0 * M * (nt + nip) * C, 2.0 * (2 * M * C + C * C)))
         return out, p
 
     # ---- fused attn2 branch (norm2 -> to_q -> dual-branch SDPA -> to_out + residual): C = 320 / d = 40 and C = 640 / d = 80 layers ----

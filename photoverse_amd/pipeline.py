@@ -10,6 +10,7 @@ with no communication inside the loop; final latents are collected with ONE ``al
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -21,11 +22,17 @@ from .scheduler import DPMSolverMultistepScheduler
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
-                 two_streams: bool = True, batch_splits: int = 1, training_mode: bool = False, fusion_seed: int = 0):
+                 two_streams: bool = True, batch_splits: int = 1, training_mode: bool = False, fusion_seed: int = 0,
+                 merge_lowres: Optional[bool] = None):
         """``training_mode``: the reference enables grad on the LAST denoising step only (infer.py:99), where every cross-attention
         layer of both forwards then draws its branch fusion (attention_processor.py:413-420).  Here the draw runs on the device inside
         the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps.  This is the forward semantics
-        of that mode; the differentiated last step lives in ``train.TrainStep(face_loss=...)``."""
+        of that mode; the differentiated last step lives in ``train.TrainStep(face_loss=...)``.
+
+        ``merge_lowres`` (default: env ``PV_MERGE_LOWRES``, on): the two CFG forwards (infer.py:103-114) run their two highest-resolution levels
+        as two parallel graph branches, but everything below (16 x 16 and 8 x 8 levels, mid block) as ONE plan over both branches' samples:
+        at M = B * 256 / B * 64 rows a single branch cannot fill the chip without split-K (fp32 slabs + a reduce launch per conv) and both
+        branches stream the same 29.5 MB of weights per conv.  Samples never interact inside the UNet, so the result per sample is unchanged."""
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
@@ -49,6 +56,7 @@ class DenoiseLoop:
         self.text_u = torch.zeros_like(self.text_c)
         self.ip_c = torch.zeros((batch * n_ip, xdim), dtype=f16, device=dev)
         self.ip_u = torch.zeros_like(self.ip_c)
+        self.two_streams = two_streams
         # Engines: one per (CFG branch, sub-batch).  batch_splits > 1 cuts each forward into independent sub-batches (samples
         # never interact inside the UNet) that run as additional parallel graph branches.
         if batch % batch_splits:
@@ -56,8 +64,35 @@ class DenoiseLoop:
         sb = batch // batch_splits
         self.eps_u = torch.empty_like(self.latents)
         self.eps_c = torch.empty_like(self.latents)
-        self.engines_u, self.engines_c = [], []
-        for i in range(batch_splits):
+        self.engines_u, self.engines_c, self.engines_m = [], [], []
+        if merge_lowres is None:
+            merge_lowres = os.environ.get("PV_MERGE_LOWRES", "1") != "0"
+        n_lv = len(cfg.block_out_channels)
+        split = 2
+        self.merge_lowres = bool(merge_lowres and not training_mode and batch_splits == 1 and n_lv > split
+                                 and ((latent_size >> split) ** 2) % 64 == 0 and latent_size % (1 << (n_lv - 1)) == 0)
+        if self.merge_lowres:
+            # text / image-token buffers of the two branches are the halves of ONE buffer: the merged plan reads it whole
+            text_all = torch.zeros((2 * batch * n_text, xdim), dtype=f16, device=dev)
+            ip_all = torch.zeros((2 * batch * n_ip, xdim), dtype=f16, device=dev)
+            self.text_u, self.text_c = text_all[:batch * n_text], text_all[batch * n_text:]
+            self.ip_u, self.ip_c = ip_all[:batch * n_ip], ip_all[batch * n_ip:]
+            boc = cfg.block_out_channels
+            n_in, n_out = (latent_size >> split) ** 2, (latent_size >> (split - 1)) ** 2       # pixels per sample at the two seams
+            c_in, c_out = boc[split - 1], boc[split]           # downsampler of level split-1 keeps its width; upsampler of the first merged up block
+            mid_in = torch.empty((2 * batch * n_in, c_in), dtype=f16, device=dev)
+            mid_in_cs = torch.zeros((2 * batch * n_in // 64, 2, c_in), dtype=f32, device=dev)
+            mid_out = torch.empty((2 * batch * n_out, c_out), dtype=f16, device=dev)
+            mid_out_cs = torch.zeros((2 * batch * n_out // 64, 2, c_out), dtype=f32, device=dev)
+            kw = dict(timesteps=self.timesteps, state=self.state, n_text=n_text, split=split)
+            for i, (text, ip, eps, lst) in enumerate(((self.text_u, self.ip_u, self.eps_u, self.engines_u), (self.text_c, self.ip_c, self.eps_c, self.engines_c))):
+                half_in = (mid_in[i * batch * n_in:(i + 1) * batch * n_in], mid_in_cs[i * batch * n_in // 64:(i + 1) * batch * n_in // 64])
+                half_out = (mid_out[i * batch * n_out:(i + 1) * batch * n_out], mid_out_cs[i * batch * n_out // 64:(i + 1) * batch * n_out // 64])
+                lst.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, text=text, ip=ip, out=eps, segment="outer",
+                                       mid_in=half_in, mid_out=half_out, **kw))
+            self.engines_m.append(unet.engine(2 * batch, latent_size, latent_size, n_ip, 1, text=text_all, ip=ip_all, segment="mid",
+                                              mid_in=(mid_in, mid_in_cs), mid_out=(mid_out, mid_out_cs), **kw))
+        for i in range(0 if self.merge_lowres else batch_splits):
             sl = slice(i * sb, (i + 1) * sb)
             kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text)
             if training_mode:
@@ -77,7 +112,12 @@ class DenoiseLoop:
         self.two_streams = two_streams
         n_side = (2 * batch_splits - 1) if two_streams else 0
         self._sides = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
-        self.launches_per_step = sum(len(e.rec) for e in self.engines_u + self.engines_c) + len(self.tail)
+        self.launches_per_step = sum(len(e.rec) for e in self.all_engines) + len(self.tail)
+
+    @property
+    def all_engines(self):
+        """Every plan of a step (uncond / cond branches and, with ``merge_lowres``, the merged low-resolution part)."""
+        return self.engines_u + self.engines_c + self.engines_m
 
     # ------------------------------------------------------------------
     def set_conditioning(self, cond: Tuple[torch.Tensor, torch.Tensor], uncond: Tuple[torch.Tensor, torch.Tensor]):
@@ -87,7 +127,7 @@ class DenoiseLoop:
             dt.copy_(text.reshape(dt.shape))
             di.copy_(ip.reshape(di.shape))
         # K/V projections of the conditioning: once per generation, outside the per-step graph
-        for e in self.engines_u + self.engines_c:
+        for e in self.all_engines:
             e.run_conditioning()
 
     def reset(self, noise: torch.Tensor):
@@ -98,6 +138,32 @@ class DenoiseLoop:
         self._host_step = 0
 
     def _step_eager(self):
+        if self.merge_lowres:
+            # head_u || head_c -> merged low-resolution part (both branches' samples as one batch) -> tail_u || tail_c -> CFG + solver step
+            (eu,), (ec,), (em,) = self.engines_u, self.engines_c, self.engines_m
+            main = torch.cuda.current_stream()
+            side = self._sides[0] if self.two_streams else None
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ec.rec_head.run()
+                eu.rec_head.run()
+                main.wait_stream(side)
+            else:
+                eu.rec_head.run()
+                ec.rec_head.run()
+            em.rec.run()
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ec.rec_tail.run()
+                eu.rec_tail.run()
+                main.wait_stream(side)
+            else:
+                eu.rec_tail.run()
+                ec.rec_tail.run()
+            self.tail.run()
+            return
         if self.two_streams:
             # the unconditional and conditional forwards are independent until the CFG combine: fork them onto two HIP
             # streams (two parallel branches of the captured graph) so the small low-resolution launches of one overlap

@@ -194,14 +194,28 @@ class UNetEngine:
                  timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
                  latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
                  ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, device_fusion: Optional[str] = None,
-                 fusion_seed: int = 0):
+                 fusion_seed: int = 0, segment: Optional[str] = None, split: int = 2, mid_in=None, mid_out=None):
         """``device_fusion``: None - branch weights (w_text, w_ip) are launch parameters patched by the host (``_set_fusion``);
         ``"always"`` - every forward draws them on the device (grad-mode semantics of attention_processor.py:413-420, graph-safe);
         ``"last_step"`` - drawn only when the loop state says this is the last denoising step (``run_inference(training_mode=True)``,
-        infer.py:99), (1, 1) otherwise."""
+        infer.py:99), (1, 1) otherwise.
+
+        ``segment`` (pipeline.DenoiseLoop's low-resolution CFG merge): the forward as THREE plans.  ``"outer"`` records the first ``split``
+        resolution levels of the down path into ``rec_head`` (its last launch, the level's downsampling conv, writes into ``mid_in`` = (tensor,
+        column statistics): this branch's half of a buffer shared with the other CFG branch) and the matching last ``split`` up blocks + conv_out
+        into ``rec_tail`` (starting from ``mid_out`` = this branch's half of the merged part's output); ``"mid"`` records everything in
+        between at batch = BOTH branches (``mid_in`` / ``mid_out`` = the whole shared buffers)."""
         self.unet, self.B, self.H, self.W, self.P, self.NT = unet, batch, h, w, n_ip, n_text
+        if segment not in (None, "outer", "mid"):
+            raise ValueError("segment must be None, 'outer' or 'mid'")
+        if segment is not None and (mid_in is None or mid_out is None or device_fusion is not None):
+            raise ValueError("a plan segment needs the shared mid_in / mid_out buffers (and host-side fusion weights)")
+        self.segment, self.split, self.mid_in, self.mid_out = segment, split, mid_in, mid_out
         cfg = unet.config
         rec = self.rec = Recorder(device)
+        self.rec_head, self.rec_tail = (rec, Recorder(device)) if segment == "outer" else (None, None)
+        if self.rec_tail is not None:
+            self.rec_tail.colstats = rec.colstats           # the skips the tail reads were written (with their statistics) by the head
         # launches that depend on the conditioning only (text / image-token K,V projections of the 16 cross-attention layers,
         # attention_processor.py:304-305,392-393): replayed when the conditioning changes, NOT every denoising step
         self.rec_cond = Recorder(device)
@@ -294,6 +308,13 @@ class UNetEngine:
                                                _f32(a2.to_out[0].bias), kimg, vimg, batch=b, nq=n, heads=heads, d=d, nt=self.NT, nip=self.P,
                                                ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias), ln_eps=blk.norm2.eps, fusion=fus)
             self.xattn_params[name] = xp
+        elif Recorder.xattn_lnq_supported(C, heads, self.NT, self.P):
+            # C = 1280: norm2 -> to_q -> dual-branch SDPA head-parallel in one launch (pv_xq.hip), then to_out + bias + residual
+            xa, xp = rec.cross_attention_lnq(hs, _f16(a2.to_q.weight), kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n,
+                                             nt=self.NT, nip=self.P, d=d, ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias),
+                                             ln_eps=blk.norm2.eps, vnorm=vnorm, fusion=fus)
+            self.xattn_params[name] = xp
+            hs = rec.gemm(xa, _f16(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         else:
             n2 = rec.layernorm(hs, _f32(blk.norm2.weight), _f32(blk.norm2.bias), eps=blk.norm2.eps)
             q = rec.gemm(n2, _f16(a2.to_q.weight), rows_per_image=n)
@@ -335,15 +356,34 @@ class UNetEngine:
         bt = torch.cat([_f32(m.time_emb_proj.bias) for m in resnets] + ([torch.zeros(pad, device=rec.device)] if pad else []), 0)
         temb_all = rec.gemm(e2, wt.contiguous(), bias=bt.contiguous(), out_f32=True)
 
-        # conv_in (cin = 4): im2col to K = 36 -> 64 (zero padded), then the MFMA GEMM
-        kin = cfg.in_channels * 9
-        kpad = (kin + 63) // 64 * 64
-        cols = rec.im2col3x3(self.x_in, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
-        w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=rec.device)
-        w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
-        x = rec.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True)
-        skips = [(x, h, w)]
+        seg, split = self.segment, self.split
+        n_lv = len(u.down_blocks)
+        if seg is not None and not (0 < split < n_lv):
+            raise ValueError("split must leave at least one resolution level on either side")
+
+        def adopt(t_cs, rows):
+            """a tensor written by ANOTHER plan (with its column statistics) becomes this plan's current activation"""
+            t, cs = t_cs
+            assert t.shape[0] == rows and cs is not None
+            self.rec.colstats[(t.data_ptr(), rows, t.shape[1])] = cs
+            return t
+
+        if seg != "mid":
+            # conv_in (cin = 4): im2col to K = 36 -> 64 (zero padded), then the MFMA GEMM
+            kin = cfg.in_channels * 9
+            kpad = (kin + 63) // 64 * 64
+            cols = rec.im2col3x3(self.x_in, batch=B, cin=cfg.in_channels, h=h, wd=w, kpad=kpad)
+            w_in = torch.zeros(c0, kpad, dtype=torch.float16, device=rec.device)
+            w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
+            x = rec.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True)
+            skips = [(x, h, w)]
+        else:
+            h, w = h >> split, w >> split
+            x = adopt(self.mid_in, B * h * w)
+            skips = [(x, h, w)]
         for bi, blk in enumerate(u.down_blocks):
+            if (seg == "outer" and bi >= split) or (seg == "mid" and bi < split):
+                continue
             for i, res in enumerate(blk.resnets):
                 x = self._resnet(res, x, None, B, h, w, temb_all, toffs[id(res)])
                 if blk.has_attn:
@@ -351,15 +391,27 @@ class UNetEngine:
                 skips.append((x, h, w))
             if blk.downsamplers is not None:
                 conv = blk.downsamplers[0].conv
+                boundary = seg == "outer" and bi == split - 1         # this branch's half of the merged part's input
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=B, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2), colstats=True)
+                             conv=dict(batch=B, hin=h, win=w, hout=h // 2, wout=w // 2, stride=2), colstats=True,
+                             out=self.mid_in[0] if boundary else None, colstats_out=self.mid_in[1] if boundary else None)
                 h, w = h // 2, w // 2
-                skips.append((x, h, w))
-        mb = u.mid_block
-        x = self._resnet(mb.resnets[0], x, None, B, h, w, temb_all, toffs[id(mb.resnets[0])])
-        x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, B, h, w)
-        x = self._resnet(mb.resnets[1], x, None, B, h, w, temb_all, toffs[id(mb.resnets[1])])
+                if not boundary:
+                    skips.append((x, h, w))                           # (at the boundary the skip belongs to the merged part)
+        if seg != "outer":
+            mb = u.mid_block
+            x = self._resnet(mb.resnets[0], x, None, B, h, w, temb_all, toffs[id(mb.resnets[0])])
+            x = self._transformer("mid_block.attentions.0", mb.attentions[0], x, B, h, w)
+            x = self._resnet(mb.resnets[1], x, None, B, h, w, temb_all, toffs[id(mb.resnets[1])])
+        n_up = len(u.up_blocks)
         for bi, blk in enumerate(u.up_blocks):
+            outer_up = bi >= n_up - split
+            if (seg == "outer" and not outer_up) or (seg == "mid" and outer_up):
+                continue
+            if seg == "outer" and bi == n_up - split:
+                rec = self.rec = self.rec_tail                        # the tail plan starts from this branch's half of the merged output
+                h, w = self.H >> (split - 1), self.W >> (split - 1)
+                x = adopt(self.mid_out, B * h * w)
             for i, res in enumerate(blk.resnets):
                 sk, sh, sw = skips.pop()
                 assert (sh, sw) == (h, w)
@@ -368,13 +420,21 @@ class UNetEngine:
                     x = self._transformer(f"up_blocks.{bi}.attentions.{i}", blk.attentions[i], x, B, h, w)
             if blk.upsamplers is not None:
                 conv = blk.upsamplers[0].conv
+                boundary = seg == "mid" and bi == n_up - split - 1
                 x = rec.gemm(x, _conv3_w(conv.weight), bias=_f32(conv.bias),
-                             conv=dict(batch=B, hin=h, win=w, hout=h * 2, wout=w * 2, upsample=1), colstats=True)
+                             conv=dict(batch=B, hin=h, win=w, hout=h * 2, wout=w * 2, upsample=1), colstats=True,
+                             out=self.mid_out[0] if boundary else None, colstats_out=self.mid_out[1] if boundary else None)
                 h, w = h * 2, w * 2
+        assert not skips, "every skip connection is consumed inside the plan segment that produced it"
+        if seg == "mid":
+            self.out = x
+            return
         xn = rec.groupnorm(x, _f32(u.conv_norm_out.weight), _f32(u.conv_norm_out.bias), batch=B, hw=h * w,
                            eps=u.conv_norm_out.eps, act=ACT_SILU)
         wo = u.conv_out.weight.detach().permute(0, 2, 3, 1).reshape(cfg.out_channels, -1).to(torch.float16).contiguous()
         self.out = rec.conv_out(xn, wo, _f32(u.conv_out.bias), batch=B, cin=c0, h=h, wd=w, cout=cfg.out_channels, out=self.out_buf)
+        if seg == "outer":
+            self.rec = Recorder.concat(self.rec_head, self.rec_tail)      # introspection / timing view of the branch's own launches
 
     def run_conditioning(self):
         self.rec_cond.run()

@@ -432,6 +432,55 @@ def test_cross_attention_fused_branch(rec_cls, d, n, p, wt, wi, ln, fus):
     torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
 
 
+@pytest.mark.parametrize("n,p,wt,wi,ln,fus", [(256, 1, 1.0, 1.0, True, False), (64, 5, 1.0, 1.0, True, False), (200, 6, 2.0, 0.0, False, False),
+                                             (256, 16, 0.0, 2.0, True, True), (130, 0, 1.0, 0.0, True, False)])
+def test_cross_attention_lnq_head_parallel(rec_cls, n, p, wt, wi, ln, fus):
+    """pv_cross_attention_lnq (C = 1280 / d = 160: norm2 -> to_q -> dual-branch SDPA in ONE head-parallel launch, norm2 folded algebraically into
+    the GEMM on the raw rows) vs an fp32 torch reference on the same fp16-rounded operands and vs the three launches it replaces (LayerNorm,
+    to_q GEMM, pv_cross_attention); ragged row counts (tails), no image tokens, device-side fusion weights, a LARGE row mean (the fold subtracts
+    mean * rowsum(W) from the accumulators: cancellation is exercised)."""
+    from photoverse_amd import ops
+    B, H, NT, d = 2, 8, 77, 160
+    C = H * d
+    hs = h16(B * n, C, seed=140)
+    hs[:, ::7] += 1.5
+    hs[: n // 2] += 3.0                                  # half of the rows: mean ~ 3 sigma
+    kvt, kvip = h16(B * NT, 2 * C, seed=141), h16(B * max(p, 1), 2 * C, seed=142)
+    wq = h16(C, C, scale=C ** -0.5, seed=143)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(146))
+    beta = 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(147))
+    assert ops.Recorder.xattn_lnq_supported(C, H, NT, p)
+    rec = rec_cls("cuda")
+    dhs, dt, di = hs.cuda(), kvt.cuda(), kvip.cuda()
+    vn = torch.zeros(B, H, max(p, 1), device="cuda")
+    fusion = torch.tensor([wt, wi], device="cuda") if fus else None
+    out, _ = rec.cross_attention_lnq(dhs, wq.cuda(), dt[:, :C], dt[:, C:], di[:, :C] if p else None, di[:, C:] if p else None, batch=B, heads=H, nq=n, nt=NT,
+                                     nip=p, ln_gamma=gamma.cuda() if ln else None, ln_beta=beta.cuda() if ln else None, vnorm=vn if p else None,
+                                     w_text=-7.0 if fus else wt, w_ip=-7.0 if fus else wi, fusion=fusion)
+    n2 = rec.layernorm(dhs, gamma.cuda(), beta.cuda()) if ln else dhs
+    q = rec.gemm(n2, wq.cuda(), rows_per_image=n)
+    if p:
+        unf, _ = rec.cross_attention(q, dt[:, :C], dt[:, C:], di[:, :C], di[:, C:], batch=B, heads=H, nq=n, nt=NT, nip=p, d=d, w_text=wt, w_ip=wi)
+    rec.run()
+    torch.cuda.synchronize()
+    x = hs.float()
+    xn = F.layer_norm(x, (C,), gamma, beta, 1e-5) if ln else x
+    hv = lambda t, m: t.float().view(B, m, H, d).transpose(1, 2)
+    qq = hv(xn @ wq.float().t(), n)
+    ref = wt * F.scaled_dot_product_attention(qq, hv(kvt[:, :C], NT), hv(kvt[:, C:], NT))
+    if p:
+        vip = hv(kvip[:, C:], p)
+        ref = ref + wi * F.scaled_dot_product_attention(qq, hv(kvip[:, :C], p), vip)
+    ref = ref.transpose(1, 2).reshape(B * n, C)
+    assert torch.isfinite(out).all()
+    err = rel_l2(out, ref)
+    print(f"cross_attention_lnq n={n} P={p} ln={ln}: vs fp32 {err:.2e}" + (f", three-launch path vs fp32 {rel_l2(unf, ref):.2e}" if p else ""))
+    assert err < 2e-3
+    if p:
+        assert rel_l2(unf, ref) < 2e-3 and rel_l2(out, unf) < 2e-3
+        torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
+
+
 @pytest.mark.parametrize("M,N,geglu,ln,bias", [(1000, 960, False, True, False), (256, 320, False, False, True), (4096, 2560, True, True, True),
                                               (130, 640, True, False, False)])
 def test_row_gemm_layernorm_linear_geglu(rec_cls, M, N, geglu, ln, bias):

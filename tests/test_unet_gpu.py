@@ -298,8 +298,9 @@ def test_bench_contract_line():
     assert d["vs_baseline"] is None and d["dtype"] == "f16" and "workload" in d["config"] and d["finite"] is True
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel", "avg_launch_us", "runner_up"):
         assert k in rf, k
+    assert {rf["kernel"].split("<")[0], rf["runner_up"]["kernel"].split("<")[0]} <= {"conv_big_kernel", "gemm_conv_kernel"}      # the two 3x3-conv instantiations
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.05 < rf["frac"] < 1.0
     # derived label, self-verifying multi-GPU fields, the attn2 branch over ALL layers
@@ -307,7 +308,9 @@ def test_bench_contract_line():
     assert d["ms_per_step_ranks"]["n"] == 1 and d["ms_per_step_ranks"]["max"] == pytest.approx(d["ms_per_step"], rel=1e-3)
     xa = d["xattn_fused"]
     assert set(xa["levels"]) == {"320", "640", "1280"} and xa["levels"]["320"]["fused"] and xa["levels"]["320"]["launches_per_layer"] == 1
-    assert xa["levels"]["640"]["fused"] and xa["levels"]["640"]["launches_per_layer"] == 1 and not xa["levels"]["1280"]["fused"]
+    assert xa["levels"]["640"]["fused"] and xa["levels"]["640"]["launches_per_layer"] == 1
+    # C = 1280: norm2 + to_q + both SDPAs head-parallel in one launch, to_out + residual as a GEMM (round 3: four launches)
+    assert not xa["levels"]["1280"]["fused"] and xa["levels"]["1280"]["head_parallel"] and xa["levels"]["1280"]["launches_per_layer"] == 2
     assert xa["all_layers"]["layers_per_step"] == 32 and 0.02 < xa["all_layers"]["frac"] < 1.0 and xa["north_star_target_frac"] == 0.40
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
                          "--no-train-forward"], capture_output=True, text=True, timeout=600, cwd=root)
@@ -386,6 +389,42 @@ def test_bs16_full_size_samples_match_bs1_runs(monkeypatch, full_hip_unet):
     worst = max(rel_l2(full2[i:i + 1], s1) for i, s1 in singles2.items())
     print(f"bs=16 sample vs its bs=1 run (default split-K), 2 CFG steps, full size: worst rel-L2 = {worst:.3e}")
     assert worst < 4e-3
+
+
+def test_lowres_merge_of_the_two_cfg_forwards_changes_nothing_per_sample(full_hip_unet, monkeypatch):
+    """``DenoiseLoop(merge_lowres=True)`` (default) runs the 16 x 16 / 8 x 8 levels and the mid block of the uncond and cond forwards as ONE plan over
+    both branches' samples (three plans per step: heads, merged part, tails).  Samples never interact inside the UNet: with split-K off the
+    latents equal the two-plan loop's BIT FOR BIT (every kernel accumulates each output in the same order whatever the tile or batch); with the
+    default split-K heuristic (which sees a different M) they agree to rounding."""
+    from photoverse_amd import ops
+    from photoverse_amd.pipeline import DenoiseLoop
+    hip = full_hip_unet
+    g = torch.Generator().manual_seed(77)
+    B, P, T = 4, 1, 2
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, 64, 64, generator=g)
+
+    def run(merge):
+        loop = DenoiseLoop(hip, B, 64, P, T, 7.5, merge_lowres=merge)
+        assert loop.merge_lowres == merge and len(loop.engines_m) == (1 if merge else 0)
+        loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        loop.reset(noise)
+        out = loop.run().clone().cpu()
+        n = loop.launches_per_step
+        del loop
+        return out, n
+
+    monkeypatch.setattr(ops, "SPLITK_MAX", 1)
+    a, na = run(True)
+    b, nb = run(False)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    monkeypatch.undo()
+    a2, _ = run(True)
+    b2, _ = run(False)
+    err = rel_l2(a2, b2)
+    print(f"low-resolution CFG merge vs two whole forwards (default split-K): rel-L2 {err:.2e}; launches per step {na} vs {nb}")
+    assert err < 2e-3 and na < nb
 
 
 def _two_rank_loop_worker(rank, world, port, q):

@@ -104,6 +104,26 @@ def xfused(name, n, p=1, fused=True, d=40):
     cases.append((name, f))
 
 
+def xlnq(name, n, p=1, fused=True):
+    """attn2 branch at C = 1280: norm2 + to_q + dual SDPA head-parallel (pv_cross_attention_lnq) + to_out, or the four launches."""
+    def f():
+        rec = Recorder(dev)
+        d, C = 160, 1280
+        hs, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
+        wq, wo, bo = h16(C, C, scale=0.03), h16(C, C, scale=0.03), torch.zeros(C, device=dev)
+        g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        if fused:
+            xa, _ = rec.cross_attention_lnq(hs, wq, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, nq=n, nt=77, nip=p, ln_gamma=g, ln_beta=bt)
+        else:
+            n2 = rec.layernorm(hs, g, bt)
+            q = rec.gemm(n2, wq, rows_per_image=n)
+            xa, _ = rec.cross_attention(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], batch=B, heads=8, nq=n, nt=77, nip=p, d=d)
+        rec.gemm(xa, wo, bias=bo, residual=hs, rows_per_image=n)
+        M = B * n
+        return rec, 4.0 * M * C * C + 4.0 * M * (77 + p) * C, 2.0 * 3 * M * C
+    cases.append((name, f))
+
+
 def rowgemm(name, M, N, geglu=False, fused=True):
     """LayerNorm + K = 320 Linear (+ GEGLU): the row-owning launch (pv_row_gemm) or the two launches it replaces."""
     def f():
@@ -274,6 +294,10 @@ xfused("attn2 branch C320 n4096 P5 FUSED", 4096, p=5)
 xfused("attn2 branch C640 n1024 FUSED", 1024, d=80)
 xfused("attn2 branch C640 n1024 4 launches", 1024, fused=False, d=80)
 xfused("attn2 branch C640 n1024 P5 FUSED", 1024, p=5, d=80)
+xlnq("attn2 branch C1280 n256 LNQ + to_out (2 launches)", 256)
+xlnq("attn2 branch C1280 n256 4 launches", 256, fused=False)
+xlnq("attn2 branch C1280 n64 LNQ + to_out (2 launches)", 64)
+xlnq("attn2 branch C1280 n64 4 launches", 64, fused=False)
 conv_out("conv_out 320->4 @64", 320, 4, 64)
 conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)

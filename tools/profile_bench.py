@@ -13,7 +13,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "prof_bench")
 steps = sys.argv[1] if len(sys.argv) > 1 else "5"
-DOM = "gemm_conv_kernel<5, true, false, true, false, 4>"
+sys.path.insert(0, ROOT)
+from bench import KERNEL_SOURCES, git_blob_sha1  # noqa: E402
 env = dict(os.environ, TMPDIR="/tmp")
 base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "2", "--no-cpu-baseline", "--no-train-forward"]
 
@@ -28,8 +29,12 @@ def run(args, tag):
 
 d, out = run(["--kernel-trace", "--stats"], "stats")
 line = [l for l in out.splitlines() if l.startswith("{")]
+DOM = None
 if line:
     open(os.path.join(OUT, "bench_under_rocprof.json"), "w").write(line[-1] + "\n")
+    DOM = (json.loads(line[-1]).get("roofline") or {}).get("kernel")      # the dominant launch symbol as bench.py determined it from the launch tags
+if not DOM:
+    sys.exit("bench.py printed no roofline.kernel: nothing to attribute the PMC passes to")
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     os.remove(f)   # large; the stats summary is what is kept
 for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
@@ -49,7 +54,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum"):
         for c, v in cs.items():
             traffic.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 dom = {k: v for k, v in traffic.items() if DOM in k}
-summary = {"dominant_kernel": DOM, "per_kernel": traffic}
+# the kernel sources these counters were collected on: bench.py reports roofline.traffic_stale when the tree's differ
+summary = {"dominant_kernel": DOM, "source_blobs": {k: git_blob_sha1(os.path.join(ROOT, k)) for k in KERNEL_SOURCES}, "per_kernel": traffic}
 if dom:
     v = next(iter(dom.values()))
     fetch_kb = v.get("FETCH_SIZE", {}).get("mean_per_launch")
