@@ -10,7 +10,12 @@
 //
 //   GEMM   Q^T[n][row] = Wq'[h*160 + n][:] . X^T, K = C in 64-deep steps: the head's 160 weight rows stream through a four-stage LDS ring
 //          (LDS-DMA, 8-row x 128-B pieces, chunk ^= row & 7, counted vmcnt, one raw s_barrier per step); X fragments (MFMA-B: lane = row,
-//          8 consecutive channels) are loaded straight from global memory two steps ahead - a wave's 32 rows are its own.
+//          8 consecutive channels) are read from the same ring.
+//   roles  144 KiB of LDS = one workgroup per CU, so nothing overlaps a wave's stalls but its own workgroup: waves 0-3 COMPUTE (one per
+//          SIMD), waves 4-7 only LOAD - they issue every LDS-DMA of the kernel: per step 20 weight pieces and the 16 pieces of the
+//          workgroup's rows (full 128-B lines; the first form read the rows as MFMA-shaped fragments straight from global memory - 16
+//          64-B segments per wave-instruction - and spent 2 240 - 2 860 cycles per step against 640 of MFMA issue,
+//          profiles/r04_xlnq_stamps.txt), and, once the GEMM has released the ring, the K / V images.
 //   norm2  folded algebraically, so the GEMM runs on the RAW rows:  to_q(LN(x)) = rstd * (Wq' . x - mean * rowsum(Wq')) + Wq . beta,
 //          Wq' = Wq diag(gamma).  sum(x) and sum(x^2) are accumulated from the very fragments the MFMAs consume (v_dot2_f32_f16); the
 //          normalised activations are never rounded to fp16 (the four-launch path rounds them once).
@@ -30,10 +35,16 @@ constexpr int XKEYS = 96, IP0 = 80;          // K / V image rows: text keys [0, 
 constexpr int NKB = XKEYS / 16;
 constexpr int KS = D;                        // K image rows are unpadded (the image is one contiguous LDS-DMA target); 16-B chunk ^= F[(row >> 2) & 3]
 constexpr int VS = 176;                      // V image row stride in halfs (pv_attn.hip ACfg<160>::VS: eight key rows on eight different 32-B slots)
-constexpr int NST = 4;                       // weight ring stages
-constexpr int W_STAGE = D * 128;             // 160 rows x 64 k x 2 B = 20 KiB
-constexpr int W_PIECES = D / 8;              // 20 LDS-DMA pieces per stage, 5 per wave
-constexpr int SMEM_BYTES = NST * W_STAGE + XKEYS * KS * 2 + XKEYS * VS * 2;   // 80 + 30 + 33 KiB
+constexpr int NST = 4;                       // ring stages
+constexpr int W_BYTES = D * 128;             // weight part of a stage: 160 rows x 64 k x 2 B = 20 KiB
+constexpr int X_BYTES = 128 * 128;           // activation part: the workgroup's 128 rows x 64 k x 2 B = 16 KiB
+constexpr int W_STAGE = W_BYTES + X_BYTES;   // 36 KiB
+constexpr int NLOAD = 4;                     // loader waves (waves 4-7): one per SIMD beside a computing wave
+constexpr int LPW = D / 8 / NLOAD, LPX = 128 / 8 / NLOAD;   // 8-row LDS-DMA pieces per loader and stage: 5 weight + 4 activation
+constexpr int LP = LPW + LPX;
+constexpr int KV_BYTES = XKEYS * KS * 2 + XKEYS * VS * 2;   // 30 + 33 KiB: the K / V images take over the ring once the GEMM is done
+constexpr int SMEM_BYTES = NST * W_STAGE;    // 144 KiB: one workgroup per CU
+static_assert(KV_BYTES <= SMEM_BYTES, "K / V images alias the ring");
 constexpr int K_INSTR = XKEYS * (KS / 8) / 64;      // 30 LDS-DMA wave-instructions fill the K image, 33 the V image (pad chunks read zeros)
 constexpr int V_INSTR = XKEYS * (VS / 8) / 64;
 static_assert(XKEYS * (KS / 8) % 64 == 0 && XKEYS * (VS / 8) % 64 == 0, "K / V images are whole numbers of 1-KiB LDS-DMA writes");
@@ -74,28 +85,30 @@ struct I0 { static constexpr int value = 0; };
 struct I1 { static constexpr int value = 1; };
 struct I2 { static constexpr int value = 2; };
 
-__global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_params p) {
+template <int HPW>       // heads per 160-feature block: 1 (d = 160, C = 1280) or 2 (d = 80, C = 640)
+__global__ __launch_bounds__(512, 2) void xattn_lnq_kernel(const pv_xattn_lnq_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;
-    half_t* sK = reinterpret_cast<half_t*>(smem + NST * W_STAGE);
+    half_t* sK = reinterpret_cast<half_t*>(smem);            // (after the GEMM)
     half_t* sV = sK + XKEYS * KS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int C = p.heads * D;
+    const int C = p.heads * p.d;
+    const int nblk = C / D;                                  // 160-feature blocks = workgroups per row tile (h below is the BLOCK index)
     const int nqt = (p.nq + 127) / 128;
     const int rid = (int)blockIdx.x;
     // heads fastest: the eight workgroups that read the same 128 rows run together (the rows come from L2 once they have been touched)
-    const int h = rid % p.heads, qt = (rid / p.heads) % nqt, b = rid / (p.heads * nqt);
+    const int h = rid % nblk, qt = (rid / nblk) % nqt, b = rid / (nblk * nqt);
     const int nk = C / 64;
 
     // ---- the head's K / V images (conditioning only) by LDS-DMA: image chunk idx = 64 j + lane of wave-instruction j -> (row, position); the
     // source is the row's chunk (position ^ swizzle) of the text / image-token K (V) rows, an out-of-range offset (zeros) for padding ----
-    {
+    auto issue_kv = [&](int lw) {                   // lw: loader index 0 .. 3
         constexpr unsigned OOB = 0x80000000u;
-        const __amdgpu_buffer_rsrc_t rkt = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.kt), 0, (int)(((size_t)p.batch * p.nt - 1) * p.ldkt * 2 + (size_t)p.heads * D * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rvt = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vt), 0, (int)(((size_t)p.batch * p.nt - 1) * p.ldvt * 2 + (size_t)p.heads * D * 2), 0x00020000);
-        for (int j = wave; j < K_INSTR; j += 4) {
+        const __amdgpu_buffer_rsrc_t rkt = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.kt), 0, (int)(((size_t)p.batch * p.nt - 1) * p.ldkt * 2 + (size_t)C * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rvt = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vt), 0, (int)(((size_t)p.batch * p.nt - 1) * p.ldvt * 2 + (size_t)C * 2), 0x00020000);
+        for (int j = lw; j < K_INSTR; j += NLOAD) {
             const int idx = j * 64 + lane, r = idx / (KS / 8), c = idx - r * (KS / 8);
             const int sc = (c & ~3) | ((c & 3) ^ kswz(r));
             const bool is_t = r < p.nt, is_i = r >= IP0 && r < IP0 + p.nip;
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_param
                 }
             }
         }
-        for (int j = wave; j < V_INSTR; j += 4) {
+        for (int j = lw; j < V_INSTR; j += NLOAD) {
             const int idx = j * 64 + lane, r = idx / (VS / 8), c = idx - r * (VS / 8);
             const bool in_row = c < D / 8;
             const bool is_t = in_row && r < p.nt, is_i = in_row && r >= IP0 && r < IP0 + p.nip;
@@ -127,95 +140,97 @@ __global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_param
                 }
             }
         }
-    }
+    };
 
     // ---- GEMM: Q^T = Wq'[head rows] . X^T on the raw rows ----
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wq), 0, C * C * 2, 0x00020000);
     const int lrow = lane >> 3;
-    // piece j = wave + 4 i (i < 5): LDS rows 8 j + lrow hold weight rows h*D + PHI(8 j + lrow), 16-B chunk (lane & 7) ^ lrow of the 64-deep slab
-    unsigned w_off[5];
+    const bool loader = wave >= 4;
+    const int lw = max(wave - 4, 0);
+    // stage kt: weight pieces j = lw + 4 i (i < 5): LDS rows 8 j + lrow hold weight rows h*D + PHI(8 j + lrow); activation pieces j = lw + 4 i (i < 4):
+    // the workgroup's rows 8 j + lrow (rows past the sample's nq: out-of-range offset -> zeros); 16-B chunk (lane & 7) ^ lrow of the 64-deep slab
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.hs), 0, (int)(((size_t)p.batch * p.nq - 1) * p.ld_hs * 2 + (size_t)C * 2), 0x00020000);
+    unsigned w_off[LPW], x_off[LPX];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) w_off[i] = (unsigned)(h * D + phi((wave + 4 * i) * 8 + lrow)) * (unsigned)(C * 2) + (unsigned)(((lane & 7) ^ lrow) * 16);
-    auto issue_w = [&](int kt) {
+    for (int i = 0; i < LPW; ++i)
+        w_off[i] = (unsigned)(h * D + phi((lw + NLOAD * i) * 8 + lrow)) * (unsigned)(C * 2) + (unsigned)(((lane & 7) ^ lrow) * 16);
+#pragma unroll
+    for (int i = 0; i < LPX; ++i) {
+        const int r = qt * 128 + (lw + NLOAD * i) * 8 + lrow;
+        x_off[i] = r < p.nq ? (unsigned)(((size_t)b * p.nq + r) * p.ld_hs * 2) + (unsigned)(((lane & 7) ^ lrow) * 16) : 0x80000000u;
+    }
+    auto issue_stage = [&](int kt) {
         char* dst = sW + (kt & (NST - 1)) * W_STAGE;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + (wave + 4 * i) * 8 * 128), 16, (int)(w_off[i] + (unsigned)kt * 128u), 0, 0, 0);
-    };
-    int qrow[2];
-    const half_t* xrow[2];
+        for (int i = 0; i < LPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(dst + (lw + NLOAD * i) * 8 * 128), 16, (int)(w_off[i] + (unsigned)kt * 128u), 0, 0, 0);
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
-        xrow[qi] = reinterpret_cast<const half_t*>(p.hs) + ((size_t)b * p.nq + min(qrow[qi], p.nq - 1)) * p.ld_hs + fq * 8;
+        for (int i = 0; i < LPX; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, PV_LDS_PTR(dst + W_BYTES + (lw + NLOAD * i) * 8 * 128), 16,
+                                                     (int)(x_off[i] == 0x80000000u ? x_off[i] : x_off[i] + (unsigned)kt * 128u), 0, 0, 0);
+    };
+    if (loader) {
+        // ---- loader waves: stages 0, 1, 2, then per step stage kt+3 into the buffer the computing waves left at the barrier; "stage kt landed" =
+        // at most the two younger stages outstanding.  After the GEMM: the K / V images into the (now free) ring. ----
+        issue_stage(0);
+        if (nk > 1) issue_stage(1);
+        if (nk > 2) issue_stage(2);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) wait_vmcnt<2 * LP>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) issue_stage(kt + 3);
+        }
+        __builtin_amdgcn_s_barrier();                         // every computing wave has read the last stage: the ring is free
+        asm volatile("" ::: "memory");
+        issue_kv(lw);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                         // K / V images landed
+        return;
     }
-    half8_t xb[3][2][2];                                     // [step mod 3][qi][ks]: the fragments of steps kt, kt+1, kt+2
-    auto load_x = [&](int kt, half8_t (&dst)[2][2]) {
+    int qrow[2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) dst[qi][ks] = *reinterpret_cast<const half8_t*>(xrow[qi] + kt * 64 + ks * 32);
-    };
+    for (int qi = 0; qi < 2; ++qi) qrow[qi] = qt * 128 + wave * 32 + qi * 16 + fr;
     float4_t qacc[NFQ][2];
 #pragma unroll
     for (int f = 0; f < NFQ; ++f)
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) qacc[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-
-    // vmcnt counts LDS-DMA and plain loads together, in issue order.  Issue order: W(0) W(1) W(2) X(0) X(1), then per step kt: W(kt+3) X(kt+2).
-    // "X(kt) and stage kt landed" <=> at most the ops issued after X(kt) are outstanding: [W(kt+2) X(kt+1)] of step kt-1 ... = 2 x 9 at the top of
-    // step kt (before its own issue) - so a weight stage has two whole steps to land.
-    issue_w(0);
-    if (nk > 1) issue_w(1);
-    if (nk > 2) issue_w(2);
-    load_x(0, xb[0]);
-    if (nk > 1) load_x(1, xb[1]);
-
     const half2_t one2 = half2_t{(half_t)1.0f, (half_t)1.0f};
-    auto step = [&](int kt, auto c0, auto c2) {
-        constexpr int cur = decltype(c0)::value, nxt2 = decltype(c2)::value;
-        // stage kt landed (own pieces) + every wave done with the reads of stage kt-1 (whose buffer stage kt+3 refills)
-        if (kt + 2 < nk) wait_vmcnt<9>(); else wait_vmcnt<0>();
+    // computing waves: no vector-memory operation in the loop; behind the barrier stage kt has landed and stage kt-1 (refilled next) is free
+    for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 3 < nk) issue_w(kt + 3);
-        if (kt + 2 < nk) load_x(kt + 2, xb[nxt2]);
         const char* sw = sW + (kt & (NST - 1)) * W_STAGE;
+        const char* sx = sw + W_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            half8_t xb[2];
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                const int row = wave * 32 + qi * 16 + fr;
+                xb[qi] = *reinterpret_cast<const half8_t*>(sx + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+            }
 #pragma unroll
             for (int f = 0; f < NFQ; ++f) {
                 const int row = f * 16 + fr;
                 const half8_t a = *reinterpret_cast<const half8_t*>(sw + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi) qacc[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[cur][qi][ks], qacc[f][qi], 0, 0, 0);
+                for (int qi = 0; qi < 2; ++qi) qacc[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[qi], qacc[f][qi], 0, 0, 0);
             }
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                const half8_t x = xb[cur][qi][ks];
+            for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const half2_t x2 = half2_t{x[2 * j], x[2 * j + 1]};
+                    const half2_t x2 = half2_t{xb[qi][2 * j], xb[qi][2 * j + 1]};
                     s1[qi] = dot2(x2, one2, s1[qi]);
                     s2[qi] = dot2(x2, x2, s2[qi]);
                 }
-            }
         }
-    };
-    // The wait in `step` assumes that X(kt+1) was issued AFTER W(kt+2): true from step 1 on (per-step order W, X); for step 0 the prologue
-    // issued X(0) X(1) after W(0..2), so vmcnt(9) at the top of step 0 would also let X(0) be outstanding -> drain to "X(1) only" there.
-    {
-        if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();       // everything but X(1): W(0..2) and X(0) have landed
     }
-    for (int kt = 0; kt < nk; kt += 3) {
-        step(kt, I0{}, I2{});
-        if (kt + 1 < nk) step(kt + 1, I1{}, I0{});
-        if (kt + 2 < nk) step(kt + 2, I2{}, I1{});
-    }
-
-    // K / V images: every wave's LDS-DMAs are older than its last vmcnt wait of the loop; the image-token rows were written behind a drained queue
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // ring free -> the loaders fill in the K / V images while the queries are finalised below
     asm volatile("" ::: "memory");
 
     // ---- norm2 fold, query bias, B operand of the score product ----
@@ -242,75 +257,93 @@ __global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_param
         }
     }
 
-    // to_v_ip_norm (attention_processor.py:397): ||Vip[b, p, h, :]||_2, once per (b, h)
-    if (p.vnorm && qt == 0 && tid < p.nip) {
+    __builtin_amdgcn_s_barrier();                             // K / V images landed (the loaders waited for their DMAs in front of this barrier)
+    asm volatile("" ::: "memory");
+
+    // to_v_ip_norm (attention_processor.py:397): ||Vip[b, p, head, :]||_2, once per (b, head)
+    constexpr int DH = D / HPW;                              // head dim
+    if (p.vnorm && qt == 0 && tid < p.nip * HPW) {
+        const int hh = tid / p.nip, ip = tid - hh * p.nip;
         float a = 0.f;
-        for (int d = 0; d < D; ++d) {
-            const float v = (float)sV[(IP0 + tid) * VS + d];
+        for (int d = 0; d < DH; ++d) {
+            const float v = (float)sV[(IP0 + ip) * VS + hh * DH + d];
             a += v * v;
         }
-        p.vnorm[((size_t)b * p.heads + h) * p.nip + tid] = sqrtf(a);
+        p.vnorm[((size_t)b * p.heads + h * HPW + hh) * p.nip + ip] = sqrtf(a);
     }
 
-    // ---- S^T = K . Q^T, two softmaxes, O^T = V^T . P^T (pv_attn.hip: xattn_kernel) ----
-    float4_t s[NKB][2];
+    // ---- per head: S^T = K . Q^T, two softmaxes (pv_attn.hip: xattn_kernel); then O^T = V^T . P^T ----
+    // HPW = 2: head hh owns features [80 hh, 80 hh + 80) of the block = k-steps {0, 1, lower half of 2} / {upper half of 2, 3, 4}: the shared
+    // step is taken with the other head's lane groups zeroed in the B operand (lane group g of step 2 = features 64 + 8 g .. + 7)
+    const float sc = rsqrtf((float)DH) * 1.4426950408889634f;
+    half8_t pb[HPW][NKB / 2][2];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int hh = 0; hh < HPW; ++hh) {
+        float4_t s[NKB][2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) s[kb][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
+            for (int qi = 0; qi < 2; ++qi) s[kb][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * KS + (ks * 4 + (fq ^ kswz(fr))) * 8);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (HPW == 2 && ((hh == 0 && ks > 2) || (hh == 1 && ks < 2))) continue;
+            half8_t qm[2] = {qf[0][ks], qf[1][ks]};
+            if (HPW == 2 && ks == 2) {
+                const bool mine = hh == 0 ? fq < 2 : fq >= 2;
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+                for (int qi = 0; qi < 2; ++qi) qm[qi] = mine ? qm[qi] : zero8();
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const half8_t a = *reinterpret_cast<const half8_t*>(sK + (kb * 16 + fr) * KS + (ks * 4 + (fq ^ kswz(fr))) * 8);
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qm[qi], s[kb][qi], 0, 0, 0);
+            }
         }
-    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
-    half8_t pb[NKB / 2][2];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        float mt = -INFINITY, mi = -INFINITY;
+        for (int qi = 0; qi < 2; ++qi) {
+            float mt = -INFINITY, mi = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb * 16 + fq * 4 + r;
-                const float v = s[kb][qi][r];
-                if (key < p.nt) mt = fmaxf(mt, v);
-                if (key >= IP0 && key < IP0 + p.nip) mi = fmaxf(mi, v);
-            }
-        mt = pv_quad_max(mt);
-        mi = pv_quad_max(mi);
-        float lt = 0.f, li = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb * 16 + fq * 4 + r;
-                const bool is_t = key < p.nt;
-                const bool is_i = key >= IP0 && key < IP0 + p.nip;
-                float e = 0.f;
-                if (is_t) {
-                    e = PV_EXP2((s[kb][qi][r] - mt) * sc);
-                    lt += e;
-                } else if (is_i) {
-                    e = PV_EXP2((s[kb][qi][r] - mi) * sc);
-                    li += e;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 16 + fq * 4 + r;
+                    const float v = s[kb][qi][r];
+                    if (key < p.nt) mt = fmaxf(mt, v);
+                    if (key >= IP0 && key < IP0 + p.nip) mi = fmaxf(mi, v);
                 }
-                s[kb][qi][r] = e;
-            }
-        lt = pv_quad_sum(lt);
-        li = pv_quad_sum(li);
-        const float ft = (p.fusion ? p.fusion[0] : p.w_text) / lt, fi = p.nip ? (p.fusion ? p.fusion[1] : p.w_ip) / li : 0.f;
+            mt = pv_quad_max(mt);
+            mi = pv_quad_max(mi);
+            float lt = 0.f, li = 0.f;
 #pragma unroll
-        for (int s2i = 0; s2i < NKB / 2; ++s2i)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k0 = (2 * s2i) * 16 + fq * 4 + r, k1 = k0 + 16;
-                pb[s2i][qi][r] = (half_t)(s[2 * s2i][qi][r] * (k0 < IP0 ? ft : fi));
-                pb[s2i][qi][r + 4] = (half_t)(s[2 * s2i + 1][qi][r] * (k1 < IP0 ? ft : fi));
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 16 + fq * 4 + r;
+                    const bool is_t = key < p.nt;
+                    const bool is_i = key >= IP0 && key < IP0 + p.nip;
+                    float e = 0.f;
+                    if (is_t) {
+                        e = PV_EXP2((s[kb][qi][r] - mt) * sc);
+                        lt += e;
+                    } else if (is_i) {
+                        e = PV_EXP2((s[kb][qi][r] - mi) * sc);
+                        li += e;
+                    }
+                    s[kb][qi][r] = e;
+                }
+            lt = pv_quad_sum(lt);
+            li = pv_quad_sum(li);
+            const float ft = (p.fusion ? p.fusion[0] : p.w_text) / lt, fi = p.nip ? (p.fusion ? p.fusion[1] : p.w_ip) / li : 0.f;
+#pragma unroll
+            for (int s2i = 0; s2i < NKB / 2; ++s2i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k0 = (2 * s2i) * 16 + fq * 4 + r, k1 = k0 + 16;
+                    pb[hh][s2i][qi][r] = (half_t)(s[2 * s2i][qi][r] * (k0 < IP0 ? ft : fi));
+                    pb[hh][s2i][qi][r + 4] = (half_t)(s[2 * s2i + 1][qi][r] * (k1 < IP0 ? ft : fi));
+                }
+        }
     }
     float4_t o[NFQ][2];
 #pragma unroll
@@ -323,9 +356,9 @@ __global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_param
         for (int f = 0; f < NFQ; ++f) {
             const half8_t a = vt_frag(sV, s2i * 32, f * 16, fr, fq);
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2i][qi], o[f][qi], 0, 0, 0);
+            for (int qi = 0; qi < 2; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[(f * 16) / DH][s2i][qi], o[f][qi], 0, 0, 0);
         }
-    half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
+    half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;     // the block's 160 features = HPW consecutive heads
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         if (qrow[qi] < p.nq) {
@@ -343,22 +376,26 @@ __global__ __launch_bounds__(256) void xattn_lnq_kernel(const pv_xattn_lnq_param
 }  // namespace
 
 extern "C" int pv_cross_attention_lnq(const pv_xattn_lnq_params* p, void* stream) {
-    if (!p || !p->hs || !p->wq || !p->kt || !p->vt || !p->out || p->d != D || p->heads <= 0 || p->batch <= 0 || p->nq <= 0 || p->nt <= 0 || p->nt > IP0 ||
+    if (!p || !p->hs || !p->wq || !p->kt || !p->vt || !p->out || (p->d != D && p->d != D / 2) || p->heads <= 0 || p->batch <= 0 || p->nq <= 0 || p->nt <= 0 || p->nt > IP0 ||
         p->nip < 0 || p->nip > XKEYS - IP0 || (p->nip > 0 && (!p->kip || !p->vip)) || (p->ln && !p->wq_rowsum) || (p->ld_hs % 8) || (p->ldo % 4) ||
         (p->ldkt % 4) || (p->ldvt % 8) || (p->nip > 0 && ((p->ldkip % 4) || (p->ldvip % 8))))
         return (int)hipErrorInvalidValue;
-    const size_t C = (size_t)p->heads * D;
+    const size_t C = (size_t)p->heads * p->d;
+    if (C % D) return (int)hipErrorInvalidValue;
     if (C * C * 2 >= (1ull << 31)) return (int)hipErrorInvalidValue;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_lnq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_lnq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_lnq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int nqt = (p->nq + 127) / 128;
-    hipLaunchKernelGGL(xattn_lnq_kernel, dim3((unsigned)(nqt * p->heads * p->batch)), dim3(256), SMEM_BYTES, reinterpret_cast<hipStream_t>(stream), *p);
+    const dim3 grid((unsigned)(nqt * (C / D) * p->batch));
+    if (p->d == D) hipLaunchKernelGGL(xattn_lnq_kernel<1>, grid, dim3(512), SMEM_BYTES, reinterpret_cast<hipStream_t>(stream), *p);
+    else hipLaunchKernelGGL(xattn_lnq_kernel<2>, grid, dim3(512), SMEM_BYTES, reinterpret_cast<hipStream_t>(stream), *p);
     return PV_CHECK_LAUNCH();
 }

@@ -451,15 +451,17 @@ class Recorder:
 
     @staticmethod
     def xattn_lnq_supported(C: int, heads: int, nt: int, nip: int) -> bool:
-        return Recorder.XLNQ and heads * 160 == C and 0 < nt <= 80 and 0 <= nip <= 16
+        """d = 160 (C = 1280: one head per 160-feature block) or d = 80 (C = 640: two heads per block)."""
+        return Recorder.XLNQ and C % heads == 0 and C // heads in (160, 80) and 0 < nt <= 80 and 0 <= nip <= 16
 
-    def cross_attention_lnq(self, hs, wq, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d=160, ln_gamma=None, ln_beta=None, ln_eps=1e-5,
+    def cross_attention_lnq(self, hs, wq, kt, vt, kip, vip, *, batch, heads, nq, nt, nip, d=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5,
                             w_text=1.0, w_ip=1.0, vnorm=None, fusion=None, out=None):
         """``ctx = SDPA_dual(to_q(LayerNorm(hs)), K, V)`` per head; ``wq``: to_q.weight fp16 [C][C].  norm2 is folded at plan-build time so
         that the kernel's GEMM reads the raw rows: gamma scales the columns of wq, ``q_bias = wq . beta``, and the kernel corrects with the
         row statistics it accumulates itself: ``rstd * (wq' . x - mean * rowsum(wq')) + q_bias``."""
-        C = heads * d
-        assert hs.shape[1] == C and wq.shape == (C, C) and wq.dtype == torch.float16
+        C = hs.shape[1]
+        d = C // heads if d is None else d
+        assert heads * d == C and d in (160, 80) and wq.shape == (C, C) and wq.dtype == torch.float16
         if out is None:
             out = self.empty((batch * nq, C), torch.float16)
         q_bias = rowsum = None

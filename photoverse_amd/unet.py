@@ -309,7 +309,7 @@ class UNetEngine:
                                                ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias), ln_eps=blk.norm2.eps, fusion=fus)
             self.xattn_params[name] = xp
         elif Recorder.xattn_lnq_supported(C, heads, self.NT, self.P):
-            # C = 1280: norm2 -> to_q -> dual-branch SDPA head-parallel in one launch (pv_xq.hip), then to_out + bias + residual
+            # C = 1280 (and C = 640 when PV_XFUSED_WIDTHS leaves it out): norm2 -> to_q -> dual-branch SDPA head-parallel in one launch (pv_xq.hip), then to_out + bias + residual
             xa, xp = rec.cross_attention_lnq(hs, _f16(a2.to_q.weight), kvt[:, :C], kvt[:, C:], kvip[:, :C], kvip[:, C:], batch=b, heads=heads, nq=n,
                                              nt=self.NT, nip=self.P, d=d, ln_gamma=_f32(blk.norm2.weight), ln_beta=_f32(blk.norm2.bias),
                                              ln_eps=blk.norm2.eps, vnorm=vnorm, fusion=fus)

@@ -432,15 +432,17 @@ def test_cross_attention_fused_branch(rec_cls, d, n, p, wt, wi, ln, fus):
     torch.testing.assert_close(vn.cpu(), vip.norm(dim=-1), rtol=1e-4, atol=1e-4)     # to_v_ip_norm, attention_processor.py:397
 
 
-@pytest.mark.parametrize("n,p,wt,wi,ln,fus", [(256, 1, 1.0, 1.0, True, False), (64, 5, 1.0, 1.0, True, False), (200, 6, 2.0, 0.0, False, False),
-                                             (256, 16, 0.0, 2.0, True, True), (130, 0, 1.0, 0.0, True, False)])
-def test_cross_attention_lnq_head_parallel(rec_cls, n, p, wt, wi, ln, fus):
-    """pv_cross_attention_lnq (C = 1280 / d = 160: norm2 -> to_q -> dual-branch SDPA in ONE head-parallel launch, norm2 folded algebraically into
+@pytest.mark.parametrize("d,n,p,wt,wi,ln,fus", [(160, 256, 1, 1.0, 1.0, True, False), (160, 64, 5, 1.0, 1.0, True, False), (160, 200, 6, 2.0, 0.0, False, False),
+                                               (160, 256, 16, 0.0, 2.0, True, True), (160, 130, 0, 1.0, 0.0, True, False),
+                                               (80, 1024, 1, 1.0, 1.0, True, False), (80, 200, 5, 1.0, 1.0, True, False), (80, 128, 16, 0.0, 2.0, False, True)])
+def test_cross_attention_lnq_head_parallel(rec_cls, d, n, p, wt, wi, ln, fus):
+    """pv_cross_attention_lnq (C = 1280 / d = 160 and C = 640 / d = 80 - two heads per 160-feature block, the shared contraction step masked per
+    head: norm2 -> to_q -> dual-branch SDPA in ONE head-parallel launch, norm2 folded algebraically into
     the GEMM on the raw rows) vs an fp32 torch reference on the same fp16-rounded operands and vs the three launches it replaces (LayerNorm,
     to_q GEMM, pv_cross_attention); ragged row counts (tails), no image tokens, device-side fusion weights, a LARGE row mean (the fold subtracts
     mean * rowsum(W) from the accumulators: cancellation is exercised)."""
     from photoverse_amd import ops
-    B, H, NT, d = 2, 8, 77, 160
+    B, H, NT = 2, 8, 77
     C = H * d
     hs = h16(B * n, C, seed=140)
     hs[:, ::7] += 1.5

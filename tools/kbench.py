@@ -104,11 +104,11 @@ def xfused(name, n, p=1, fused=True, d=40):
     cases.append((name, f))
 
 
-def xlnq(name, n, p=1, fused=True):
-    """attn2 branch at C = 1280: norm2 + to_q + dual SDPA head-parallel (pv_cross_attention_lnq) + to_out, or the four launches."""
+def xlnq(name, n, p=1, fused=True, d=160):
+    """attn2 branch at C = 1280 / 640: norm2 + to_q + dual SDPA head-parallel (pv_cross_attention_lnq) + to_out, or the four launches."""
     def f():
         rec = Recorder(dev)
-        d, C = 160, 1280
+        C = 8 * d
         hs, kvt, kvi = h16(B * n, C), h16(B * 77, 2 * C), h16(B * p, 2 * C)
         wq, wo, bo = h16(C, C, scale=0.03), h16(C, C, scale=0.03), torch.zeros(C, device=dev)
         g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
@@ -298,6 +298,7 @@ xlnq("attn2 branch C1280 n256 LNQ + to_out (2 launches)", 256)
 xlnq("attn2 branch C1280 n256 4 launches", 256, fused=False)
 xlnq("attn2 branch C1280 n64 LNQ + to_out (2 launches)", 64)
 xlnq("attn2 branch C1280 n64 4 launches", 64, fused=False)
+xlnq("attn2 branch C640 n1024 LNQ + to_out (2 launches)", 1024, d=80)
 conv_out("conv_out 320->4 @64", 320, 4, 64)
 conv_out("conv_out 128->3 @512 bs4 (VAE)", 128, 3, 512, b=4)
 gn("gn+silu 320 @64", 320, 64)
