@@ -385,7 +385,7 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the launch symbol with the largest share of one step's algorithmic flops (round 4: conv_big_kernel<true, false>,
+        # dominant kernel = the launch symbol with the largest share of one step's algorithmic flops (round 4: big_tile_kernel<true, false>,
         # the 256 x 320-tile 3x3 conv with GroupNorm column statistics of the 64x64 level; the runner-up is the 128-row instantiation that
         # runs the 32x32 level); replay exactly its launches of one step and time them with HIP events on the launch stream
         engines = loop.all_engines

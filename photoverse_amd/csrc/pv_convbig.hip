@@ -33,19 +33,22 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int ROW_BYTES = BK * 2;                   // 64 B per LDS row
-constexpr int BN = 320, NW = 8;
-constexpr int NF = 5;                               // per wave: (16 MI) rows x 80 columns = MI x 5 fragments of 16 x 16; MI = 8: 256-row tile, MI = 4: 128-row tile
+constexpr int NW = 8;
 constexpr int NBUF = 4;                             // ring: three stages in flight, one being read
-constexpr int B_PIECES = BN / 16;                   // 16-row LDS-DMA pieces of the weight tile per stage: 20
-constexpr int BP = (B_PIECES + NW - 1) / NW;        // 3 weight pieces for waves 0-3, 2 for waves 4-7
-constexpr int B_BYTES = BN * ROW_BYTES;
-template <int MI>
+// MODE: 0 = 3x3 conv, 1 = Linear / 1x1 (taps = 1), 2 = Linear with the GEGLU gate in the epilogue.  Waves: 2 (M) x 4 (N); a wave owns (16 MI) rows x
+// (16 NF) columns; NF = 5 -> 320-column tile, NF = 4 (GEGLU: value | gate fragment pairs, pv_gemm.hip's pack_geglu row order) -> 256-column tile
+template <int MI, int NF>
 struct BigCfg {
     static constexpr int BM = 2 * MI * 16;              // two wave rows
-    static constexpr int AP = BM / 16 / NW;             // activation pieces per wave and stage: 2 (256 rows) / 1 (128 rows)
-    static constexpr int A_BYTES = BM * ROW_BYTES;
-    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 36 KiB / 28 KiB
-    static constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;   // 144 KiB / 112 KiB: one workgroup per CU either way
+    static constexpr int BN = 4 * NF * 16;              // four wave columns
+    static constexpr int AP = BM / 16 / NW;             // 16-row activation pieces per wave and stage: 2
+    static constexpr int B_PIECES = BN / 16;            // 16-row weight pieces per stage: 20 (3 for waves 0-3, 2 for waves 4-7) / 16 (2 each)
+    static constexpr int BP = (B_PIECES + NW - 1) / NW;
+    static constexpr int BP_LO = B_PIECES % NW ? BP - 1 : BP;    // pieces of the waves 4-7
+    static_assert(B_PIECES % NW == 0 || B_PIECES % NW == NW / 2, "the vmcnt bookkeeping assumes waves 0-3 (wm == 0) are the ones with the extra piece");
+    static constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 36 KiB / 32 KiB
+    static constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;   // 144 KiB / 128 KiB: one workgroup per CU either way
 };
 
 __device__ __forceinline__ float epi_act(float x, int act) {
@@ -74,10 +77,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <bool CS, bool UPS, int MI>
-__global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
-    using Cfg = BigCfg<MI>;
-    constexpr int BM = Cfg::BM, AP = Cfg::AP, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+template <bool CS, bool UPS, int MI, int MODE>
+__global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
+    constexpr int NF = MODE == 2 ? 4 : 5;
+    constexpr int TAPS = MODE == 0 ? 9 : 1;
+    using Cfg = BigCfg<MI, NF>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP, B_PIECES = Cfg::B_PIECES, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+    constexpr int P_HI = AP + BP, P_LO = AP + Cfg::BP_LO;      // LDS-DMA instructions per stage of a wave 0-3 / 4-7
+    static_assert(!UPS || MODE == 0, "the upsampling gather belongs to the conv");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int cin = p.c0 + p.c1;
-    const int K = 9 * cin;
+    const int K = TAPS * cin;
     // split-K (pv_gemm.hip's partition: blockIdx.y owns the 64-deep K-steps [kb, kb + nk_per), fp32 partial slab, fixed-order reduce launch)
     const int nk64 = K / 64;
     const int nk_per = (nk64 + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -107,6 +114,12 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + (wave + i * NW) * 16 + prow;
         const bool ok = m < p.M;
+        if (MODE != 0) {                               // Linear: the row itself; "tap 0 inside the image" <=> the row exists
+            a_mask[i] = ok ? 1u : 0u;
+            a_off0[i] = (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2;
+            a_off1[i] = (unsigned)m * (unsigned)(p.lda1 * 2) + lane_cc2;
+            continue;
+        }
         const int b = m / hw_out;
         const int rem = m - b * hw_out;
         const int y = rem / p.wout, x = rem - y * p.wout;
@@ -126,21 +139,24 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
     unsigned w_off[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) w_off[i] = (unsigned)(n0 + min(wave + i * NW, B_PIECES - 1) * 16 + prow) * (unsigned)(K * 2) + lane_cc2;
-    const bool b_full = wave + (BP - 1) * NW < B_PIECES;          // waves 0-3 (wm == 0) issue a third weight piece
-    static_assert(B_PIECES - (BP - 1) * NW == NW / 2, "the vmcnt bookkeeping below assumes b_full <=> wave < 4 <=> wm == 0");
+    const bool b_full = wave + (BP - 1) * NW < B_PIECES;          // 320-column tile: waves 0-3 (wm == 0) issue a third weight piece
 
     // K position of a stage: s -> (64-channel chunk, filter tap, 32-deep half), advanced incrementally in the loop (the closed form costs
     // two divisions by constants = a dozen dependent scalar multiplies per stage in front of every LDS-DMA issue)
     struct KPos { int s, chunk, tap, ky, kx; };
     auto kpos_of = [&](int s) {
-        const int g = kb + (s >> 1), chunk = g / 9, tap = g - chunk * 9, ky = tap / 3;
-        return KPos{s, chunk, tap, ky, tap - ky * 3};
+        const int g = kb + (s >> 1), chunk = g / TAPS, tap = g - chunk * TAPS, ky = TAPS == 9 ? tap / 3 : 1;
+        return KPos{s, chunk, tap, ky, TAPS == 9 ? tap - ky * 3 : 1};      // Linear: the "centre tap" (ky, kx) = (1, 1): no pixel shift
     };
     auto kpos_next = [&](KPos& k) {
         if (k.s & 1) {                                 // second half done: next tap (kx fastest), then next chunk
-            ++k.tap; ++k.kx;
-            if (k.kx == 3) { k.kx = 0; ++k.ky; }
-            if (k.tap == 9) { k.tap = 0; k.ky = 0; ++k.chunk; }
+            if (TAPS == 9) {
+                ++k.tap; ++k.kx;
+                if (k.kx == 3) { k.kx = 0; ++k.ky; }
+                if (k.tap == 9) { k.tap = 0; k.ky = 0; ++k.chunk; }
+            } else {
+                ++k.chunk;
+            }
         }
         ++k.s;
     };
@@ -202,12 +218,12 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
         __builtin_amdgcn_sched_barrier(0);
     };
     // "stage s+1 landed" <=> at most the pieces of the two younger issued stages (s+2, s+3) are outstanding.  A wave counts its own pieces:
-    // AP + BP = 5 per stage for waves 0-3 (b_full <=> wm == 0), 4 for waves 4-7.  The last stages (nothing younger in flight) drain fully.
+    // P_HI per stage for waves 0-3 (wm == 0), P_LO for waves 4-7 (320-column tile: 5 / 4).  The last stages (nothing younger in flight) drain fully.
     // ---- prologue: stages 0, 1, 2 (the LOAD segment of stage s issues stage s+3) ----
     {
         const int pre = min(ns, 3);
         for (int s = 0; s < pre; ++s) issue(kpos_of(s), IC<0>{}, IC<AP + BP>{});
-        if (pre == 3) { if (b_full) wait_vmcnt<2 * (AP + BP)>(); else wait_vmcnt<2 * (AP + BP - 1)>(); }   // stage 0 landed
+        if (pre == 3) { if (wm == 0) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<2 * P_LO>(); }   // stage 0 landed
         else wait_vmcnt<0>();
     }
     seg_barrier();
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
         if (s + 3 < ns) issue(kn, IC<0>{}, IC<AP + BP>{});
         kpos_next(kn);
         if (wm == 1) {                                           // waves 4-7: interval 2s+1 is the one in front of waves 0-3's LOAD(s+1)
-            if (s + 3 < ns) wait_vmcnt<2 * (AP + BP - 1)>(); else wait_vmcnt<0>();
+            if (s + 3 < ns) wait_vmcnt<2 * P_LO>(); else wait_vmcnt<0>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers BEFORE the barrier: the buffer's reads are retired when it is refilled
         seg_barrier();
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
             for (int ni = 0; ni < NF; ++ni)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         if (wm == 0) {                                           // waves 0-3: stage s+1 is read right behind the next barrier
-            if (s + 3 < ns) wait_vmcnt<2 * (AP + BP)>(); else wait_vmcnt<0>();
+            if (s + 3 < ns) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<0>();
         }
         seg_barrier();
     }
@@ -246,6 +262,36 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
             if (m >= p.M) continue;
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + nbase + ni * 16) = acc[ni][mi];
+        }
+        return;
+    }
+    if constexpr (MODE == 2) {
+        // ---- GEGLU epilogue (pv_gemm.hip's): the wave's four fragments are (value, gate) x two 16-column groups in pack_geglu's row order;
+        // out[m][(n0 >> 1) + 32 wn + 16 q + ...] = (value + bias) * gelu(gate + bias), 16-byte stores through the lane-row swap ----
+        float4_t bv[2], bg[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bv[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+            bg[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q + 1) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + arow + mi * 16;
+            if (m >= p.M) continue;
+            unsigned pk[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4_t v = acc[2 * q][mi] + bv[q], g = acc[2 * q + 1][mi] + bg[q];
+                pk[q][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[0] * pv_gelu_erf(g[0])), (half_t)(v[1] * pv_gelu_erf(g[1]))});
+                pk[q][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[2] * pv_gelu_erf(g[2])), (half_t)(v[3] * pv_gelu_erf(g[3]))});
+            }
+            half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + (n0 >> 1) + wn * (NF * 8);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            const unsigned a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+            const int col = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+            typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<uint4_t*>(orow + col) = uint4_t{a0, a1, b0, b1};
         }
         return;
     }
@@ -343,22 +389,25 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const pv_gemm_params_d
             }
         }
     };
+    if constexpr (NF == 5) {
 #pragma unroll
-    for (int hb = 0; hb < MI / 4; ++hb) {
-        group(hb, IC<0>{}, IC<2>{});
-        group(hb, IC<2>{}, IC<2>{});
-        group(hb, IC<4>{}, IC<1>{});
+        for (int hb = 0; hb < MI / 4; ++hb) {
+            group(hb, IC<0>{}, IC<2>{});
+            group(hb, IC<2>{}, IC<2>{});
+            group(hb, IC<4>{}, IC<1>{});
+        }
     }
 }
 
-template <bool CS, bool UPS, int MI>
+template <bool CS, bool UPS, int MI, int MODE>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
-    constexpr int BM = BigCfg<MI>::BM, SMEM_BYTES = BigCfg<MI>::SMEM_BYTES;
+    using Cfg = BigCfg<MI, MODE == 2 ? 4 : 5>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = Cfg::SMEM_BYTES;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = conv_big_kernel<CS, UPS, MI>;
+    auto kern = big_tile_kernel<CS, UPS, MI, MODE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -374,24 +423,37 @@ int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
 }  // namespace
 
 int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
-    // PV_CONV_BIG: 0 = never (the 128-row kernel everywhere), otherwise the minimum number of 256 x 320 tiles a launch must have
+    // PV_CONV_BIG: 0 = never (the 128-row kernel everywhere), otherwise the minimum number of 256-row tiles a launch must have
     // (read per call, not cached: the parity test runs both kernels in one process; launches are recorded once and replayed from graphs)
     const char* env = getenv("PV_CONV_BIG");
     const int min_tiles = env ? atoi(env) : 256;
     if (min_tiles <= 0) return -1;
+    const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
+    const int cin = p.c0 + p.c1;
+    if (p.taps == 1) {
+        // Linear / 1x1 layers (round 4): K >= 640 (at K = 320 the ten 32-deep stages do not amortise the ring's prologue and the one-round epilogue;
+        // PV_GEMM_BIG=0 keeps them all on pv_gemm.hip), single source, no split-K, fp16 output
+        const char* genv = getenv("PV_GEMM_BIG");
+        if (genv && atoi(genv) == 0) return -1;
+        const int bn = p.geglu ? 256 : 320;
+        if (p.c1 || splits > 1 || p.out_f32 || cin < 640 || (p.N % bn) || (p.geglu && p.colstats)) return -1;
+        if ((long)((p.M + 255) / 256) * (p.N / bn) < min_tiles) return -1;
+        if (p.geglu) return launch_big<false, false, 8, 2>(p, stream);
+        return p.colstats ? launch_big<true, false, 8, 1>(p, stream) : launch_big<false, false, 8, 1>(p, stream);
+    }
+    constexpr int BN = 320;
     const int up = p.upsample ? 2 : 1;
     const bool shape_ok = p.taps == 9 && p.stride == 1 && p.pad == 1 && p.hin * up == p.hout && p.win * up == p.wout && (p.N % BN) == 0 &&
                           !p.geglu;
     if (!shape_ok) return -1;
-    const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     if (splits == 1 && p.out_f32) return -1;                    // fp32 outputs exist only behind the reduce launch here
-    if (splits > 1 && (9 * (p.c0 + p.c1) / 64) / splits < 8) return -1;
+    if (splits > 1 && (9 * cin / 64) / splits < 8) return -1;
     // workgroups: split-K launches (16 x 16 level) count their K slices.  (A 128-row form of this tile - MI = 4, 128 x 2 tiles on the 32 x 32 level -
     // was built and measured in round 4: bit-identical, but 142 vs 127 us on conv 640 -> 640 @32 and -2.3 % in the loop: at 91 flop / B it is bound
     // by the L2 -> LDS stream like the 128 x 160 kernel, without that kernel's two independent workgroups per CU.  EXPERIMENTS.md.)
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / BN) * splits;
     if (tiles256 < min_tiles) return -1;
     const bool cs = p.colstats && splits == 1;                  // with split-K the reduce launch produces the column statistics
-    if (p.upsample) return cs ? launch_big<true, true, 8>(p, stream) : launch_big<false, true, 8>(p, stream);
-    return cs ? launch_big<true, false, 8>(p, stream) : launch_big<false, false, 8>(p, stream);
+    if (p.upsample) return cs ? launch_big<true, true, 8, 0>(p, stream) : launch_big<false, true, 8, 0>(p, stream);
+    return cs ? launch_big<true, false, 8, 0>(p, stream) : launch_big<false, false, 8, 0>(p, stream);
 }

@@ -608,15 +608,13 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
         p.a1_bytes = (uint32_t)b1;
         p.w_bytes = (uint32_t)bw;
     }
-    if (p.geglu) {
-        if (p.taps != 1 || (p.N % 128)) return (int)hipErrorInvalidValue;
-        return dispatch<4, false, true>(p, stream);
-    }
-    const bool conv = p.taps == 9;
-    if (conv) {                                          // 64 x 64 level: the 256 x 320 tile (pv_convbig.hip) where the launch fills the chip with it
+    if (p.geglu && (p.taps != 1 || (p.N % 128))) return (int)hipErrorInvalidValue;
+    {                                                    // the 256-row tile (pv_convbig.hip) where the launch fills the chip with it
         const int rc = pv_conv_big_launch(p, stream);
         if (rc >= 0) return rc;
     }
+    if (p.geglu) return dispatch<4, false, true>(p, stream);
+    const bool conv = p.taps == 9;
     if (p.N % 160 == 0) return conv ? dispatch<5, true, false>(p, stream) : dispatch<5, false, false>(p, stream);
     if (p.N % 128 == 0) return conv ? dispatch<4, true, false>(p, stream) : dispatch<4, false, false>(p, stream);
     return (int)hipErrorInvalidValue;

@@ -218,9 +218,14 @@ class Recorder:
         name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
                 f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
         # pv_convbig.hip's 256 x 320 tile (pv_conv_big_launch's rule): stride-1 / pad-1 3x3 convs whose launch has >= PV_CONV_BIG (256) such tiles
+        # pv_convbig.hip's 256-row tile (pv_conv_big_launch's rules): 3x3 convs, and Linear layers with K >= 640 (GEGLU: 256-column tiles)
         if big_shape and not (out_f32 and splitk == 1) and (splitk == 1 or (kdim // 64) // splitk >= 8):
             if tiles256 * splitk >= big_min:
-                name = f"conv_big_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8>"
+                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, 0>"
+        bn_big = 256 if geglu else 320
+        if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
+                and N % bn_big == 0 and not (geglu and cs is not None) and ((M + 255) // 256) * (N // bn_big) >= big_min):
+            name = f"big_tile_kernel<{'true' if cs is not None else 'false'}, false, 8, {2 if geglu else 1}>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
 

@@ -175,6 +175,37 @@ def test_conv3x3_dual_source_big_tile(rec_cls):
     assert rel_l2(out, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(65536, 320, 1280, False), (16384, 1920, 640, False), (8192 + 100, 3840, 1280, False), (16384, 5120, 640, True),
+                                          (4096 + 40, 10240, 1280, True)])
+def test_linear_on_the_256_row_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeypatch, M, N, K, geglu):
+    """The Linear / GEGLU modes of pv_convbig.hip's staggered 256-row tile (K >= 640: ff2 of the 64 x 64 level, fused qkv and the GEGLU projections
+    of the 32 x 32 / 16 x 16 levels) vs fp32 torch and, bit for bit, vs pv_gemm.hip's 128-row kernel (same MFMA, same K order); bias + residual +
+    column statistics on the plain form, the value * gelu(gate) epilogue on 256-column tiles, ragged M."""
+    from photoverse_amd.ops import pack_geglu
+    x = h16(M, K, seed=150)
+    w = h16(N, K, scale=K ** -0.5, seed=151)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(152))
+    res = None if geglu else h16(M, N, seed=153)
+    dx, dw, db = x.cuda(), w.cuda(), b.cuda()
+    if geglu:
+        dw, db = pack_geglu(dw, db)
+    outs, stats = {}, {}
+    for name, env in (("big", "1"), ("small", "0")):
+        monkeypatch.setenv("PV_CONV_BIG", env)
+        rec = rec_cls("cuda")
+        outs[name] = rec.gemm(dx, dw, bias=db, residual=None if res is None else res.cuda(), geglu=geglu, colstats=not geglu and M % 64 == 0, splitk=0)
+        assert rec.tags[-1][0].startswith("big_tile_kernel" if name == "big" else "gemm_conv_kernel"), rec.tags[-1]
+        stats[name] = rec.colstats.get((outs[name].data_ptr(), M, N))
+        rec.run()
+        torch.cuda.synchronize()
+    y = x.float() @ w.float().t() + b
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:]) if geglu else y + res.float()
+    assert rel_l2(outs["big"], ref) < 1e-3
+    assert torch.equal(outs["big"], outs["small"])
+    if stats["small"] is not None:
+        assert torch.equal(stats["big"], stats["small"])
+
+
 @pytest.mark.parametrize("B,c0,c1,cout,hin,splitk", [(4, 64, 0, 320, 32, None), (2, 64, 64, 640, 16, None), (8, 1280, 0, 1280, 16, 4), (2, 640, 640, 320, 16, 2)])
 def test_conv3x3_256x320_tile_upsample_and_splitk(rec_cls, monkeypatch, B, c0, c1, cout, hin, splitk):
     """The x2-upsampling gather of pv_convbig.hip (source pixel of tap (ky, kx) = ((y + ky - 1) >> 1, (x + kx - 1) >> 1), selected per lane from the
@@ -194,7 +225,7 @@ def test_conv3x3_256x320_tile_upsample_and_splitk(rec_cls, monkeypatch, B, c0, c
         rec = rec_cls("cuda")
         outs[name] = rec.gemm(rows(x0), wp, a1=rows(x1) if c1 else None, bias=bias.cuda(), colstats=True, splitk=splitk,
                               conv=dict(batch=B, hin=hin, win=hin, hout=ho, wout=ho, upsample=int(ups)))
-        assert rec.tags[-1][0].startswith("conv_big_kernel" if name == "big" else "gemm_conv_kernel"), rec.tags[-1]
+        assert rec.tags[-1][0].startswith("big_tile_kernel" if name == "big" else "gemm_conv_kernel"), rec.tags[-1]
         stats[name] = rec.colstats.get((outs[name].data_ptr(), B * ho * ho, cout))
         rec.run()
         torch.cuda.synchronize()

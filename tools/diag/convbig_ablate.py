@@ -57,7 +57,7 @@ x = torch.randn(B * hw * hw, cin, device=dev).half()
 w = (torch.randn(cout, 9 * cin, device=dev) * 0.02).half()
 rec = Recorder(dev)
 rec.gemm(x, w, bias=torch.zeros(cout, device=dev), conv=dict(batch=B, hin=hw, win=hw, hout=hw, wout=hw))
-assert rec.tags[-1][0].startswith('conv_big_kernel')
+assert rec.tags[-1][0].startswith('big_tile_kernel')
 for _ in range(100): rec.run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

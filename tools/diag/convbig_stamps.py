@@ -53,7 +53,7 @@ w = (torch.randn(cout, 9 * cin, device=dev) * 0.02).half()
 rec = Recorder(dev)
 cs = os.environ.get("GC_COLSTATS", "1") == "1"
 rec.gemm(x, w, bias=torch.zeros(cout, device=dev), conv=dict(batch=B, hin=hw, win=hw, hout=hw, wout=hw), colstats=cs)
-assert rec.tags[-1][0].startswith("conv_big_kernel"), rec.tags[-1]
+assert rec.tags[-1][0].startswith("big_tile_kernel"), rec.tags[-1]
 for _ in range(200):
     rec.run()
 torch.cuda.synchronize()
