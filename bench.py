@@ -488,8 +488,10 @@ def main():
             flops = sum(t[1] for s_ in subs for t in s_.tags)
             kinds = sorted({t[0] for s_ in subs for t in s_.tags})
             ms = time_subs(subs)
-            layers = sum(1 for s_ in subs for t in s_.tags if t[0].startswith("xattn_fused_kernel") or t[0] in ("pv_cross_attention", "xattn_lnq_kernel"))
-            levels[str(C_)] = {"layers_per_step": layers, "launches_per_step": nl, "launches_per_layer": nl // max(layers, 1), "ms_per_step": round(ms, 4),
+            # layer instances: one SDPA launch per layer and forward; the merged low-resolution plan runs BOTH CFG forwards' layers in one launch
+            layers = sum((e.B // B) for e, s_ in zip(loop.all_engines, subs) for t in s_.tags
+                         if t[0].startswith("xattn_fused_kernel") or t[0] in ("pv_cross_attention", "xattn_lnq_kernel"))
+            levels[str(C_)] = {"layers_per_step": layers, "launches_per_step": nl, "launches_per_layer": sum((e.B // B) * len(s_) for e, s_ in zip(loop.all_engines, subs)) // max(layers, 1), "ms_per_step": round(ms, 4),
                                "us_per_layer": round(ms * 1e3 / max(layers, 1), 2), "achieved": round(flops / (ms * 1e-3) / 1e12, 1),
                                "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "kernels": kinds,
                                "fused": any(k.startswith("xattn_fused_kernel") for k in kinds), "head_parallel": "xattn_lnq_kernel" in kinds}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 11
+#define PV_ABI_VERSION 12
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -79,6 +79,13 @@ typedef struct pv_gemm_params {
                               squares of the (fp16-rounded) outputs - GroupNorm statistics of the tensor being written,
                               consumed by pv_groupnorm_stats_from_colstats.  NULL = off.  fp16 output, no geglu (with splitk > 1 the
                               reduce launch produces them). */
+    const float* ln_rowsum; /* optional (ABI 12) fp32 [N]: sum_k w[n][k] of the fp16 weights.  Non-NULL = the launch computes
+                              epilogue( LayerNorm_noaffine(a0) . w^T + bias ): BasicTransformerBlock.norm1 / norm3 [EXT] folded into the Linear that
+                              follows it - the GEMM runs on the RAW rows and the epilogue applies rstd * (acc - mean * ln_rowsum[n]); the caller
+                              folds the affine part (gamma scales the columns of w, w . beta joins the bias).  Row statistics come from the
+                              fragments the MFMAs consume.  Only the 256-row-tile Linear path takes it (taps == 1, K >= 640, c1 == 0, no split-K,
+                              N % 320 == 0 or geglu with N % 256 == 0, >= 256 tiles): anything else returns hipErrorInvalidValue. */
+    float ln_eps;
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 

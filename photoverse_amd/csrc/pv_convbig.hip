@@ -77,7 +77,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <bool CS, bool UPS, int MI, int MODE>
+// LN (Linear modes): LayerNorm without its affine part folded into the launch - the GEMM runs on the raw rows, the row statistics are accumulated from
+// the A fragments the MFMAs consume (v_dot2_f32_f16: in the shadow of the 40 MFMAs of a segment), the epilogue applies rstd * (acc - mean * rowsum(W)).
+template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
     constexpr int NF = MODE == 2 ? 4 : 5;
     constexpr int TAPS = MODE == 0 ? 9 : 1;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP, B_PIECES = Cfg::B_PIECES, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
     constexpr int P_HI = AP + BP, P_LO = AP + Cfg::BP_LO;      // LDS-DMA instructions per stage of a wave 0-3 / 4-7
     static_assert(!UPS || MODE == 0, "the upsampling gather belongs to the conv");
+    static_assert(!LN || (MODE != 0 && !CS), "the LayerNorm fold exists for the Linear modes (their outputs feed attention / a Linear: no column statistics)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = pv_lane_id();
     const int wave = pv_wave_id();
@@ -114,10 +117,9 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + (wave + i * NW) * 16 + prow;
         const bool ok = m < p.M;
-        if (MODE != 0) {                               // Linear: the row itself; "tap 0 inside the image" <=> the row exists
-            a_mask[i] = ok ? 1u : 0u;
-            a_off0[i] = (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2;
-            a_off1[i] = (unsigned)m * (unsigned)(p.lda1 * 2) + lane_cc2;
+        if (MODE != 0) {                               // Linear (single source): the row itself, or out of range past M; no masks, no second source
+            a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
+            a_off1[i] = a_mask[i] = 0;
             continue;
         }
         const int b = m / hw_out;
@@ -178,7 +180,10 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         const unsigned tap_bit = 1u << k.tap;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
-            if (j < AP) {
+            if (j < AP && MODE != 0) {
+                const unsigned off = a_off0[j] == OOB ? OOB : a_off0[j] + (unsigned)(c * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
+            } else if (j < AP) {
                 unsigned off = first ? a_off0[j] : a_off1[j];
                 if (UPS) off += (unsigned)(((a_mask[j] >> 9) & 1u ? oy_odd : oy_even) + ((a_mask[j] >> 10) & 1u ? ox_odd : ox_even) + sc2);
                 else off += (unsigned)tap_delta;
@@ -203,6 +208,9 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     const int frag_off = fr * ROW_BYTES + ((fq ^ swz((fr >> 2) & 3)) << 4);   // fragment row bases are multiples of 16: the swizzle only sees fr
 
     half8_t wb[NF], xa[MI];
+    float ln_s1[LN ? MI : 1], ln_s2[LN ? MI : 1];
+#pragma unroll
+    for (int mi = 0; mi < (LN ? MI : 1); ++mi) ln_s1[mi] = ln_s2[mi] = 0.f;
     auto read_frags = [&](int s) {                   // all 13 fragments of stage s: 5 column (W) + 8 row (A)
         const char* sa = smem + (s & (NBUF - 1)) * STAGE_BYTES + wm * (MI * 16) * ROW_BYTES + frag_off;
         const char* sb = smem + (s & (NBUF - 1)) * STAGE_BYTES + A_BYTES + wn * (NF * 16) * ROW_BYTES + frag_off;
@@ -240,12 +248,22 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers BEFORE the barrier: the buffer's reads are retired when it is refilled
         seg_barrier();
-        // ---- MFMA(s): 40 MFMAs ----
+        // ---- MFMA(s): 40 MFMAs (LN: + the row sums of the fragments, 8 v_dot2 per fragment) ----
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            if constexpr (LN) {
+                const half2_t one2 = half2_t{(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half2_t x2 = half2_t{xa[mi][2 * j], xa[mi][2 * j + 1]};
+                    ln_s1[mi] = __builtin_amdgcn_fdot2(x2, one2, ln_s1[mi], false);
+                    ln_s2[mi] = __builtin_amdgcn_fdot2(x2, x2, ln_s2[mi], false);
+                }
+            }
+        }
         if (wm == 0) {                                           // waves 0-3: stage s+1 is read right behind the next barrier
             if (s + 3 < ns) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<0>();
         }
@@ -265,6 +283,23 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         }
         return;
     }
+    // LN: mean / rstd of this lane's rows (the four lanes that share fr hold the four 8-channel groups of every 32-deep stage)
+    // (in place: ln_s1 becomes the mean, ln_s2 the reciprocal standard deviation)
+    if constexpr (LN) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float a = pv_quad_sum(ln_s1[mi]) / (float)K, q2 = pv_quad_sum(ln_s2[mi]) / (float)K;
+            ln_s1[mi] = a;
+            ln_s2[mi] = rsqrtf(fmaxf(q2 - a * a, 0.f) + p.ln_eps);
+        }
+    }
+    auto ln_fold = [&](float4_t v, const float4_t rs, int mi) {       // rstd * (acc - mean * rowsum)
+        if constexpr (LN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ln_s2[mi] * (v[r] - ln_s1[mi] * rs[r]);
+        }
+        return v;
+    };
     if constexpr (MODE == 2) {
         // ---- GEGLU epilogue (pv_gemm.hip's): the wave's four fragments are (value, gate) x two 16-column groups in pack_geglu's row order;
         // out[m][(n0 >> 1) + 32 wn + 16 q + ...] = (value + bias) * gelu(gate + bias), 16-byte stores through the lane-row swap ----
@@ -274,6 +309,12 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
             bv[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
             bg[q] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (2 * q + 1) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
         }
+        float4_t rv[2], rg[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rv[q] = LN ? *reinterpret_cast<const float4_t*>(p.ln_rowsum + nbase + (2 * q) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+            rg[q] = LN ? *reinterpret_cast<const float4_t*>(p.ln_rowsum + nbase + (2 * q + 1) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + arow + mi * 16;
@@ -281,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
             unsigned pk[2][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float4_t v = acc[2 * q][mi] + bv[q], g = acc[2 * q + 1][mi] + bg[q];
+                const float4_t v = ln_fold(acc[2 * q][mi], rv[q], mi) + bv[q], g = ln_fold(acc[2 * q + 1][mi], rg[q], mi) + bg[q];
                 pk[q][0] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[0] * pv_gelu_erf(g[0])), (half_t)(v[1] * pv_gelu_erf(g[1]))});
                 pk[q][1] = __builtin_bit_cast(unsigned, half2_t{(half_t)(v[2] * pv_gelu_erf(g[2])), (half_t)(v[3] * pv_gelu_erf(g[3]))});
             }
@@ -307,36 +348,42 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         // time-embedding row: one per IMAGE.  When the block's 64 rows lie inside one image (always, for hw_out % 64 == 0) it is loaded once
         // (added AFTER the bias, per element, as pv_gemm.hip does: the results stay bit-identical)
         const int mb0 = m0 + wm * (MI * 16) + hb * 64;
-        const bool one_image = p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);
-        float4_t radd_v[GN];
+        const bool one_image = MODE == 0 && p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);   // (the Linear modes keep the per-row form: no UNet Linear has a row term)
+        float4_t rs_v[GN];
 #pragma unroll
-        for (int t = 0; t < GN; ++t)
+        for (int t = 0; t < GN; ++t) rs_v[t] = LN ? *reinterpret_cast<const float4_t*>(p.ln_rowsum + nbase + (G0 + t) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
+        float4_t radd_v[MODE == 0 ? GN : 1];
+#pragma unroll
+        for (int t = 0; t < (MODE == 0 ? GN : 1); ++t)
             radd_v[t] = one_image ? *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(mb0 / hw_out) * p.rowadd_ld + nbase + (G0 + t) * 16)
                                   : float4_t{0.f, 0.f, 0.f, 0.f};
-        half4_t res[4][GN];
-        if (p.residual) {
+        constexpr int RB = LN ? 2 : 4;                 // residual rows in flight (the LayerNorm fold keeps 16 more registers live)
+        half4_t res[RB][GN];
+        auto fetch_res = [&](int q0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int mm = min(m0 + arow + (hb * 4 + q) * 16, p.M - 1);
+            for (int q = 0; q < RB; ++q) {
+                const int mm = min(m0 + arow + (hb * 4 + q0 + q) * 16, p.M - 1);
 #pragma unroll
                 for (int t = 0; t < GN; ++t)
                     res[q][t] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + (G0 + t) * 16);
             }
-        }
+        };
+        if (p.residual) fetch_res(0);
         float4_t cs[GN], cq[GN];
 #pragma unroll
         for (int t = 0; t < GN; ++t) cs[t] = cq[t] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mi = hb * 4 + q;
+            if (RB < 4 && q == RB && p.residual) fetch_res(RB);
             const int m = m0 + arow + mi * 16;
             if (m >= p.M) continue;
             const float* radd = (p.rowadd && !one_image) ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
             unsigned pk[GN][2];
 #pragma unroll
             for (int t = 0; t < GN; ++t) {
-                float4_t v = acc[G0 + t][mi] + add_v[t];
-                if (one_image) v += radd_v[t];
+                float4_t v = ln_fold(acc[G0 + t][mi], rs_v[t], mi) + add_v[t];
+                if (MODE == 0 && one_image) v += radd_v[MODE == 0 ? t : 0];
                 else if (radd) v += *reinterpret_cast<const float4_t*>(radd + (G0 + t) * 16);
                 if (p.act) {
 #pragma unroll
@@ -344,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
                 }
                 if (p.residual) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)res[q][t][r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[q % RB][t][r];
                 }
                 const half4_t hv = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 pk[t][0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
@@ -399,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     }
 }
 
-template <bool CS, bool UPS, int MI, int MODE>
+template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = BigCfg<MI, MODE == 2 ? 4 : 5>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = Cfg::SMEM_BYTES;
@@ -407,7 +454,7 @@ int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     bool& attr_set = attr_set_dev[dev_id & 63];
-    auto kern = big_tile_kernel<CS, UPS, MI, MODE>;
+    auto kern = big_tile_kernel<CS, UPS, MI, MODE, LN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -438,6 +485,10 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
         const int bn = p.geglu ? 256 : 320;
         if (p.c1 || splits > 1 || p.out_f32 || cin < 640 || (p.N % bn) || (p.geglu && p.colstats)) return -1;
         if ((long)((p.M + 255) / 256) * (p.N / bn) < min_tiles) return -1;
+        if (p.ln_rowsum) {
+            if (p.colstats) return -1;
+            return p.geglu ? launch_big<false, false, 8, 2, true>(p, stream) : launch_big<false, false, 8, 1, true>(p, stream);
+        }
         if (p.geglu) return launch_big<false, false, 8, 2>(p, stream);
         return p.colstats ? launch_big<true, false, 8, 1>(p, stream) : launch_big<false, false, 8, 1>(p, stream);
     }

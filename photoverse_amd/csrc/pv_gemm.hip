@@ -613,6 +613,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
         const int rc = pv_conv_big_launch(p, stream);
         if (rc >= 0) return rc;
     }
+    if (p.ln_rowsum) return (int)hipErrorInvalidValue;   // the LayerNorm fold exists on the 256-row-tile Linear path only (header)
     if (p.geglu) return dispatch<4, false, true>(p, stream);
     const bool conv = p.taps == 9;
     if (p.N % 160 == 0) return conv ? dispatch<5, true, false>(p, stream) : dispatch<5, false, false>(p, stream);

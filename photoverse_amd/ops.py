@@ -154,11 +154,14 @@ class Recorder:
     def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
              rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
              out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None,
-             colstats: bool = False, colstats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             colstats: bool = False, colstats_out: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None, ln_eps: float = 1e-5) -> torch.Tensor:
         """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin].
         ``colstats``: the output feeds a GroupNorm - let the epilogue leave its per-column (sum, sum of squares) behind so that
         ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: fp32, GEGLU; with split-K the
-        reduce launch produces them)."""
+        reduce launch produces them).
+        ``ln_gamma`` / ``ln_beta``: ``out = epilogue(LayerNorm(a) @ W^T + bias)`` in ONE launch (``gemm_ln_supported`` says where): the affine part is
+        folded here, at plan-build time (gamma scales the columns of w - for ``geglu`` BEFORE the caller's ``pack_geglu``, so pass the packed weight
+        of an already scaled matrix via ``fold_layernorm`` -, w . beta joins the bias), the kernel normalises through its epilogue."""
         lda0, c0 = _rows(a)
         lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
         taps = 9 if conv is not None else 1
@@ -204,9 +207,13 @@ class Recorder:
             assert cs.shape == ((M + 63) // 64, 2, N) and cs.dtype == torch.float32 and cs.is_contiguous()
         else:
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
+        ln_rowsum = None
+        if ln_gamma is not None:
+            assert Recorder.gemm_ln_supported(M, N, kdim, geglu) and conv is None and a1 is None and not colstats and splitk == 1
+            ln_rowsum = w.float().sum(1).contiguous()            # of the fp16 values the MFMAs see (w already carries gamma: fold_layernorm)
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs))
-        self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out) if t is not None)
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps))
+        self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MI>
         # (MULTI = the tile-loop instantiation pv_gemm.hip's choose_tpw picks for the short-K GEGLU layers with >= 1024 workgroups)
@@ -221,13 +228,35 @@ class Recorder:
         # pv_convbig.hip's 256-row tile (pv_conv_big_launch's rules): 3x3 convs, and Linear layers with K >= 640 (GEGLU: 256-column tiles)
         if big_shape and not (out_f32 and splitk == 1) and (splitk == 1 or (kdim // 64) // splitk >= 8):
             if tiles256 * splitk >= big_min:
-                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, 0>"
+                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, 0, false>"
         bn_big = 256 if geglu else 320
         if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
                 and N % bn_big == 0 and not (geglu and cs is not None) and ((M + 255) // 256) * (N // bn_big) >= big_min):
-            name = f"big_tile_kernel<{'true' if cs is not None else 'false'}, false, 8, {2 if geglu else 1}>"
+            name = f"big_tile_kernel<{'true' if cs is not None else 'false'}, false, 8, {2 if geglu else 1}, {'true' if ln_rowsum is not None else 'false'}>"
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
         return out
+
+    #: LayerNorm folded into the 256-row-tile Linear launches (norm1 -> qkv, norm3 -> GEGLU at the 32 x 32 / 16 x 16 levels).  OFF by default: it removes
+    #: 28 LayerNorm launches and 1.2 GB of HBM traffic per step and is exact to the same 2.5e-4, but measured 31.05 -> 30.98 steps/s same box (the
+    #: v_dot2 row sums ride in the MFMA segments of a pair whose partner is issuing its LDS-DMA: not free).  PV_GEMM_LN=1 enables it.
+    GEMM_LN = os.environ.get("PV_GEMM_LN", "0") != "0"
+
+    @staticmethod
+    def gemm_ln_supported(M: int, N: int, K: int, geglu: bool) -> bool:
+        """Where ``gemm(ln_gamma=...)`` exists: the Linear modes of the 256-row tile (pv_conv_big_launch's rule)."""
+        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
+        bn = 256 if geglu else 320
+        return (Recorder.GEMM_LN and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and K >= 640 and N % bn == 0
+                and ((M + 255) // 256) * (N // bn) >= big_min)
+
+    @staticmethod
+    def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+        """LayerNorm's affine part folded into the Linear behind it: (w diag(gamma), bias + w . beta), w fp16 [N][K] in NATURAL row order."""
+        w32 = w.float()
+        b = w32 @ beta.float().to(w.device)
+        if bias is not None:
+            b = b + bias.float()
+        return (w32 * gamma.float().to(w.device)[None, :]).to(torch.float16).contiguous(), b.contiguous()
 
     def groupnorm(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5,
                   act=ACT_NONE, groups=32, return_stats=False) -> torch.Tensor:

@@ -280,6 +280,10 @@ class UNetEngine:
         if USE_ROWGEMM and Recorder.row_gemm_supported(C, 3 * C):
             # norm1 + [to_q; to_k; to_v] as ONE row-owning launch (pv_rowgemm.hip): rows normalised in registers, weights streamed
             qkv = rec.row_gemm(hs, wqkv, ln_gamma=_f32(blk.norm1.weight), ln_beta=_f32(blk.norm1.bias), ln_eps=blk.norm1.eps)
+        elif Recorder.gemm_ln_supported(b * n, 3 * C, C, False):
+            # norm1 folded into the fused qkv Linear on the 256-row tile: the GEMM reads the raw rows, the epilogue normalises
+            wl, bl = Recorder.fold_layernorm(wqkv, None, _f32(blk.norm1.weight), _f32(blk.norm1.bias))
+            qkv = rec.gemm(hs, wl, bias=bl, rows_per_image=n, ln_gamma=True, ln_eps=blk.norm1.eps, splitk=0)
         else:
             n1 = rec.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
             qkv = rec.gemm(n1, wqkv, rows_per_image=n)
@@ -328,6 +332,11 @@ class UNetEngine:
             # norm3 + GEGLU projection + gate as ONE row-owning launch
             wg, bg = pack_geglu_rows(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
             gg = rec.row_gemm(hs, wg, bias=bg, ln_gamma=_f32(blk.norm3.weight), ln_beta=_f32(blk.norm3.bias), ln_eps=blk.norm3.eps, geglu=True)
+        elif Recorder.gemm_ln_supported(b * n, blk.ff.net[0].proj.weight.shape[0], C, True):
+            # norm3 folded into the GEGLU projection (256-row tile, 256-column tiles)
+            wl, bl = Recorder.fold_layernorm(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias), _f32(blk.norm3.weight), _f32(blk.norm3.bias))
+            wg, bg = pack_geglu(wl, bl)
+            gg = rec.gemm(hs, wg, bias=bg, geglu=True, rows_per_image=n, ln_gamma=True, ln_eps=blk.norm3.eps)
         else:
             n3 = rec.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
             wg, bg = pack_geglu(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))

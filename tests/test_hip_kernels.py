@@ -206,6 +206,41 @@ def test_linear_on_the_256_row_tile_equals_the_128_row_kernel_bitwise(rec_cls, m
         assert torch.equal(stats["big"], stats["small"])
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(16384, 1920, 640, False), (8192 + 72, 3840, 1280, False), (16384, 5120, 640, True), (4096 + 40, 10240, 1280, True)])
+def test_layernorm_folded_into_the_linear_behind_it(rec_cls, monkeypatch, M, N, K, geglu):
+    """pv_gemm_params.ln_rowsum (ABI 12): norm1 -> fused qkv and norm3 -> GEGLU projection of the 32 x 32 / 16 x 16 transformer blocks as ONE launch on
+    the 256-row tile - the GEMM runs on the raw rows, the row statistics come from the MFMA fragments, the epilogue applies
+    rstd * (acc - mean * rowsum(W)) - vs fp32 torch and vs the two launches it replaces (LayerNorm, GEMM); large row means exercise the cancellation."""
+    from photoverse_amd import ops
+    from photoverse_amd.ops import pack_geglu
+    monkeypatch.setattr(ops.Recorder, "GEMM_LN", True)          # (off by default: measured neutral-to-negative in the loop; the entry point stays tested)
+    x = h16(M, K, seed=160)
+    x[:, ::5] += 1.0
+    x[: M // 2] += 3.0
+    w = h16(N, K, scale=K ** -0.5, seed=161)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(162))
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(163))
+    beta = 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(164))
+    assert ops.Recorder.gemm_ln_supported(M, N, K, geglu)
+    rec = rec_cls("cuda")
+    dx, dw, db = x.cuda(), w.cuda(), b.cuda()
+    wl, bl = ops.Recorder.fold_layernorm(dw, db, gamma, beta)
+    if geglu:
+        wl, bl = pack_geglu(wl, bl)
+    out = rec.gemm(dx, wl, bias=bl, geglu=geglu, ln_gamma=True, splitk=0)
+    assert rec.tags[-1][0].startswith("big_tile_kernel") and rec.tags[-1][0].endswith("true>"), rec.tags[-1]
+    n1 = rec.layernorm(dx, gamma.cuda(), beta.cuda())
+    w2, b2 = pack_geglu(dw, db) if geglu else (dw, db)
+    two = rec.gemm(n1, w2, bias=b2, geglu=geglu, splitk=0)
+    rec.run()
+    torch.cuda.synchronize()
+    y = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.float().t() + b
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:]) if geglu else y
+    e1, e2 = rel_l2(out, ref), rel_l2(two, ref)
+    print(f"LayerNorm folded into the Linear M={M} N={N} K={K} geglu={geglu}: vs fp32 {e1:.2e} (two launches: {e2:.2e})")
+    assert torch.isfinite(out).all() and e1 < 1e-3 and e2 < 1e-3 and rel_l2(out, two) < 1e-3
+
+
 @pytest.mark.parametrize("B,c0,c1,cout,hin,splitk", [(4, 64, 0, 320, 32, None), (2, 64, 64, 640, 16, None), (8, 1280, 0, 1280, 16, 4), (2, 640, 640, 320, 16, 2)])
 def test_conv3x3_256x320_tile_upsample_and_splitk(rec_cls, monkeypatch, B, c0, c1, cout, hin, splitk):
     """The x2-upsampling gather of pv_convbig.hip (source pixel of tap (ky, kx) = ((y + ky - 1) >> 1, (x + kx - 1) >> 1), selected per lane from the
