@@ -86,6 +86,9 @@ typedef struct pv_gemm_params {
                               fragments the MFMAs consume.  Only the 256-row-tile Linear path takes it (taps == 1, K >= 640, c1 == 0, no split-K,
                               N % 320 == 0 or geglu with N % 256 == 0, >= 256 tiles): anything else returns hipErrorInvalidValue. */
     float ln_eps;
+    int32_t big_tile_min;  /* (ABI 12) 256-row-tile path (pv_convbig.hip): minimum number of 256-row tiles (x K slices) the launch must have to take it.
+                              0 = library default (256 = one workgroup per CU; env PV_CONV_BIG overrides), < 0 = never.  A caller that runs two such
+                              launches side by side on two streams (the uncond / cond forwards of a CFG step) passes 128: each fills half the chip. */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 

@@ -19,7 +19,7 @@ class GemmParams(C.Structure):
                 ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
                 ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
                 ("upsample", c_int), ("pad", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int),
-                ("splitk", c_int), ("splitk_ws", c_void_p), ("colstats", c_void_p), ("ln_rowsum", c_void_p), ("ln_eps", c_float)]
+                ("splitk", c_int), ("splitk_ws", c_void_p), ("colstats", c_void_p), ("ln_rowsum", c_void_p), ("ln_eps", c_float), ("big_tile_min", c_int)]
 
 
 class GroupNormParams(C.Structure):

@@ -473,7 +473,7 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     // PV_CONV_BIG: 0 = never (the 128-row kernel everywhere), otherwise the minimum number of 256-row tiles a launch must have
     // (read per call, not cached: the parity test runs both kernels in one process; launches are recorded once and replayed from graphs)
     const char* env = getenv("PV_CONV_BIG");
-    const int min_tiles = env ? atoi(env) : 256;
+    const int min_tiles = p.big_tile_min ? p.big_tile_min : (env ? atoi(env) : 256);     // the caller's threshold wins (pv_gemm_params.big_tile_min)
     if (min_tiles <= 0) return -1;
     const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     const int cin = p.c0 + p.c1;

@@ -92,6 +92,9 @@ class Recorder:
         self.keep: List[object] = []       # tensors / structs referenced by raw pointer
         self.colstats: dict = {}           # (data_ptr, rows, cols) of a GEMM output -> its epilogue column statistics
         self.bytes_allocated = 0
+        #: minimum number of 256-row tiles for pv_convbig.hip's tile (pv_gemm_params.big_tile_min): 256 = one workgroup per CU; a plan that runs beside
+        #: another one on a second stream (the two CFG forwards) uses 128; env PV_CONV_BIG overrides (0 = never)
+        self.big_min = int(os.environ["PV_CONV_BIG"]) if "PV_CONV_BIG" in os.environ else 256
 
     # ------------------------------------------------------------------ memory
     def empty(self, shape, dtype=torch.float16) -> torch.Tensor:
@@ -114,7 +117,7 @@ class Recorder:
     def subset(self, pred) -> "Recorder":
         """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
         r = Recorder.__new__(Recorder)
-        r.lib, r.device, r.keep, r.bytes_allocated, r.colstats = self.lib, self.device, self.keep, 0, self.colstats
+        r.lib, r.device, r.keep, r.bytes_allocated, r.colstats, r.big_min = self.lib, self.device, self.keep, 0, self.colstats, self.big_min
         sel = [i for i, t in enumerate(self.tags) if pred(t)]
         r.calls = [self.calls[i] for i in sel]
         r.tags = [self.tags[i] for i in sel]
@@ -191,7 +194,7 @@ class Recorder:
         splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
         # pv_convbig.hip's 256 x 320 tile on the 16 x 16 level: 64 tiles x BIG_SPLITK K-slices = one workgroup per CU (the 128-row kernel runs
         # these convs as 256 tiles x 2 slices)
-        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
+        big_min = self.big_min
         up = 2 if (conv is not None and geo[6]) else 1
         big_shape = (conv is not None and big_min > 0 and geo[5] == 1 and geo[7] == 1 and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
         tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
@@ -209,10 +212,10 @@ class Recorder:
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
         ln_rowsum = None
         if ln_gamma is not None:
-            assert Recorder.gemm_ln_supported(M, N, kdim, geglu) and conv is None and a1 is None and not colstats and splitk == 1
+            assert Recorder.gemm_ln_supported(M, N, kdim, geglu, self.big_min) and conv is None and a1 is None and not colstats and splitk == 1
             ln_rowsum = w.float().sum(1).contiguous()            # of the fp16 values the MFMAs see (w already carries gamma: fold_layernorm)
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps))
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps), big_min if big_min > 0 else -1)
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MI>
@@ -242,9 +245,9 @@ class Recorder:
     GEMM_LN = os.environ.get("PV_GEMM_LN", "0") != "0"
 
     @staticmethod
-    def gemm_ln_supported(M: int, N: int, K: int, geglu: bool) -> bool:
+    def gemm_ln_supported(M: int, N: int, K: int, geglu: bool, big_min: Optional[int] = None) -> bool:
         """Where ``gemm(ln_gamma=...)`` exists: the Linear modes of the 256-row tile (pv_conv_big_launch's rule)."""
-        big_min = int(os.environ.get("PV_CONV_BIG", "256"))
+        big_min = int(os.environ.get("PV_CONV_BIG", "256")) if big_min is None else big_min
         bn = 256 if geglu else 320
         return (Recorder.GEMM_LN and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and K >= 640 and N % bn == 0
                 and ((M + 255) // 256) * (N // bn) >= big_min)

@@ -85,16 +85,19 @@ class DenoiseLoop:
             mid_out = torch.empty((2 * batch * n_out, c_out), dtype=f16, device=dev)
             mid_out_cs = torch.zeros((2 * batch * n_out // 64, 2, c_out), dtype=f32, device=dev)
             kw = dict(timesteps=self.timesteps, state=self.state, n_text=n_text, split=split)
+            side_by_side = dict(big_min=128) if two_streams else {}      # heads / tails of the two branches run concurrently: half the chip each
             for i, (text, ip, eps, lst) in enumerate(((self.text_u, self.ip_u, self.eps_u, self.engines_u), (self.text_c, self.ip_c, self.eps_c, self.engines_c))):
                 half_in = (mid_in[i * batch * n_in:(i + 1) * batch * n_in], mid_in_cs[i * batch * n_in // 64:(i + 1) * batch * n_in // 64])
                 half_out = (mid_out[i * batch * n_out:(i + 1) * batch * n_out], mid_out_cs[i * batch * n_out // 64:(i + 1) * batch * n_out // 64])
                 lst.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, text=text, ip=ip, out=eps, segment="outer",
-                                       mid_in=half_in, mid_out=half_out, **kw))
+                                       mid_in=half_in, mid_out=half_out, **kw, **side_by_side))
             self.engines_m.append(unet.engine(2 * batch, latent_size, latent_size, n_ip, 1, text=text_all, ip=ip_all, segment="mid",
                                               mid_in=(mid_in, mid_in_cs), mid_out=(mid_out, mid_out_cs), **kw))
         for i in range(0 if self.merge_lowres else batch_splits):
             sl = slice(i * sb, (i + 1) * sb)
             kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text)
+            if two_streams and batch_splits == 1:
+                kw.update(big_min=128)                    # the two whole forwards run side by side
             if training_mode:
                 kw.update(device_fusion="last_step")
             fs = dict(fusion_seed=fusion_seed * 4096 + 2 * i) if training_mode else {}

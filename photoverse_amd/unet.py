@@ -194,7 +194,7 @@ class UNetEngine:
                  timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
                  latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
                  ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, device_fusion: Optional[str] = None,
-                 fusion_seed: int = 0, segment: Optional[str] = None, split: int = 2, mid_in=None, mid_out=None):
+                 fusion_seed: int = 0, segment: Optional[str] = None, split: int = 2, mid_in=None, mid_out=None, big_min: Optional[int] = None):
         """``device_fusion``: None - branch weights (w_text, w_ip) are launch parameters patched by the host (``_set_fusion``);
         ``"always"`` - every forward draws them on the device (grad-mode semantics of attention_processor.py:413-420, graph-safe);
         ``"last_step"`` - drawn only when the loop state says this is the last denoising step (``run_inference(training_mode=True)``,
@@ -219,6 +219,11 @@ class UNetEngine:
         # launches that depend on the conditioning only (text / image-token K,V projections of the 16 cross-attention layers,
         # attention_processor.py:304-305,392-393): replayed when the conditioning changes, NOT every denoising step
         self.rec_cond = Recorder(device)
+        if big_min is not None and "PV_CONV_BIG" not in os.environ:
+            # this plan runs beside another one on a second stream: a launch of 128 one-per-CU workgroups fills ITS half of the chip
+            for r in (rec, self.rec_tail):
+                if r is not None:
+                    r.big_min = big_min
         dev = rec.device
         xdim = cfg.cross_attention_dim
         self.x_in = latents_in if latents_in is not None else rec.empty((batch, cfg.in_channels, h, w), torch.float32)
@@ -280,7 +285,7 @@ class UNetEngine:
         if USE_ROWGEMM and Recorder.row_gemm_supported(C, 3 * C):
             # norm1 + [to_q; to_k; to_v] as ONE row-owning launch (pv_rowgemm.hip): rows normalised in registers, weights streamed
             qkv = rec.row_gemm(hs, wqkv, ln_gamma=_f32(blk.norm1.weight), ln_beta=_f32(blk.norm1.bias), ln_eps=blk.norm1.eps)
-        elif Recorder.gemm_ln_supported(b * n, 3 * C, C, False):
+        elif Recorder.gemm_ln_supported(b * n, 3 * C, C, False, rec.big_min):
             # norm1 folded into the fused qkv Linear on the 256-row tile: the GEMM reads the raw rows, the epilogue normalises
             wl, bl = Recorder.fold_layernorm(wqkv, None, _f32(blk.norm1.weight), _f32(blk.norm1.bias))
             qkv = rec.gemm(hs, wl, bias=bl, rows_per_image=n, ln_gamma=True, ln_eps=blk.norm1.eps, splitk=0)
@@ -332,7 +337,7 @@ class UNetEngine:
             # norm3 + GEGLU projection + gate as ONE row-owning launch
             wg, bg = pack_geglu_rows(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias))
             gg = rec.row_gemm(hs, wg, bias=bg, ln_gamma=_f32(blk.norm3.weight), ln_beta=_f32(blk.norm3.bias), ln_eps=blk.norm3.eps, geglu=True)
-        elif Recorder.gemm_ln_supported(b * n, blk.ff.net[0].proj.weight.shape[0], C, True):
+        elif Recorder.gemm_ln_supported(b * n, blk.ff.net[0].proj.weight.shape[0], C, True, rec.big_min):
             # norm3 folded into the GEGLU projection (256-row tile, 256-column tiles)
             wl, bl = Recorder.fold_layernorm(_f16(blk.ff.net[0].proj.weight), _f32(blk.ff.net[0].proj.bias), _f32(blk.norm3.weight), _f32(blk.norm3.bias))
             wg, bg = pack_geglu(wl, bl)
