@@ -336,66 +336,78 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         }
         return;
     }
-    // ---- epilogue (pv_gemm.hip's arithmetic; walked per 64-row block and per COLUMN GROUP - the fragment pairs (0,1), (2,3) and fragment 4 -
-    // so that next to the 160 accumulators only one group's bias, residual rows and column statistics are live: no scratch) ----
+    // ---- epilogue (pv_gemm.hip's arithmetic, element for element).  All 256 workgroups of a launch reach it together and 42 MB leave at once: it runs at
+    // the chip's store bandwidth (~21 k cycles), PROVIDED the stores start with the first row and each wave writes whole 160-byte row pieces: walking
+    // column groups (64 + 64 + 32-byte pieces at three different times) measured 33-37 k cycles, staging the tile through LDS for 640-byte row stores
+    // (arithmetic and stores serialised by barriers) 42 k.  So: ONE pass per 64-row block over all five fragments, and what used to spill next to the 160
+    // accumulators - bias, LayerNorm row sums, the block's time-embedding row - is staged once in the released ring and re-read per row. ----
+    float* s_bias = reinterpret_cast<float*>(smem);           // [BN]
+    float* s_rs = s_bias + BN;                                // [BN] (LN)
+    float* s_radd = s_rs + BN;                                // [2 * MI / 4][BN]: block (wm, hb) -> its image's row (MODE 0)
+    static_assert((2 + 2 * (MI / 4)) * BN * 4 <= BigCfg<MI, NF>::SMEM_BYTES, "the epilogue staging must fit the ring");
+    if constexpr (NF == 5) {
+        const int tid = (int)threadIdx.x;
+        for (int i = tid; i < BN; i += NW * 64) {
+            s_bias[i] = p.bias ? p.bias[n0 + i] : 0.f;
+            if (LN) s_rs[i] = p.ln_rowsum[n0 + i];
+        }
+        if (MODE == 0 && p.rowadd) {
+            for (int i = tid; i < 2 * (MI / 4) * BN; i += NW * 64) {
+                const int blk = i / BN, c = i - blk * BN;
+                const int img = min(m0 + blk * 64, p.M - 1) / hw_out;
+                s_radd[i] = p.rowadd[(size_t)img * p.rowadd_ld + n0 + c];
+            }
+        }
+        __syncthreads();
+    }
+    const int ncol = wn * (NF * 16) + fq * 4;                  // this lane's first column inside the tile
     const bool want_cs = CS && p.colstats != nullptr;
-    auto group = [&](int hb, auto g0c, auto gnc) {
-        constexpr int G0 = decltype(g0c)::value, GN = decltype(gnc)::value;     // fragments G0 .. G0 + GN - 1
-        float4_t add_v[GN];
-#pragma unroll
-        for (int t = 0; t < GN; ++t)
-            add_v[t] = p.bias ? *reinterpret_cast<const float4_t*>(p.bias + nbase + (G0 + t) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
-        // time-embedding row: one per IMAGE.  When the block's 64 rows lie inside one image (always, for hw_out % 64 == 0) it is loaded once
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+    auto block = [&](int hb) {
+        // time-embedding row: one per IMAGE.  When the block's 64 rows lie inside one image (always, for hw_out % 64 == 0) it is the staged one
         // (added AFTER the bias, per element, as pv_gemm.hip does: the results stay bit-identical)
         const int mb0 = m0 + wm * (MI * 16) + hb * 64;
         const bool one_image = MODE == 0 && p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);   // (the Linear modes keep the per-row form: no UNet Linear has a row term)
-        float4_t rs_v[GN];
+        const float* s_ra = s_radd + (wm * (MI / 4) + hb) * BN + ncol;
+        constexpr int RBUF = CS ? 1 : 2;               // residual rows: one in use (+ one in flight, unless the 40 statistics registers are live too)
+        half4_t res[RBUF][NF];
+        auto fetch_res = [&](int q) {
+            const int mm = min(m0 + arow + (hb * 4 + q) * 16, p.M - 1);
 #pragma unroll
-        for (int t = 0; t < GN; ++t) rs_v[t] = LN ? *reinterpret_cast<const float4_t*>(p.ln_rowsum + nbase + (G0 + t) * 16) : float4_t{0.f, 0.f, 0.f, 0.f};
-        float4_t radd_v[MODE == 0 ? GN : 1];
-#pragma unroll
-        for (int t = 0; t < (MODE == 0 ? GN : 1); ++t)
-            radd_v[t] = one_image ? *reinterpret_cast<const float4_t*>(p.rowadd + (size_t)(mb0 / hw_out) * p.rowadd_ld + nbase + (G0 + t) * 16)
-                                  : float4_t{0.f, 0.f, 0.f, 0.f};
-        constexpr int RB = LN ? 2 : 4;                 // residual rows in flight (the LayerNorm fold keeps 16 more registers live)
-        half4_t res[RB][GN];
-        auto fetch_res = [&](int q0) {
-#pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                const int mm = min(m0 + arow + (hb * 4 + q0 + q) * 16, p.M - 1);
-#pragma unroll
-                for (int t = 0; t < GN; ++t)
-                    res[q][t] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + (G0 + t) * 16);
-            }
+            for (int t = 0; t < NF; ++t)
+                res[q % RBUF][t] = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.residual) + (size_t)mm * p.ldr + nbase + t * 16);
         };
-        if (p.residual) fetch_res(0);
-        float4_t cs[GN], cq[GN];
+        if (RBUF == 2 && p.residual) fetch_res(0);
+        float4_t cs[NF], cq[NF];
 #pragma unroll
-        for (int t = 0; t < GN; ++t) cs[t] = cq[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NF; ++t) cs[t] = cq[t] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mi = hb * 4 + q;
-            if (RB < 4 && q == RB && p.residual) fetch_res(RB);
+            if (p.residual && (RBUF == 1 || q + 1 < 4)) fetch_res(RBUF == 1 ? q : q + 1);
             const int m = m0 + arow + mi * 16;
             if (m >= p.M) continue;
+            asm volatile("" ::: "memory");             // the staged operands are RE-READ per row (held across the rows they would spill)
             const float* radd = (p.rowadd && !one_image) ? p.rowadd + (size_t)(m / hw_out) * p.rowadd_ld + nbase : nullptr;
-            unsigned pk[GN][2];
-#pragma unroll
-            for (int t = 0; t < GN; ++t) {
-                float4_t v = ln_fold(acc[G0 + t][mi], rs_v[t], mi) + add_v[t];
-                if (MODE == 0 && one_image) v += radd_v[MODE == 0 ? t : 0];
-                else if (radd) v += *reinterpret_cast<const float4_t*>(radd + (G0 + t) * 16);
+            half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n0 + wn * (NF * 16);
+            auto value = [&](int t, unsigned (&pk)[2]) {
+                float4_t v = acc[t][mi];
+                if constexpr (LN) v = ln_fold(v, *reinterpret_cast<const float4_t*>(s_rs + ncol + t * 16), mi);
+                v += *reinterpret_cast<const float4_t*>(s_bias + ncol + t * 16);
+                if (MODE == 0 && one_image) v += *reinterpret_cast<const float4_t*>(s_ra + t * 16);
+                else if (radd) v += *reinterpret_cast<const float4_t*>(radd + t * 16);
                 if (p.act) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], p.act);
                 }
                 if (p.residual) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)res[q % RB][t][r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)res[q % RBUF][t][r];
                 }
                 const half4_t hv = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                pk[t][0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
-                pk[t][1] = __builtin_bit_cast(unsigned, half2_t{hv[2], hv[3]});
+                pk[0] = __builtin_bit_cast(unsigned, half2_t{hv[0], hv[1]});
+                pk[1] = __builtin_bit_cast(unsigned, half2_t{hv[2], hv[3]});
                 if (want_cs) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -404,23 +416,28 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
                         cq[t][r] += f * f;
                     }
                 }
-            }
-            half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n0 + wn * (NF * 16);
-            if constexpr (GN == 2) {      // 16-byte stores: v_permlane16_swap trades the even lane rows' second fragment against the odd lane rows' first
-                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            };
+#pragma unroll
+            for (int t = 0; t + 1 < NF; t += 2) {   // a fragment pair at a time (the row's 160 bytes still leave within a few hundred cycles): 16-byte stores -
+                unsigned pa[2], pb[2];              // v_permlane16_swap trades the even lane rows' second fragment against the odd lane rows' first
+                value(t, pa);
+                value(t + 1, pb);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                 const unsigned a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
-                const int col = (fq & 1) ? (G0 + 1) * 16 + (fq - 1) * 4 : G0 * 16 + fq * 4;
-                typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+                const int col = (fq & 1) ? (t + 1) * 16 + (fq - 1) * 4 : t * 16 + fq * 4;
                 *reinterpret_cast<uint4_t*>(orow + col) = uint4_t{a0, a1, b0, b1};
-            } else {
-                typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<uint2_t*>(orow + G0 * 16 + fq * 4) = uint2_t{pk[0][0], pk[0][1]};
+                asm volatile("" ::: "memory");
+            }
+            if constexpr (NF & 1) {                 // the odd fifth fragment: 8-byte stores
+                unsigned pa[2];
+                value(NF - 1, pa);
+                *reinterpret_cast<uint2_t*>(orow + (NF - 1) * 16 + fq * 4) = uint2_t{pa[0], pa[1]};
             }
         }
         if (want_cs && mb0 < p.M) {
 #pragma unroll
-            for (int t = 0; t < GN; ++t)
+            for (int t = 0; t < NF; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     cs[t][r] = row16_sum(cs[t][r]);
@@ -429,20 +446,16 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
             if (fr == 0) {
                 float* dst = p.colstats + ((size_t)(m0 / 64 + wm * (MI / 4) + hb) * 2) * p.N + nbase;
 #pragma unroll
-                for (int t = 0; t < GN; ++t) {
-                    *reinterpret_cast<float4_t*>(dst + (G0 + t) * 16) = cs[t];
-                    *reinterpret_cast<float4_t*>(dst + p.N + (G0 + t) * 16) = cq[t];
+                for (int t = 0; t < NF; ++t) {
+                    *reinterpret_cast<float4_t*>(dst + t * 16) = cs[t];
+                    *reinterpret_cast<float4_t*>(dst + p.N + t * 16) = cq[t];
                 }
             }
         }
     };
     if constexpr (NF == 5) {
 #pragma unroll
-        for (int hb = 0; hb < MI / 4; ++hb) {
-            group(hb, IC<0>{}, IC<2>{});
-            group(hb, IC<2>{}, IC<2>{});
-            group(hb, IC<4>{}, IC<1>{});
-        }
+        for (int hb = 0; hb < MI / 4; ++hb) block(hb);
     }
 }
 

@@ -236,7 +236,9 @@ class Recorder:
         if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
                 and N % bn_big == 0 and not (geglu and cs is not None) and ((M + 255) // 256) * (N // bn_big) >= big_min):
             name = f"big_tile_kernel<{'true' if cs is not None else 'false'}, false, 8, {2 if geglu else 1}, {'true' if ln_rowsum is not None else 'false'}>"
-        self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out)))
+        # 4th tag field: workgroups of the launch (bench.py separates the chip-filling launches of the one-per-CU tile from the half-chip ones)
+        wgs = (((M + 255) // 256) * (N // (256 if geglu else 320)) if name.startswith("big_tile_kernel") else ((M + 127) // 128) * max(N // bn, 1)) * splitk
+        self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out), wgs))
         return out
 
     #: LayerNorm folded into the 256-row-tile Linear launches (norm1 -> qkv, norm3 -> GEGLU at the 32 x 32 / 16 x 16 levels).  OFF by default: it removes

@@ -16,7 +16,7 @@ variants = {
     "no LDS-DMA in the loop": lambda s: s.replace("        if (s + 3 < ns) issue(kn, IC<0>{}, IC<AP + BP>{});\n", ""),
     "no fragment reads in the loop": lambda s: s.replace("        read_frags(s);\n", "        if (s == 0) read_frags(s);\n        asm volatile(\"\" : \"+v\"(xa[0]), \"+v\"(wb[0]));\n"),
     "A pieces only": lambda s: s.replace("} else if (j - AP < BP - 1 || b_full) {", "} else if (false) {"),
-    "W pieces only": lambda s: s.replace("            if (j < AP) {\n                const unsigned off", "            if (j < AP) {\n                if (k.s > 2) continue;\n                const unsigned off"),
+    "W pieces only": lambda s: s.replace("            } else if (j < AP) {\n                unsigned off", "            } else if (j < AP) {\n                if (k.s > 2) continue;\n                unsigned off"),
     "no MFMA, no reads (LDS-DMA + barriers only)": lambda s: variants["no fragment reads in the loop"](variants["no MFMA (operands kept live)"](s)),
 }
 sel = os.environ.get("CB_VARIANTS")

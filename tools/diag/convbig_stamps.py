@@ -31,7 +31,8 @@ out = parts[0]
 for i in range(2):
     out += "        if (s == %s) STAMP(%d);\n        seg_barrier();\n        if (s == %s) STAMP(%d);\n" % (STEP, 5 + 2 * i, STEP, 6 + 2 * i) + parts[i + 1]
 s = s[:body0] + out + s[body1:]
-tail = "                    *reinterpret_cast<float4_t*>(dst + p.N + ni * 16) = cq[ni];\n                }\n            }\n        }\n    }\n}"
+# end of kernel: behind the group epilogue's loop
+tail = "        for (int hb = 0; hb < MI / 4; ++hb) block(hb);\n    }\n}"
 s = sub1(s, tail, tail[:-1] + "    STAMP(3);\n}")
 s += '\nextern "C" int pv_gc_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_stamps), 64 * 8); }\n'
 src, lib = "/tmp/pv_convbig_stamps.hip", "/tmp/libpv_diag_convbig.so"
