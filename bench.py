@@ -383,6 +383,43 @@ def main():
     rccl_world = dist.get_world_size() if use_dist else 1
     finite = bool(torch.isfinite(final).all().item())
 
+    def replay(groups, reps=5):
+        """``groups``: one after the other; a group is a list of LANES, a lane a list of recorders run in order on one stream: lane 0 on the current
+        stream, the others on a side stream, concurrently - a step's schedule (the uncond and cond plans side by side, the merged low-resolution plan alone)
+        restricted to the launches in the recorders.  Returns ms per replay (HIP events on the launch stream)."""
+        stream = torch.cuda.current_stream()
+        sides = [torch.cuda.Stream(device=dev) for _ in range(max(len(g_) for g_ in groups) - 1)]
+
+        def once():
+            for grp in groups:
+                for lane, sd in zip(grp[1:], sides):
+                    sd.wait_stream(stream)
+                    with torch.cuda.stream(sd):
+                        for r_ in lane:
+                            r_.run()
+                for r_ in grp[0]:
+                    r_.run()
+                for _, sd in zip(grp[1:], sides):
+                    stream.wait_stream(sd)
+        once()
+        torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(reps):
+            once()
+        b_.record(stream)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b_) / reps
+
+    def step_schedule(subs_of):
+        """The replay groups of ``subs_of`` (engine -> recorder subset) in the step's own schedule."""
+        lane_u = [subs_of[e] for e in loop.engines_u if len(subs_of[e])]
+        lane_c = [subs_of[e] for e in loop.engines_c if len(subs_of[e])]
+        alone = [[[subs_of[e]]] for e in loop.engines_m if len(subs_of[e])]
+        if args.one_stream or not lane_u or not lane_c:
+            return [[[r_]] for r_ in lane_u + lane_c] + alone
+        return [[lane_u, lane_c]] + alone
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the launch symbol with the largest share of one step's algorithmic flops (round 4: big_tile_kernel<true, false>,
@@ -398,41 +435,9 @@ def main():
         subs = [e.rec.subset(lambda t: t[0] == dom) for e in engines]
         nl = sum(len(s) for s in subs)
         flops = sum(t[1] for s in subs for t in s.tags)
-        stream = torch.cuda.current_stream()
-        reps = 5
-        side = torch.cuda.Stream(device=dev)
-
-        def replay(groups):
-            """``groups``: lists of recorders; the recorders of one group run CONCURRENTLY (first on the current stream, the others on a side stream),
-            groups one after the other - the schedule of a step restricted to this kernel.  Returns ms per replay (HIP events on the launch stream)."""
-            def once():
-                for grp in groups:
-                    if len(grp) > 1:
-                        side.wait_stream(stream)
-                        with torch.cuda.stream(side):
-                            for r_ in grp[1:]:
-                                r_.run()
-                    grp[0].run()
-                    if len(grp) > 1:
-                        stream.wait_stream(side)
-            once()
-            torch.cuda.synchronize()
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for _ in range(reps):
-                once()
-            b_.record(stream)
-            torch.cuda.synchronize()
-            return a.elapsed_time(b_) / reps
-
         # as the step schedules it: the two per-branch plans side by side (their launches of this kernel may have 128 one-per-CU workgroups each: half the
         # chip, by design - pv_gemm_params.big_tile_min), the merged low-resolution plan alone
-        by_eng = dict(zip(engines, subs))
-        pair = [by_eng[e] for e in loop.engines_u + loop.engines_c if len(by_eng[e])]
-        alone = [by_eng[e] for e in loop.engines_m if len(by_eng[e])]
-        two = not args.one_stream and len(pair) > 1
-        groups = ([pair] if two else [[r_] for r_ in pair]) + [[r_] for r_ in alone]
-        ms = replay(groups)
+        ms = replay(step_schedule(dict(zip(engines, subs))))
         ach = flops / (ms * 1e-3) / 1e12
         # the same kernel one launch at a time (what a rocprofv3 per-dispatch duration of an un-overlapped launch shows), over its chip-filling launches only
         # (>= 256 workgroups: the 64 x 64 level)
@@ -441,7 +446,7 @@ def main():
         nb = sum(len(s_) for s_ in big_subs)
         if nb:
             fb = sum(t[1] for s_ in big_subs for t in s_.tags)
-            msb = replay([[r_] for r_ in big_subs if len(r_)])
+            msb = replay([[[r_]] for r_ in big_subs if len(r_)])
             single = {"what": "launches of this kernel with >= 256 workgroups (they fill the chip alone), replayed one at a time on one stream", "launches_per_step": nb,
                       "avg_launch_us": round(msb * 1e3 / nb, 2), "achieved": round(fb / (msb * 1e-3) / 1e12, 1), "frac": round(fb / (msb * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
         # HBM traffic of this kernel from the rocprofv3 PMC passes of the same command (tools/profile_bench.py; counters are
@@ -463,9 +468,7 @@ def main():
         if len(ranked) > 1:
             subs2 = [e.rec.subset(lambda t: t[0] == ranked[1]) for e in engines]
             nl2, fl2 = sum(len(s_) for s_ in subs2), sum(t[1] for s_ in subs2 for t in s_.tags)
-            by2 = dict(zip(engines, subs2))
-            pair2 = [by2[e] for e in loop.engines_u + loop.engines_c if len(by2[e])]
-            ms2 = replay(([pair2] if (two and len(pair2) > 1) else [[r_] for r_ in pair2]) + [[by2[e]] for e in loop.engines_m if len(by2[e])])
+            ms2 = replay(step_schedule(dict(zip(engines, subs2))))
             second = {"kernel": ranked[1], "launches_per_step": nl2, "avg_launch_us": round(ms2 * 1e3 / nl2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1),
                       "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                       "share_of_step_flops": round(fl2 / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
@@ -490,22 +493,10 @@ def main():
     # to_q + dual-branch SDPA + to_out kernel.  It exists for the C = 320 layers (pv_xfused.hip); the 640 / 1280-channel layers run four
     # launches (LayerNorm, to_q GEMM, dual-branch attention, to_out GEMM + residual).  Reported per level AND over all 16 attn2 layers,
     # time-weighted, against the 0.40 target.  Same measurement as the roofline object: the branch's launches of one step replayed
-    # back to back on one stream between HIP events.  (The text / image-token K, V projections depend on the conditioning only and run
+    # in the step's schedule (the uncond and cond plans side by side on two streams, the merged low-resolution plan alone) between HIP events.  (The text / image-token K, V projections depend on the conditioning only and run
     # once per generation, outside the step.)
     xfused = None
     if rank == 0 and not args.no_roofline:
-        def time_subs(subs, reps=5):
-            for s_ in subs:
-                s_.run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream())
-            for _ in range(reps):
-                for s_ in subs:
-                    s_.run()
-            e1.record(torch.cuda.current_stream())
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
         levels, tot_ms, tot_fl, tot_n = {}, 0.0, 0.0, 0
         for C_ in (320, 640, 1280):
             subs = [e.rec.subset_role(f"attn2:{C_}") for e in loop.all_engines]
@@ -514,7 +505,7 @@ def main():
                 continue
             flops = sum(t[1] for s_ in subs for t in s_.tags)
             kinds = sorted({t[0] for s_ in subs for t in s_.tags})
-            ms = time_subs(subs)
+            ms = replay(step_schedule(dict(zip(loop.all_engines, subs))))
             # layer instances: one SDPA launch per layer and forward; the merged low-resolution plan runs BOTH CFG forwards' layers in one launch
             layers = sum((e.B // B) for e, s_ in zip(loop.all_engines, subs) for t in s_.tags
                          if t[0].startswith("xattn_fused_kernel") or t[0] in ("pv_cross_attention", "xattn_lnq_kernel"))

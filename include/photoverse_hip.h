@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 12
+#define PV_ABI_VERSION 13
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -283,6 +283,9 @@ typedef struct pv_xattn_fused_params {
     int32_t batch, nq, heads, d, nt, nip;
     float w_text, w_ip;                        /* branch weights: (1,1) no_grad; (2,0) / (0,2) / (1,1) grad mode */
     const float* fusion;                       /* optional DEVICE pair overriding (w_text, w_ip): graph-safe grad-mode fusion */
+    int32_t rows_per_workgroup;                /* C = 640 only; 0 = the launch decides (64-row workgroups while 128-row ones would not fill the chip: */
+                                               /* < 384), 64 / 128 = the caller's choice: a caller that runs two such launches side by side on two */
+                                               /* streams (the uncond / cond forwards, infer.py:103-114) asks for 128.  Same results either way (ABI 13) */
 } pv_xattn_fused_params;
 int pv_cross_attention_fused(const pv_xattn_fused_params* p, void* stream);
 int pv_xattn_pack_kv(const void* kt, const void* vt, int32_t ldkt, int32_t ldvt, const void* kip, const void* vip,

@@ -67,7 +67,7 @@ class XAttnFusedParams(C.Structure):
     _fields_ = [("hs", c_void_p), ("ld_hs", c_int), ("ln", c_int), ("ln_eps", c_float),
                 ("wq", c_void_p), ("q_bias", c_void_p), ("wo", c_void_p), ("bias_o", c_void_p), ("kimg", c_void_p), ("vimg", c_void_p),
                 ("out", c_void_p), ("ld_out", c_int), ("batch", c_int), ("nq", c_int), ("heads", c_int), ("d", c_int),
-                ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p)]
+                ("nt", c_int), ("nip", c_int), ("w_text", c_float), ("w_ip", c_float), ("fusion", c_void_p), ("rows_per_workgroup", c_int)]
 
 
 class XAttnLnqParams(C.Structure):
@@ -164,7 +164,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

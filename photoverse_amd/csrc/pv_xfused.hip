@@ -747,10 +747,12 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
     p.kimg_bytes = (uint32_t)kb;
     p.vimg_bytes = (uint32_t)vb;
     // rows per workgroup: 128 (a wave owns two 16-row tiles: every weight fragment read from LDS feeds two MFMAs) or 64.  The C = 640 levels
-    // have 16 x 1024 rows = 128 workgroups of 128 - half of the 256 CUs; 64-row workgroups fill the chip (PV_XF_ROWS=64/128 overrides).
+    // have 16 x 1024 rows = 128 workgroups of 128 - half of the 256 CUs; 64-row workgroups fill the chip.  A caller with two such launches side by
+    // side (the CFG branches on two streams) asks for 128 rows through rows_per_workgroup: 58 vs 78 us per layer in that schedule (PV_XF_ROWS=64/128 overrides both).
     static const int rows_env = [] { const char* e = getenv("PV_XF_ROWS"); return e ? atoi(e) : 0; }();
     const size_t M = (size_t)p.batch * p.nq;
     int rows = C == 640 && M / 128 < 384 ? 64 : 128;
+    if (C == 640 && (p.rows_per_workgroup == 64 || p.rows_per_workgroup == 128)) rows = p.rows_per_workgroup;
     if (C == 640 && (rows_env == 64 || rows_env == 128)) rows = rows_env;
     static bool attr_set_dev[64][6] = {};
     int dev_id = 0;

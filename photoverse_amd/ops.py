@@ -555,7 +555,7 @@ class Recorder:
             wq = (w32 * ln_gamma.float()[None, :]).to(torch.float16).contiguous()
         p = XAttnFusedParams(_ptr(hs), _rows(hs)[0], int(ln_gamma is not None), float(ln_eps), _ptr(wq), _ptr(q_bias), _ptr(wo_packed), _ptr(bias_o),
                              _ptr(kimg), _ptr(vimg), _ptr(out), _rows(out)[0], batch, nq, heads, d, nt, nip, float(w_text), float(w_ip),
-                             _ptr(fusion))
+                             _ptr(fusion), 128 if (C == 640 and 0 < self.big_min <= 128) else 0)   # half-chip launches when the plan runs beside its CFG twin
         self.keep.extend(t for t in (hs, wq, q_bias, wo_packed, bias_o, kimg, vimg, fusion, out) if t is not None)
         M = batch * nq
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)

@@ -475,6 +475,15 @@ def test_cross_attention_fused_branch(rec_cls, d, n, p, wt, wi, ln, fus):
     out, _ = rec.cross_attention_fused(dhs, wq.cuda(), rec.pack_wo_for_fused(wo.cuda()), bo.cuda(), kimg, vimg, batch=B, nq=n, heads=H, d=d,
                                        nt=NT, nip=p, ln_gamma=gamma.cuda() if ln else None, ln_beta=beta.cuda() if ln else None,
                                        w_text=-7.0 if fus else wt, w_ip=-7.0 if fus else wi, fusion=fusion)
+    # C = 640: the 128-row-workgroup form a plan asks for when it runs beside its CFG twin (pv_xattn_fused_params.rows_per_workgroup)
+    out128 = None
+    if d == 80:
+        rec.big_min = 128
+        out128, p128 = rec.cross_attention_fused(dhs, wq.cuda(), rec.pack_wo_for_fused(wo.cuda()), bo.cuda(), kimg, vimg, batch=B, nq=n, heads=H, d=d,
+                                                 nt=NT, nip=p, ln_gamma=gamma.cuda() if ln else None, ln_beta=beta.cuda() if ln else None,
+                                                 w_text=-7.0 if fus else wt, w_ip=-7.0 if fus else wi, fusion=fusion)
+        assert p128.rows_per_workgroup == 128
+        rec.big_min = 256
     # the four-launch path
     n2 = rec.layernorm(dhs, gamma.cuda(), beta.cuda()) if ln else dhs
     q = rec.gemm(n2, wq.cuda(), rows_per_image=n)
@@ -482,6 +491,8 @@ def test_cross_attention_fused_branch(rec_cls, d, n, p, wt, wi, ln, fus):
     unf = rec.gemm(xa, wo.cuda(), bias=bo.cuda(), residual=dhs, rows_per_image=n)
     rec.run()
     torch.cuda.synchronize()
+    if out128 is not None:
+        assert torch.equal(out128, out)              # the row arithmetic does not depend on the workgroup's row count
     x = hs.float()
     xn = F.layer_norm(x, (C,), gamma, beta, 1e-5) if ln else x
     hv = lambda t, m: t.float().view(B, m, H, d).transpose(1, 2)
