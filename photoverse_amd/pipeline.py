@@ -68,7 +68,7 @@ class DenoiseLoop:
         if merge_lowres is None:
             merge_lowres = os.environ.get("PV_MERGE_LOWRES", "1") != "0"
         n_lv = len(cfg.block_out_channels)
-        split = 2
+        split = int(os.environ.get("PV_MERGE_SPLIT", "2"))     # resolution levels that stay in the per-branch plans (A/B switch; 3 = only 8 x 8 + mid merged)
         self.merge_lowres = bool(merge_lowres and not training_mode and batch_splits == 1 and n_lv > split
                                  and ((latent_size >> split) ** 2) % 64 == 0 and latent_size % (1 << (n_lv - 1)) == 0)
         if self.merge_lowres:
