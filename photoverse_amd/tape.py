@@ -215,6 +215,25 @@ class Tape:
         self.back.append(bwd)
         return out
 
+    def ln_linear(self, x: Var, gamma, beta, w16, wT16, *, eps=1e-5, bias=None, rows_per_image=None) -> Var:
+        """``Linear(LayerNorm(x))`` with a FROZEN Linear: one row-owning launch where pv_row_gemm takes the shape (K = 320: the 64 x 64-level blocks'
+        norm1 -> [to_q; to_k; to_v] and norm3 -> ff.net[0].proj), else LayerNorm + GEMM.  The normalised rows are never written: the backward needs
+        only x (layernorm_backward recomputes the statistics) and the unfolded weight."""
+        K, N = x.t.shape[1], w16.shape[0]
+        if not (Recorder.row_gemm_supported(K, N) and x.t.shape[0] >= 4096 and x.t.is_contiguous()):
+            return self.linear(self.layernorm(x, gamma, beta, eps=eps), w16, wT16, bias=bias, rows_per_image=rows_per_image)
+        y = self.rf.row_gemm(x.t, w16, bias=bias, ln_gamma=gamma, ln_beta=beta, ln_eps=eps)
+        out = Var(y, x.needs)
+
+        def bwd():
+            if out.g is None or not x.needs:
+                return
+            dn = self.rb.gemm(out.g, wT16, rows_per_image=rows_per_image)
+            dx, _ = self.rb.layernorm_backward(x.t, dn, gamma, beta, eps=eps, want_affine=False)
+            self._accum(x, dx)
+        self.back.append(bwd)
+        return out
+
     def self_attention(self, qkv: Var, *, batch, heads, n, d, causal=False) -> Var:
         C = heads * d
         lse = self.rf.empty((batch, heads, n), torch.float32)

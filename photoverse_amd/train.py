@@ -329,8 +329,8 @@ class TrainStep:
         hs = tp.linear(g, *tp.frozen(_conv1_w(m.proj_in.weight)), bias=_f32(m.proj_in.bias), rows_per_image=n)
         # attn1 ([EXT] AttnProcessor2_0, models/unet.py:20-24)
         a1 = blk.attn1
-        n1 = tp.layernorm(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), eps=blk.norm1.eps)
-        qkv = tp.linear(n1, *tp.frozen(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)), rows_per_image=n)
+        qkv = tp.ln_linear(hs, _f32(blk.norm1.weight), _f32(blk.norm1.bias), *tp.frozen(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)),
+                           eps=blk.norm1.eps, rows_per_image=n)
         sa = tp.self_attention(qkv, batch=B, heads=heads, n=n, d=d)
         hs = tp.linear(sa, *tp.frozen(a1.to_out[0].weight), bias=_f32(a1.to_out[0].bias), residual=hs, rows_per_image=n)
         # attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435), grad mode: fusion drawn on the device
@@ -371,8 +371,8 @@ class TrainStep:
                                 vnorm_coef=self.vnorm_weight * self.grad_scale / (self.n_xattn * B * heads * self.E))
         hs = tp.linear(xa, *tp.frozen(a2.to_out[0].weight), bias=_f32(a2.to_out[0].bias), residual=hs, rows_per_image=n)
         # GEGLU feed-forward (pre-activation kept for the backward)
-        n3 = tp.layernorm(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), eps=blk.norm3.eps)
-        hg = tp.linear(n3, *tp.frozen(blk.ff.net[0].proj.weight), bias=_f32(blk.ff.net[0].proj.bias), rows_per_image=n)
+        hg = tp.ln_linear(hs, _f32(blk.norm3.weight), _f32(blk.norm3.bias), *tp.frozen(blk.ff.net[0].proj.weight), eps=blk.norm3.eps,
+                          bias=_f32(blk.ff.net[0].proj.bias), rows_per_image=n)
         gg = tp.geglu(hg)
         hs = tp.linear(gg, *tp.frozen(blk.ff.net[2].weight), bias=_f32(blk.ff.net[2].bias), residual=hs, rows_per_image=n)
         return tp.linear(hs, *tp.frozen(_conv1_w(m.proj_out.weight)), bias=_f32(m.proj_out.bias), residual=x, rows_per_image=n, colstats=True)
