@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 13
+#define PV_ABI_VERSION 14
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -383,6 +383,8 @@ typedef struct pv_layernorm_bwd_params {
     int32_t dy_group, dy_skip;         /* dy_group > 1: row r reads dy row r / dy_group; the first dy_skip rows of a group get 0 */
     float dy_scale;                    /* multiplies dy (1 / count of a mean; 1.0 otherwise) */
     int32_t rows_per_wave;             /* rows each wave walks (0 = 1): dgb_partial has ceil(rows / (4 * rows_per_wave)) blocks */
+    const void* add; int32_t ldadd;    /* optional fp16 [rows][cols]: dx = LayerNorm gradient + add (the gradient x already holds from its other */
+                                       /* consumers - the residual stream: one launch instead of the gradient + an add pass) (ABI 14) */
 } pv_layernorm_bwd_params;
 int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream);
 /* out[i] = scale * sum_b x[b][i], b in order (deterministic) */

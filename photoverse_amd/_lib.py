@@ -93,7 +93,7 @@ class XAttnBwdParams(C.Structure):
 class LayerNormBwdParams(C.Structure):
     _fields_ = [("x", c_void_p), ("ldx", c_int), ("dy", c_void_p), ("lddy", c_int), ("dx", c_void_p), ("lddx", c_int),
                 ("gamma", c_void_p), ("beta", c_void_p), ("dgb_partial", c_void_p), ("rows", c_int), ("cols", c_int), ("eps", c_float),
-                ("act", c_int), ("dy_group", c_int), ("dy_skip", c_int), ("dy_scale", c_float), ("rows_per_wave", c_int)]
+                ("act", c_int), ("dy_group", c_int), ("dy_skip", c_int), ("dy_scale", c_float), ("rows_per_wave", c_int), ("add", c_void_p), ("ldadd", c_int)]
 
 
 #: every symbol ``include/photoverse_hip.h`` declares: name -> (restype, argtypes)
@@ -164,7 +164,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 

@@ -69,12 +69,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pv_layernorm_b
         s1 = pv_wave_sum(s1) / (float)p.cols;
         s2 = pv_wave_sum(s2) / (float)p.cols;
         half_t* dx = reinterpret_cast<half_t*>(p.dx) + (size_t)row * p.lddx;
+        const half_t* ad = p.add ? reinterpret_cast<const half_t*>(p.add) + (size_t)row * p.ldadd : nullptr;
         for (int c = lane; c < p.cols; c += 64) {
             const float xh = ((float)x[c] - mean) * rstd;
             const float z = p.gamma[c] * xh + p.beta[c];
             float g = (float)dy[c] * dys;
             if (p.act == PV_ACT_LEAKY_RELU && z < 0.f) g *= 0.01f;
-            dx[c] = (half_t)(rstd * (g * p.gamma[c] - s1 - xh * s2));
+            dx[c] = (half_t)(rstd * (g * p.gamma[c] - s1 - xh * s2) + (ad ? (float)ad[c] : 0.f));
         }
     }
     __syncthreads();
@@ -158,13 +159,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const pv_layerno
     s2 = sub_sum<LPR>(s2) / (float)p.cols;
     if (!live) return;
     half_t* dx = reinterpret_cast<half_t*>(p.dx) + (size_t)row * p.lddx;
+    const half_t* ad = p.add ? reinterpret_cast<const half_t*>(p.add) + (size_t)row * p.ldadd : nullptr;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = sub + i * LPR;
         if (ch < nchunk) {
-            half8_t o;
+            half8_t o, a = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ad) a = *reinterpret_cast<const half8_t*>(ad + ch * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)(rstd * (gv[i][j] - s1 - xv[i][j] * s2));
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(rstd * (gv[i][j] - s1 - xv[i][j] * s2) + (float)a[j]);
             *reinterpret_cast<half8_t*>(dx + ch * 8) = o;
         }
     }

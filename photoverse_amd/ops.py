@@ -644,17 +644,18 @@ class Recorder:
             self._add(self.lib.pv_reduce_blocks, _ptr(part), nsplit, n * k, sc, _ptr(out))
         return out
 
-    def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0):
+    def layernorm_backward(self, x, dy, gamma, beta, *, eps=1e-5, act=ACT_NONE, want_affine=True, dy_group=1, dy_skip=0, dy_scale=1.0, add=None):
         """dx fp16 [rows, cols] and (dgamma, dbeta) fp32 [2, cols].  ``dy_group`` > 1: dy has rows / dy_group rows, row r uses
-        dy[r // dy_group] * dy_scale, except the first ``dy_skip`` rows of each group (zero)."""
+        dy[r // dy_group] * dy_scale, except the first ``dy_skip`` rows of each group (zero).  ``add``: fp16 [rows, cols] added to dx (the
+        gradient x already holds from its other consumers)."""
         rows, cols = x.shape
         dx = self.empty((rows, cols), torch.float16)
         rpw = 2 if (want_affine and rows >= 2048) else 1   # rows per wave: halves the dgamma / dbeta partial blocks; 8 left 129 workgroups for 4112 rows (130 us)
         nblk = (rows + 4 * rpw - 1) // (4 * rpw)
         part = self.empty((nblk, 2, cols), torch.float32) if want_affine else None
         p = LayerNormBwdParams(_ptr(x), _rows(x)[0], _ptr(dy), _rows(dy)[0], _ptr(dx), cols, _ptr(gamma), _ptr(beta), _ptr(part), rows, cols,
-                               float(eps), act, int(dy_group), int(dy_skip), float(dy_scale), rpw)
-        self.keep.extend((x, dy, gamma, beta))
+                               float(eps), act, int(dy_group), int(dy_skip), float(dy_scale), rpw, _ptr(add), _rows(add)[0] if add is not None else 0)
+        self.keep.extend(t for t in (x, dy, gamma, beta, add) if t is not None)
         self._add(self.lib.pv_layernorm_backward, p)
         dgb = None
         if want_affine:

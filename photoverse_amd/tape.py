@@ -208,10 +208,15 @@ class Tape:
             if out.g is None:
                 return
             kw = dict(dy_group=mean_group, dy_skip=1, dy_scale=1.0 / (mean_group - 1)) if mean_group > 1 else {}
-            dx, dgb = self.rb.layernorm_backward(x.t, out.g, gamma, beta, eps=eps, act=act, want_affine=on_affine is not None, **kw)
+            fuse = x.needs and x.g is not None and x.g.shape == x.t.shape      # the accumulation rides in the same launch
+            dx, dgb = self.rb.layernorm_backward(x.t, out.g, gamma, beta, eps=eps, act=act, want_affine=on_affine is not None,
+                                                 add=x.g if fuse else None, **kw)
             if on_affine is not None:
                 on_affine(dgb)
-            self._accum(x, dx)
+            if fuse:
+                x.g = dx
+            else:
+                self._accum(x, dx)
         self.back.append(bwd)
         return out
 
@@ -229,8 +234,8 @@ class Tape:
             if out.g is None or not x.needs:
                 return
             dn = self.rb.gemm(out.g, wT16, rows_per_image=rows_per_image)
-            dx, _ = self.rb.layernorm_backward(x.t, dn, gamma, beta, eps=eps, want_affine=False)
-            self._accum(x, dx)
+            dx, _ = self.rb.layernorm_backward(x.t, dn, gamma, beta, eps=eps, want_affine=False, add=x.g)
+            x.g = dx
         self.back.append(bwd)
         return out
 

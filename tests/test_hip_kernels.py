@@ -947,6 +947,9 @@ def test_layernorm_backward_kernels(rows, cols, affine, act):
     beta = (0.1 * torch.randn(cols, generator=g)).to(dev)
     rec = Recorder(dev)
     dx, dgb = rec.layernorm_backward(x, dy, gamma, beta, eps=1e-5, act=ACT_LEAKY_RELU if act == "leaky" else ACT_NONE, want_affine=affine)
+    # `add` (ABI 14): the gradient x already holds rides in the same launch; here a column-sliced view (ldadd > cols)
+    wide = torch.randn(rows, cols + 8, generator=g).half().to(dev)
+    dx_add, _ = rec.layernorm_backward(x, dy, gamma, beta, eps=1e-5, act=ACT_LEAKY_RELU if act == "leaky" else ACT_NONE, want_affine=affine, add=wide[:, :cols])
     rec.run()
     torch.cuda.synchronize()
     xr = x.float().requires_grad_(True)
@@ -956,6 +959,7 @@ def test_layernorm_backward_kernels(rows, cols, affine, act):
         y = torch.nn.functional.leaky_relu(y, 0.01)
     y.backward(dy.float())
     assert rel_l2(dx.float(), xr.grad) < 1.5e-3
+    assert rel_l2(dx_add.float(), xr.grad + wide[:, :cols].float()) < 1.5e-3
     if affine:
         assert rel_l2(dgb[0], gr.grad) < 1e-4 and rel_l2(dgb[1], br.grad) < 1e-4
     else:
