@@ -95,6 +95,7 @@ class Recorder:
         #: minimum number of 256-row tiles for pv_convbig.hip's tile (pv_gemm_params.big_tile_min): 256 = one workgroup per CU; a plan that runs beside
         #: another one on a second stream (the two CFG forwards) uses 128; env PV_CONV_BIG overrides (0 = never)
         self.big_min = int(os.environ["PV_CONV_BIG"]) if "PV_CONV_BIG" in os.environ else 256
+        self.big_split2 = False          # set by the plan that runs alone on the chip at batch 2B (UNetEngine(segment="mid"))
 
     # ------------------------------------------------------------------ memory
     def empty(self, shape, dtype=torch.float16) -> torch.Tensor:
@@ -118,6 +119,7 @@ class Recorder:
         """A recorder sharing this one's buffers that replays only the calls whose tag satisfies ``pred``."""
         r = Recorder.__new__(Recorder)
         r.lib, r.device, r.keep, r.bytes_allocated, r.colstats, r.big_min = self.lib, self.device, self.keep, 0, self.colstats, self.big_min
+        r.big_split2 = self.big_split2
         sel = [i for i, t in enumerate(self.tags) if pred(t)]
         r.calls = [self.calls[i] for i in sel]
         r.tags = [self.tags[i] for i in sel]
@@ -201,6 +203,10 @@ class Recorder:
         if (big_shape and auto_splitk and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
                 and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
             splitk = BIG_SPLITK
+        elif (big_shape and auto_splitk and self.big_split2 and 2 <= SPLITK_MAX and tiles256 < big_min <= tiles256 * 2 and (kdim // 64) // 2 >= 16):
+            # the merged low-resolution plan's 16 x 16 convs (batch 2B: 128 tiles): two K-slices on the one-per-CU tile instead of 512 unsplit
+            # 128-row workgroups: +0.35 % of a step same-box; the same rule on plans that do not run alone (training, --one-stream) loses 0.4 %
+            splitk = 2
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)

@@ -224,6 +224,8 @@ class UNetEngine:
             for r in (rec, self.rec_tail):
                 if r is not None:
                     r.big_min = big_min
+        if segment == "mid" and "PV_CONV_BIG" not in os.environ:
+            rec.big_split2 = True                           # the merged plan runs alone at batch 2B: its 16 x 16 convs take two K-slices on the one-per-CU tile
         dev = rec.device
         xdim = cfg.cross_attention_dim
         self.x_in = latents_in if latents_in is not None else rec.empty((batch, cfg.in_channels, h, w), torch.float32)
