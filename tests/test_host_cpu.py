@@ -38,6 +38,42 @@ def test_cabi_exports_every_declared_symbol(lib):
     assert lib.pv_device_count() in (-1, 0) or torch.cuda.is_available()
 
 
+def test_cabi_rejects_bad_parameter_blocks_before_touching_the_device(lib):
+    """Error behaviour of the C-ABI (no GPU needed: every entry point validates its parameter block before its first HIP call and returns
+    hipErrorInvalidValue = 1): empty blocks, and the shape limits the header documents for the attn2 entry points and pv_row_gemm."""
+    import ctypes as C
+    from photoverse_amd import _lib
+    INVALID = 1
+    for name, cls in (("pv_gemm_conv", _lib.GemmParams), ("pv_attention", _lib.AttnParams), ("pv_cross_attention", _lib.XAttnParams),
+                      ("pv_cross_attention_fused", _lib.XAttnFusedParams), ("pv_cross_attention_lnq", _lib.XAttnLnqParams), ("pv_row_gemm", _lib.RowGemmParams),
+                      ("pv_groupnorm_apply", _lib.GroupNormParams), ("pv_layernorm", _lib.LayerNormParams), ("pv_layernorm_backward", _lib.LayerNormBwdParams),
+                      ("pv_attention_backward", _lib.AttnBwdParams), ("pv_cross_attention_backward", _lib.XAttnBwdParams),
+                      ("pv_groupnorm_backward", _lib.GroupNormBwdParams)):
+        assert getattr(lib, name)(C.byref(cls()), None) == INVALID, name
+    FAKE = 0x1000                                    # never dereferenced: the shape checks come first
+
+    def call(fn, cls, ptrs, base, **kw):
+        p = cls()
+        for k in ptrs:
+            setattr(p, k, FAKE)
+        for k, v in {**base, **kw}.items():
+            setattr(p, k, v)
+        return fn(C.byref(p), None)
+
+    lnq = lambda **kw: call(lib.pv_cross_attention_lnq, _lib.XAttnLnqParams, ("hs", "wq", "q_bias", "wq_rowsum", "kt", "vt", "kip", "vip", "out"),
+                            dict(ld_hs=1280, ln=1, ln_eps=1e-5, ldkt=2560, ldvt=2560, ldkip=2560, ldvip=2560, ldo=1280, batch=2, nq=256, heads=8, d=160, nt=77, nip=1,
+                                 w_text=1.0, w_ip=1.0), **kw)
+    for bad in (dict(d=40), dict(nt=81), dict(nip=17), dict(ld_hs=1283), dict(wq_rowsum=0), dict(batch=0)):      # d in {160, 80}; nt <= 80; nip <= 16; 16-byte rows; ln needs the row sums
+        assert lnq(**bad) == INVALID, bad
+    fused = lambda **kw: call(lib.pv_cross_attention_fused, _lib.XAttnFusedParams, ("hs", "wq", "wo", "kimg", "vimg", "out"),
+                              dict(ld_hs=320, ld_out=320, batch=2, nq=256, heads=8, d=40, nt=77, nip=1, w_text=1.0, w_ip=1.0), **kw)
+    for bad in (dict(d=48), dict(nq=200), dict(heads=4), dict(nip=0), dict(nt=60), dict(nip=17)):                # C in {320, 640}; nq % 128; 8 heads; 64 < nt <= 80; 1 <= nip <= 16
+        assert fused(**bad) == INVALID, bad
+    rowg = lambda **kw: call(lib.pv_row_gemm, _lib.RowGemmParams, ("x", "w", "out"), dict(ld_x=320, M=4096, K=320, N=960, ln=1, ln_eps=1e-5, geglu=0, ld_out=960), **kw)
+    for bad in (dict(K=640, ld_x=640), dict(N=1000, ld_out=1000), dict(ld_out=320), dict(M=0)):                   # K == 320; N % 320 == 0; ld_out >= N
+        assert rowg(**bad) == INVALID, bad
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors of the parameter structs: field names and order equal the header's."""
     from photoverse_amd import _lib
