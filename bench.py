@@ -345,7 +345,8 @@ def main():
     unet = build_random_unet(args.ip_tokens, dev)          # identical random-init weights on every rank
 
     B, S, P, T = args.batch, args.latent, args.ip_tokens, max(args.steps, args.warmup, 1)   # the schedule covers the warm-up too
-    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream, batch_splits=args.batch_splits)
+    loop = DenoiseLoop(unet, B, S, P, T, args.guidance, use_graph=not args.no_graph, two_streams=not args.one_stream, batch_splits=args.batch_splits,
+                       share_prefix=False)       # the headline: two FULL forwards per step
     g = torch.Generator().manual_seed(1234)    # global batch drawn once on CPU (infer.py:52-59), sliced per rank
     GB = B * world
     noise = torch.randn(GB, 4, S, S, generator=g)
@@ -526,6 +527,35 @@ def main():
                       "flops_counted": "algorithmic: 4 M C^2 (to_q + to_out) + 4 M (77 + P) C (both SDPA products), M = B * H * W of the level",
                       "phase_roofline": "profiles/r04_xfused_phase_roofline.md", "pmc": "profiles/r03_pmc_xfused.txt (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_BUSY_CYCLES of the fused kernel)"}
 
+    # OPTIONAL, separately labelled (round-3 verdict item 9): the two CFG forwards of a step share the part that never sees the conditioning (conv_in ->
+    # first ResnetBlock -> first transformer block up to attn1): exact (bit-identical latents), 2.5 % fewer flops.  `value` above stays two FULL forwards.
+    shared = None
+    if rank == 0 and world == 1 and not args.no_roofline and not args.one_stream and args.batch_splits == 1:
+        k2 = min(args.steps, 20)
+        loop2 = DenoiseLoop(unet, B, S, P, max(k2, 3), args.guidance, use_graph=not args.no_graph, share_prefix=True)
+        if loop2.share_prefix:
+            loop2.set_conditioning((text_c[sl].to(dev), ip_c[sl].to(dev)), (text_u[sl].to(dev), ip_u[sl].to(dev)))
+            loop2.reset(noise[sl])
+            for _ in range(3):
+                loop2.step()
+            torch.cuda.synchronize()
+            loop2.reset(noise[sl])
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                loop2.step()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t2) / k2
+            fl_full = sum(t[1] for e in loop.all_engines for t in e.rec.tags)
+            fl2 = sum(t[1] for e in loop2.all_engines for t in e.rec.tags)
+            shared = {"what": "NOT the headline: the same loop with the conditioning-independent prefix of the two CFG forwards (conv_in, first ResnetBlock, first transformer "
+                              "block up to attn1) computed once per step instead of twice (DenoiseLoop(share_prefix=True)); latents bit-identical "
+                              "(tests/test_unet_gpu.py::test_shared_prefix_of_the_two_cfg_forwards_is_exact)",
+                      "value": round(1.0 / dt2, 3), "unit": "denoising steps/s (bs=%d)" % B, "ms_per_step": round(dt2 * 1e3, 3), "steps": k2,
+                      "flops_vs_two_full_forwards": round(fl2 / fl_full, 4), "launches_per_step": loop2.launches_per_step,
+                      "step_mfma_frac_of_reduced_flops": round(fl2 / 1e12 / dt2 / MFMA_PEAK_TFLOPS, 4)}
+        loop2 = None
+        torch.cuda.empty_cache()
+
     # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
     # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.
     # Inference-style engine (fused GEGLU / fused attn2, no activations kept); the whole iteration is `train_step` below.  NOT part of `value`.
@@ -601,7 +631,7 @@ def main():
             "finite": finite, "rccl_world": rccl_world, "collective": ("all_gather_into_tensor over RCCL (final latents)" if use_dist else "none (single process)"),
             "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "n": len(rank_ms)},
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "xattn_fused": xfused, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "shared_prefix": shared, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:

@@ -23,7 +23,7 @@ class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
                  two_streams: bool = True, batch_splits: int = 1, training_mode: bool = False, fusion_seed: int = 0,
-                 merge_lowres: Optional[bool] = None):
+                 merge_lowres: Optional[bool] = None, share_prefix: Optional[bool] = None):
         """``training_mode``: the reference enables grad on the LAST denoising step only (infer.py:99), where every cross-attention
         layer of both forwards then draws its branch fusion (attention_processor.py:413-420).  Here the draw runs on the device inside
         the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps.  This is the forward semantics
@@ -32,7 +32,12 @@ class DenoiseLoop:
         ``merge_lowres`` (default: env ``PV_MERGE_LOWRES``, on): the two CFG forwards (infer.py:103-114) run their two highest-resolution levels
         as two parallel graph branches, but everything below (16 x 16 and 8 x 8 levels, mid block) as ONE plan over both branches' samples:
         at M = B * 256 / B * 64 rows a single branch cannot fill the chip without split-K (fp32 slabs + a reduce launch per conv) and both
-        branches stream the same 29.5 MB of weights per conv.  Samples never interact inside the UNet, so the result per sample is unchanged."""
+        branches stream the same 29.5 MB of weights per conv.  Samples never interact inside the UNet, so the result per sample is unchanged.
+
+        ``share_prefix`` (default: env ``PV_SHARE_PREFIX``, off - the headline metric counts two FULL forwards per step): conv_in, the first ResnetBlock and the first
+        transformer block up to its self-attention never see the conditioning, so the uncond and cond forwards of a step compute them twice on
+        identical inputs.  With ``share_prefix`` they are one plan whose outputs both branches start from - bit-identical latents, 2.5 % fewer
+        flops per step.  Reported by ``bench.py`` as a separately labelled number."""
         dev = unet.device
         if dev.type != "cuda":
             raise RuntimeError("DenoiseLoop needs the UNet on a HIP device (no CPU path)")
@@ -64,7 +69,15 @@ class DenoiseLoop:
         sb = batch // batch_splits
         self.eps_u = torch.empty_like(self.latents)
         self.eps_c = torch.empty_like(self.latents)
-        self.engines_u, self.engines_c, self.engines_m = [], [], []
+        self.engines_u, self.engines_c, self.engines_m, self.engines_p = [], [], [], []
+        if share_prefix is None:
+            share_prefix = os.environ.get("PV_SHARE_PREFIX", "0") == "1"
+        self.share_prefix = bool(share_prefix and not training_mode and batch_splits == 1)
+        pre_kw = {}
+        if self.share_prefix:
+            self.engines_p.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, segment="prefix", timesteps=self.timesteps,
+                                              state=self.state, n_text=n_text))
+            pre_kw = dict(prefix=self.engines_p[0].prefix_out)
         if merge_lowres is None:
             merge_lowres = os.environ.get("PV_MERGE_LOWRES", "1") != "0"
         n_lv = len(cfg.block_out_channels)
@@ -90,12 +103,12 @@ class DenoiseLoop:
                 half_in = (mid_in[i * batch * n_in:(i + 1) * batch * n_in], mid_in_cs[i * batch * n_in // 64:(i + 1) * batch * n_in // 64])
                 half_out = (mid_out[i * batch * n_out:(i + 1) * batch * n_out], mid_out_cs[i * batch * n_out // 64:(i + 1) * batch * n_out // 64])
                 lst.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, text=text, ip=ip, out=eps, segment="outer",
-                                       mid_in=half_in, mid_out=half_out, **kw, **side_by_side))
+                                       mid_in=half_in, mid_out=half_out, **kw, **side_by_side, **pre_kw))
             self.engines_m.append(unet.engine(2 * batch, latent_size, latent_size, n_ip, 1, text=text_all, ip=ip_all, segment="mid",
                                               mid_in=(mid_in, mid_in_cs), mid_out=(mid_out, mid_out_cs), **kw))
         for i in range(0 if self.merge_lowres else batch_splits):
             sl = slice(i * sb, (i + 1) * sb)
-            kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text)
+            kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text, **pre_kw)
             if two_streams and batch_splits == 1:
                 kw.update(big_min=128)                    # the two whole forwards run side by side
             if training_mode:
@@ -120,7 +133,7 @@ class DenoiseLoop:
     @property
     def all_engines(self):
         """Every plan of a step (uncond / cond branches and, with ``merge_lowres``, the merged low-resolution part)."""
-        return self.engines_u + self.engines_c + self.engines_m
+        return self.engines_u + self.engines_c + self.engines_m + self.engines_p
 
     # ------------------------------------------------------------------
     def set_conditioning(self, cond: Tuple[torch.Tensor, torch.Tensor], uncond: Tuple[torch.Tensor, torch.Tensor]):
@@ -141,6 +154,8 @@ class DenoiseLoop:
         self._host_step = 0
 
     def _step_eager(self):
+        for e in self.engines_p:                       # the conditioning-independent prefix both branches start from (share_prefix)
+            e.rec.run()
         if self.merge_lowres:
             # head_u || head_c -> merged low-resolution part (both branches' samples as one batch) -> tail_u || tail_c -> CFG + solver step
             (eu,), (ec,), (em,) = self.engines_u, self.engines_c, self.engines_m

@@ -194,7 +194,8 @@ class UNetEngine:
                  timesteps: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, n_text: int = 77,
                  latents_in: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None,
                  ip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, device_fusion: Optional[str] = None,
-                 fusion_seed: int = 0, segment: Optional[str] = None, split: int = 2, mid_in=None, mid_out=None, big_min: Optional[int] = None):
+                 fusion_seed: int = 0, segment: Optional[str] = None, split: int = 2, mid_in=None, mid_out=None, big_min: Optional[int] = None,
+                 prefix=None):
         """``device_fusion``: None - branch weights (w_text, w_ip) are launch parameters patched by the host (``_set_fusion``);
         ``"always"`` - every forward draws them on the device (grad-mode semantics of attention_processor.py:413-420, graph-safe);
         ``"last_step"`` - drawn only when the loop state says this is the last denoising step (``run_inference(training_mode=True)``,
@@ -204,12 +205,21 @@ class UNetEngine:
         resolution levels of the down path into ``rec_head`` (its last launch, the level's downsampling conv, writes into ``mid_in`` = (tensor,
         column statistics): this branch's half of a buffer shared with the other CFG branch) and the matching last ``split`` up blocks + conv_out
         into ``rec_tail`` (starting from ``mid_out`` = this branch's half of the merged part's output); ``"mid"`` records everything in
-        between at batch = BOTH branches (``mid_in`` / ``mid_out`` = the whole shared buffers)."""
+        between at batch = BOTH branches (``mid_in`` / ``mid_out`` = the whole shared buffers).
+
+        ``"prefix"`` / ``prefix=`` (optional, DenoiseLoop(share_prefix=True)): the part of a forward that does not see the conditioning - conv_in, the
+        first ResnetBlock and the first transformer block up to its self-attention - is the same computation in the uncond and cond forwards of a
+        CFG step (same latents, same timestep).  ``segment="prefix"`` records it once (``self.prefix_out``: conv_in's output, the ResnetBlock's
+        output, the hidden states behind attn1, with the column statistics their GroupNorm consumers need); a plan given ``prefix=`` that
+        dictionary starts from those tensors instead of recomputing them.  Exact: the same kernels on the same inputs."""
         self.unet, self.B, self.H, self.W, self.P, self.NT = unet, batch, h, w, n_ip, n_text
-        if segment not in (None, "outer", "mid"):
-            raise ValueError("segment must be None, 'outer' or 'mid'")
-        if segment is not None and (mid_in is None or mid_out is None or device_fusion is not None):
+        if segment not in (None, "outer", "mid", "prefix"):
+            raise ValueError("segment must be None, 'outer', 'mid' or 'prefix'")
+        if segment in ("outer", "mid") and (mid_in is None or mid_out is None or device_fusion is not None):
             raise ValueError("a plan segment needs the shared mid_in / mid_out buffers (and host-side fusion weights)")
+        if (segment == "prefix" or prefix is not None) and (device_fusion is not None or segment == "mid"):
+            raise ValueError("the shared prefix exists for the inference plans of the two CFG branches")
+        self.prefix_in, self.prefix_out = prefix, None
         self.segment, self.split, self.mid_in, self.mid_out = segment, split, mid_in, mid_out
         cfg = unet.config
         rec = self.rec = Recorder(device)
@@ -272,13 +282,17 @@ class UNetEngine:
         # every block output feeds a GroupNorm (next norm1 / Transformer2D.norm / conv_norm_out, directly or as a skip)
         return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo, colstats=True)
 
-    def _transformer(self, name: str, m: Transformer2DModel, x, b, h, w):
+    def _transformer(self, name: str, m: Transformer2DModel, x, b, h, w, stop_after_attn1: bool = False, resume_hs=None):
+        """``stop_after_attn1``: record norm -> proj_in -> attn1 only and return the hidden states (the conditioning-independent half of the block);
+        ``resume_hs``: those hidden states, computed by another plan - record the rest (attn2, feed-forward, proj_out + residual x)."""
         rec = self.rec
         n = h * w
         blk = m.transformer_blocks[0]
         C = m.proj_in.out_channels
         heads = blk.attn1.heads
         d = C // heads
+        if resume_hs is not None:
+            return self._transformer_tail(name, m, x, resume_hs, b, h, w)
         g = rec.groupnorm(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=b, hw=n, eps=m.norm.eps, act=ACT_NONE)
         hs = rec.gemm(g, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), rows_per_image=n)
         # --- attn1 (stock AttnProcessor2_0, models/unet.py:20-24) ---
@@ -296,6 +310,17 @@ class UNetEngine:
             qkv = rec.gemm(n1, wqkv, rows_per_image=n)
         sa = rec.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch=b, heads=heads, nq=n, nk=n, d=d)
         hs = rec.gemm(sa, _f16(a1.to_out[0].weight), bias=_f32(a1.to_out[0].bias), residual=hs, rows_per_image=n)
+        if stop_after_attn1:
+            return hs
+        return self._transformer_tail(name, m, x, hs, b, h, w)
+
+    def _transformer_tail(self, name: str, m: Transformer2DModel, x, hs, b, h, w):
+        rec = self.rec
+        n = h * w
+        blk = m.transformer_blocks[0]
+        C = m.proj_in.out_channels
+        heads = blk.attn1.heads
+        d = C // heads
         # --- attn2 (PhotoVerseAttnProcessor2_0, attention_processor.py:245-435) ---
         a2 = blk.attn2
         proc = a2.processor
@@ -384,7 +409,15 @@ class UNetEngine:
             self.rec.colstats[(t.data_ptr(), rows, t.shape[1])] = cs
             return t
 
-        if seg != "mid":
+        pre = self.prefix_in
+        first = u.down_blocks[0]
+        if (seg == "prefix" or pre is not None) and not (first.has_attn and len(first.resnets) >= 1):
+            raise ValueError("the shared prefix needs an attention down block first (conv_in -> ResnetBlock -> transformer block)")
+        if pre is not None:
+            # conv_in, the first ResnetBlock and the first transformer block up to attn1 were recorded by the prefix plan
+            x = adopt(pre["conv_in"], B * h * w)
+            skips = [(x, h, w)]
+        elif seg != "mid":
             # conv_in (cin = 4): im2col to K = 36 -> 64 (zero padded), then the MFMA GEMM
             kin = cfg.in_channels * 9
             kpad = (kin + 63) // 64 * 64
@@ -393,6 +426,14 @@ class UNetEngine:
             w_in[:, :kin] = u.conv_in.weight.detach().reshape(c0, kin).to(torch.float16)
             x = rec.gemm(cols, w_in, bias=_f32(u.conv_in.bias), rows_per_image=h * w, colstats=True)
             skips = [(x, h, w)]
+            if seg == "prefix":
+                key = lambda t: (t.data_ptr(), t.shape[0], t.shape[1])
+                res0 = first.resnets[0]
+                xr = self._resnet(res0, x, None, B, h, w, temb_all, toffs[id(res0)])
+                hs = self._transformer("down_blocks.0.attentions.0", first.attentions[0], xr, B, h, w, stop_after_attn1=True)
+                self.prefix_out = {"conv_in": (x, rec.colstats[key(x)]), "res": (xr, rec.colstats[key(xr)]), "hs": hs}
+                self.out = hs
+                return
         else:
             h, w = h >> split, w >> split
             x = adopt(self.mid_in, B * h * w)
@@ -401,6 +442,11 @@ class UNetEngine:
             if (seg == "outer" and bi >= split) or (seg == "mid" and bi < split):
                 continue
             for i, res in enumerate(blk.resnets):
+                if pre is not None and bi == 0 and i == 0:
+                    x = adopt(pre["res"], B * h * w)
+                    x = self._transformer("down_blocks.0.attentions.0", blk.attentions[0], x, B, h, w, resume_hs=pre["hs"])
+                    skips.append((x, h, w))
+                    continue
                 x = self._resnet(res, x, None, B, h, w, temb_all, toffs[id(res)])
                 if blk.has_attn:
                     x = self._transformer(f"down_blocks.{bi}.attentions.{i}", blk.attentions[i], x, B, h, w)

@@ -313,6 +313,10 @@ def test_bench_contract_line():
     # C = 1280: norm2 + to_q + both SDPAs head-parallel in one launch, to_out + residual as a GEMM (round 3: four launches)
     assert not xa["levels"]["1280"]["fused"] and xa["levels"]["1280"]["head_parallel"] and xa["levels"]["1280"]["launches_per_layer"] == 2
     assert xa["all_layers"]["layers_per_step"] == 32 and 0.02 < xa["all_layers"]["frac"] < 1.0 and xa["north_star_target_frac"] == 0.40
+    # the optional shared-prefix loop: a separately labelled number, never the headline
+    sp = d["shared_prefix"]
+    assert sp["what"].startswith("NOT the headline") and 0.97 < sp["flops_vs_two_full_forwards"] < 0.98 and sp["launches_per_step"] < d["config"]["launches_per_step"]
+    assert sp["value"] > 0.9 * d["value"]
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
                          "--no-train-forward"], capture_output=True, text=True, timeout=600, cwd=root)
     assert r2.returncode == 0, r2.stderr[-2000:]
@@ -390,6 +394,36 @@ def test_bs16_full_size_samples_match_bs1_runs(monkeypatch, full_hip_unet):
     worst = max(rel_l2(full2[i:i + 1], s1) for i, s1 in singles2.items())
     print(f"bs=16 sample vs its bs=1 run (default split-K), 2 CFG steps, full size: worst rel-L2 = {worst:.3e}")
     assert worst < 4e-3
+
+
+@pytest.mark.parametrize("merge", [True, False])
+def test_shared_prefix_of_the_two_cfg_forwards_is_exact(full_hip_unet, merge):
+    """``DenoiseLoop(share_prefix=True)`` (verdict item 9, opt-in: the headline counts two full forwards): conv_in, the first ResnetBlock and the first
+    transformer block up to attn1 see neither text nor image tokens, so the uncond and cond forwards of a step compute them on identical inputs; recorded
+    once, both branches start from the same tensors.  Same kernels, same inputs: the latents are BIT-identical, with fewer launches per step."""
+    from photoverse_amd.pipeline import DenoiseLoop
+    hip = full_hip_unet
+    B, S, P, T = 2, 64, 1, 3
+    g = torch.Generator().manual_seed(91)
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, S, S, generator=g)
+
+    def run(share):
+        loop = DenoiseLoop(hip, B, S, P, T, 7.5, merge_lowres=merge, share_prefix=share)
+        assert loop.share_prefix == share and len(loop.engines_p) == (1 if share else 0)
+        loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        loop.reset(noise)
+        out = loop.run().clone().cpu()
+        n, fl = loop.launches_per_step, sum(t[1] for e in loop.all_engines for t in e.rec.tags)
+        del loop
+        return out, n, fl
+
+    a, na, fa = run(True)
+    b, nb, fb = run(False)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert na < nb and 0.97 * fb < fa < 0.98 * fb        # 2.5 % of a step's algorithmic flops are computed once instead of twice
+    print(f"shared CFG prefix: launches per step {na} vs {nb}, algorithmic flops {fa / fb:.4f} of two full forwards")
 
 
 @pytest.mark.parametrize("B,S,P", [(4, 64, 1), (2, 96, 6)])
