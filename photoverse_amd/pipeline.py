@@ -72,7 +72,8 @@ class DenoiseLoop:
         self.engines_u, self.engines_c, self.engines_m, self.engines_p = [], [], [], []
         if share_prefix is None:
             share_prefix = os.environ.get("PV_SHARE_PREFIX", "0") == "1"
-        self.share_prefix = bool(share_prefix and not training_mode and batch_splits == 1)
+        first = unet.down_blocks[0]
+        self.share_prefix = bool(share_prefix and not training_mode and batch_splits == 1 and getattr(first, "has_attn", False) and len(first.resnets) >= 1)
         pre_kw = {}
         if self.share_prefix:
             self.engines_p.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, segment="prefix", timesteps=self.timesteps,

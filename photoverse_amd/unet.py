@@ -399,7 +399,7 @@ class UNetEngine:
 
         seg, split = self.segment, self.split
         n_lv = len(u.down_blocks)
-        if seg is not None and not (0 < split < n_lv):
+        if seg in ("outer", "mid") and not (0 < split < n_lv):
             raise ValueError("split must leave at least one resolution level on either side")
 
         def adopt(t_cs, rows):
