@@ -559,7 +559,7 @@ def main():
     # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
     # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.
     # Inference-style engine (fused GEGLU / fused attn2, no activations kept); the whole iteration is `train_step` below.  NOT part of `value`.
-    train_fwd = None
+    train_fwd = ip5 = None
     launches_per_step = loop.launches_per_step
     if rank == 0 and world == 1 and not args.no_train_forward and S == 64:
         loop = subs = None          # release the loop's ~8 GB of static buffers before building the training-shaped engine
@@ -592,6 +592,31 @@ def main():
                      "ms_per_forward": round(ms, 3), "tflop_per_forward": round(tfl, 3), "achieved_tflops": round(tfl / (ms * 1e-3), 1),
                      "mfma_frac": round(tfl / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(eng.out).all().item()),
                      "launches": len(eng.rec) + len(eng.rec_cond), "backward": "see train_step"}
+
+        # configs[1] with ALL FIVE image tokens (token_index = 'full': SURVEY 8d asks for P = 1 and P = 5 both): the same loop, separately labelled
+        eng = gr = None
+        torch.cuda.empty_cache()
+        k5 = min(args.steps, 15)
+        loop5 = DenoiseLoop(unet, B, S, 5, max(k5, 3), args.guidance, use_graph=not args.no_graph, share_prefix=False)
+        g5 = torch.Generator().manual_seed(4321)
+        mk = lambda *sh: torch.randn(*sh, generator=g5).to(dev)
+        loop5.set_conditioning((mk(B, 77, 768), mk(B, 5, 768)), (mk(B, 77, 768), mk(B, 5, 768)))
+        n5 = torch.randn(B, 4, S, S, generator=g5)
+        loop5.reset(n5)
+        for _ in range(3):
+            loop5.step()
+        torch.cuda.synchronize()
+        loop5.reset(n5)
+        t5 = time.perf_counter()
+        for _ in range(k5):
+            loop5.step()
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t5) / k5
+        ip5 = {"workload": "configs[1] with P = 5 image tokens (token_index = 'full'): same loop, bs=%d, 64x64 latents, guidance %.1f" % (B, args.guidance),
+               "value": round(1.0 / dt5, 3), "unit": "denoising steps/s (bs=%d)" % B, "ms_per_step": round(dt5 * 1e3, 3), "steps": k5,
+               "finite": bool(torch.isfinite(loop5.latents).all().item())}
+        loop5 = None
+        torch.cuda.empty_cache()
 
     # third, separately labelled config (BASELINE configs[3] without the optional ArcFace term): a WHOLE training iteration -
     # adapters + text encoder + UNet forward, the backward through all of them, per-module gradient clipping and AdamW - as two
@@ -631,7 +656,7 @@ def main():
             "finite": finite, "rccl_world": rccl_world, "collective": ("all_gather_into_tensor over RCCL (final latents)" if use_dist else "none (single process)"),
             "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "n": len(rank_ms)},
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "xattn_fused": xfused, "shared_prefix": shared, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "shared_prefix": shared, "ip_tokens_5": ip5, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:
