@@ -559,7 +559,7 @@ def main():
     # second, separately labelled config (BASELINE configs[3], forward half only): the UNet forward a TRAINING step runs
     # (train.py:495-506) - P = 5 image tokens, per-sample timesteps, grad-mode branch fusion drawn on the device per layer.
     # Inference-style engine (fused GEGLU / fused attn2, no activations kept); the whole iteration is `train_step` below.  NOT part of `value`.
-    train_fwd = ip5 = None
+    train_fwd = ip5 = cfg4 = None
     launches_per_step = loop.launches_per_step
     if rank == 0 and world == 1 and not args.no_train_forward and S == 64:
         loop = subs = None          # release the loop's ~8 GB of static buffers before building the training-shaped engine
@@ -617,6 +617,34 @@ def main():
                "finite": bool(torch.isfinite(loop5.latents).all().item())}
         loop5 = None
         torch.cuda.empty_cache()
+        # BASELINE configs[4], ONE rank's share (total batch 32 over 8 ranks: 4 samples of 96 x 96 latents per GPU, P = len(layers_idx) + 1 = 6 image tokens):
+        # the same loop at that shape, separately labelled; the 8-rank run is `--gpus 8 --batch 4 --latent 96 --ip_tokens 6`
+        set_visual_cross_attention_adapter(unet, (6,))
+        unet.to(dev)
+        b4, s4, p4 = 4, 96, 6
+        k4 = min(args.steps, 15)
+        loop4 = DenoiseLoop(unet, b4, s4, p4, max(k4, 3), args.guidance, use_graph=not args.no_graph, share_prefix=False)
+        loop4.set_conditioning((mk(b4, 77, 768), mk(b4, p4, 768)), (mk(b4, 77, 768), mk(b4, p4, 768)))
+        n4 = torch.randn(b4, 4, s4, s4, generator=g5)
+        loop4.reset(n4)
+        for _ in range(3):
+            loop4.step()
+        torch.cuda.synchronize()
+        loop4.reset(n4)
+        t4 = time.perf_counter()
+        for _ in range(k4):
+            loop4.step()
+        torch.cuda.synchronize()
+        dt4 = (time.perf_counter() - t4) / k4
+        tf4 = 2 * b4 * 2.1504                        # 2.1504 TFLOP per UNet forward and sample at 96 x 96, P = 6
+        cfg4 = {"workload": "configs[4], one rank's share: bs=4 per GPU (32 over 8 ranks), 96x96 latents (768x768), P = 6 image tokens, guidance %.1f" % args.guidance,
+                "value": round(1.0 / dt4, 3), "unit": "denoising steps/s (bs=4 per GPU)", "ms_per_step": round(dt4 * 1e3, 3), "steps": k4,
+                "step_mfma_frac": round(tf4 / dt4 / MFMA_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(loop4.latents).all().item()),
+                "launches_per_step": loop4.launches_per_step}
+        loop4 = None
+        torch.cuda.empty_cache()
+        set_visual_cross_attention_adapter(unet, (5,))
+        unet.to(dev)
 
     # third, separately labelled config (BASELINE configs[3] without the optional ArcFace term): a WHOLE training iteration -
     # adapters + text encoder + UNet forward, the backward through all of them, per-module gradient clipping and AdamW - as two
@@ -656,7 +684,7 @@ def main():
             "finite": finite, "rccl_world": rccl_world, "collective": ("all_gather_into_tensor over RCCL (final latents)" if use_dist else "none (single process)"),
             "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "n": len(rank_ms)},
             "step_mfma_frac": (round(step_tflop / (dt / args.steps) / 1e0 / MFMA_PEAK_TFLOPS, 4) if step_tflop else None),
-            "roofline": roofline, "xattn_fused": xfused, "shared_prefix": shared, "ip_tokens_5": ip5, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
+            "roofline": roofline, "xattn_fused": xfused, "shared_prefix": shared, "ip_tokens_5": ip5, "configs4_per_rank": cfg4, "train_forward": train_fwd, "train_step": train_step, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:

@@ -315,6 +315,7 @@ def test_bench_contract_line():
     assert xa["all_layers"]["layers_per_step"] == 32 and 0.02 < xa["all_layers"]["frac"] < 1.0 and xa["north_star_target_frac"] == 0.40
     # P = 5 (token_index = 'full') next to the P = 1 headline
     assert d["ip_tokens_5"]["finite"] is True and 0.8 * d["value"] < d["ip_tokens_5"]["value"] < 1.1 * d["value"]
+    assert d["configs4_per_rank"]["finite"] is True and d["configs4_per_rank"]["value"] > 0 and "96x96" in d["configs4_per_rank"]["workload"]
     # the optional shared-prefix loop: a separately labelled number, never the headline
     sp = d["shared_prefix"]
     assert sp["what"].startswith("NOT the headline") and 0.97 < sp["flops_vs_two_full_forwards"] < 0.98 and sp["launches_per_step"] < d["config"]["launches_per_step"]
