@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape timing of ONE launch plan of a denoising step (GPU box): every (symbol, GFLOP, workgroups) group of tagged launches replayed alone between
-HIP events.  usage: plan_breakdown.py [merged|head|tail]"""
+HIP events.  usage: plan_breakdown.py [merged|head|tail] [B S P]   (default 16 64 1 = configs[1]; 4 96 6 = configs[4] per rank)"""
 import os
 import sys
 from collections import OrderedDict
@@ -12,7 +12,7 @@ from bench import build_random_unet  # noqa: E402
 from photoverse_amd.pipeline import DenoiseLoop  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "merged"
-B, S, P = 16, 64, 1
+B, S, P = (int(a) for a in sys.argv[2:5]) if len(sys.argv) >= 5 else (16, 64, 1)
 dev = torch.device("cuda")
 unet = build_random_unet(P, dev)
 loop = DenoiseLoop(unet, B, S, P, 50, 7.5)
