@@ -618,7 +618,7 @@ def main():
         loop5 = None
         torch.cuda.empty_cache()
         # BASELINE configs[4], ONE rank's share (total batch 32 over 8 ranks: 4 samples of 96 x 96 latents per GPU, P = len(layers_idx) + 1 = 6 image tokens):
-        # the same loop at that shape, separately labelled; the 8-rank run is `--gpus 8 --batch 4 --latent 96 --ip_tokens 6`
+        # the same loop at that shape, separately labelled; the 8-rank run is `--gpus 8 --batch 4 --latent 96 --ip-tokens 6`
         set_visual_cross_attention_adapter(unet, (6,))
         unet.to(dev)
         b4, s4, p4 = 4, 96, 6
