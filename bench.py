@@ -279,6 +279,28 @@ def train_step_leg(unet, B, S, dev, reps=3, with_face=True):
             "hip_graph": hip_graph, "samples_per_s": round(B / (iter_ms * 1e-3), 2), "with_face_loss": face}
 
 
+def workload_label(B, S, P, guidance, steps, world):
+    """Which BASELINE.json config the arguments describe (B = per-GPU batch).  configs[1]: bs=16, 64x64 latents, P=1, 50 steps on one GPU;
+    configs[2]: the same per GPU on 8 GPUs (bs=128, batch-sharded); configs[4]: bs=32 over 8 GPUs = 4 per GPU, 96x96 latents (768x768),
+    P = 6 image tokens (extra_num_tokens=16 widens the adapter, not the token count of a layer: SURVEY 8d).  Anything else says so."""
+    shape = f"SD-v1.5 UNet + PhotoVerse processors, {steps}-step loop, bs={B}/GPU, {8 * S}x{8 * S} ({S}x{S} latents), P={P}, guidance {guidance:g}, fp16"
+    if (B, S, P, guidance) == (16, 64, 1, 7.5):
+        if steps != 50:
+            head = f"configs[1] shape timed over {steps} steps instead of 50" + ("" if world == 1 else f", per GPU x {world} GPUs (configs[2]-shaped, batch-sharded)")
+        elif world == 1:
+            head = "configs[1]"
+        elif world == 8:
+            head = "configs[2]: bs=128 batch-sharded over 8 GPUs (configs[1] per GPU), one all-gather of the final latents"
+        else:
+            head = f"configs[2]-shaped (configs[1] per GPU x {world} GPUs, batch-sharded)"
+    elif (B, S, P, guidance) == (4, 96, 6, 7.5):
+        head = ("configs[4] per-rank shape" if world == 1 else
+                "configs[4]: bs=32 batch-sharded over 8 GPUs" if world == 8 else f"configs[4]-shaped (its per-rank shape x {world} GPUs)")
+    else:
+        head = "custom shape (NOT a BASELINE config)"
+    return head + ": " + shape
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,12 +339,23 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             seen = [None] * world
             dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+            # the data path's one collective, on CPU tensors: every rank contributes its shard of a global batch drawn once and sliced
+            # (pipeline.shard_batch), one all_gather_into_tensor puts the shards back in rank order
+            import torch
+            from photoverse_amd.pipeline import shard_batch
+            gb = args.batch * world
+            glob = torch.arange(gb * 4, dtype=torch.float32).view(gb, 4)
+            got = torch.empty_like(glob)
+            dist.all_gather_into_tensor(got, glob[shard_batch(gb, rank, world)].contiguous())
+            gather_ok = bool(torch.equal(got, glob))
             dist.destroy_process_group()
         else:
-            seen = [(rank, local_rank, os.getpid())]
+            seen, gather_ok = [(rank, local_rank, os.getpid())], True
         if rank == 0:
             print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": [s_[0] for s_ in seen],
-                              "local_ranks": [s_[1] for s_ in seen], "distinct_pids": len({s_[2] for s_ in seen})}))
+                              "local_ranks": [s_[1] for s_ in seen], "distinct_pids": len({s_[2] for s_ in seen}), "gather_in_rank_order": gather_ok,
+                              "global_batch": args.batch * world,
+                              "workload": workload_label(args.batch, args.latent, args.ip_tokens, args.guidance, args.steps, world)}))
         return
 
     import torch
@@ -660,15 +693,7 @@ def main():
         cpu = cpu_baseline()
 
     if rank == 0:
-        shape = f"SD-v1.5 UNet + PhotoVerse processors, {args.steps}-step loop, bs={B}/GPU, {8 * S}x{8 * S} ({S}x{S} latents), P={P}, guidance {args.guidance:g}, fp16"
-        if (B, S, P, args.guidance, args.steps) == (16, 64, 1, 7.5, 50):
-            workload = ("configs[1]: " if world == 1 else f"configs[2]-shaped (configs[1] per GPU x {world} GPUs, batch-sharded): ") + shape
-        elif (B, S, P, args.guidance) == (16, 64, 1, 7.5):
-            workload = f"configs[1] shape timed over {args.steps} steps instead of 50: " + shape
-        elif (B, S, P, args.guidance) == (4, 96, 6, 7.5):
-            workload = "configs[4] per-rank shape: " + shape
-        else:
-            workload = "custom shape (NOT a BASELINE config): " + shape
+        workload = workload_label(B, S, P, args.guidance, args.steps, world)
         value = world * args.steps / dt
         step_tflop = 2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 if S == 64 else None
         out = {

@@ -301,7 +301,7 @@ int pv_xattn_fused_wo_slot(int32_t slot);
  *   ctx[b, m, h*d:(h+1)*d] = w_text*softmax(q Kt^T/sqrt(d)) Vt + w_ip*softmax(q Kip^T/sqrt(d)) Vip,  q = to_q(LayerNorm(hs))[:, head h]
  * norm2 is folded algebraically so that the GEMM reads the raw rows: to_q(LN(x)) = rstd * (wq . x - mean * wq_rowsum) + q_bias with
  * wq = to_q.weight x diag(gamma) (fp16), wq_rowsum[n] = sum_k wq[n][k] (of the fp16 values), q_bias = to_q.weight . beta.
- * d == 160; nt <= 80, nip <= 16; K / V rows as for pv_cross_attention.  (ABI 11)
+ * d in {160, 80} (80: two heads per 160-feature block); every row extent (batch*nq*ld_hs, ...) below 2 GiB; nt <= 80, nip <= 16; K / V rows as for pv_cross_attention.  (ABI 11)
  */
 typedef struct pv_xattn_lnq_params {
     const void* hs; int32_t ld_hs;             /* fp16 [batch*nq][heads*d]: block input (pre-norm2) */

@@ -13,8 +13,18 @@
 #include "pv_common.h"
 #include <type_traits>
 
+#ifndef PV_ATTN8_DEFAULT
+#define PV_ATTN8_DEFAULT (-1)   // variant of attn8_kernel taken by default; -1 = the 4-wave kernel
+#endif
 #ifndef PV_ATTN_ABLATE
 #define PV_ATTN_ABLATE 0   // 1 no exp, 2 no QK MFMA, 3 no PV MFMA: timing-only builds (wrong results)
+#endif
+
+#ifdef PV_ATTN8_STAMPS
+// diagnostic build only (tools/diag/attn8_stamps.py): per-wave shader-cycle sums of the four parts of attn8_kernel's tile loop, for three workgroups
+__device__ unsigned long long pv_attn8_stamps[3 * 8 * 8];
+extern "C" int pv_attn8_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pv_attn8_stamps), sizeof(pv_attn8_stamps)); }
+#define A8_NOW() __builtin_amdgcn_s_memtime()
 #endif
 
 namespace {
@@ -371,6 +381,297 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 }
 
 // ---------------------------------------------------------------------------------------------
+// d = 40 self attention as ONE 8-wave workgroup per CU (512 queries), the two waves of every SIMD STAGGERED by one barrier interval
+// (MI355X_MICROARCH.md, "Two waves per SIMD"): a wave alternates a MATRIX segment - P.V of tile t, then K.Q^T of tile t + 1: 56 MFMAs and
+// the 20 fragment reads, plus its one or two LDS-DMA pieces of tile t + 3 - with a VECTOR segment - the online softmax of tile t + 1: ~180
+// VALU instructions, no LDS, no MFMA.  Waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave holds the matrix pipe while
+// its partner issues the exponentials; in the 4-wave kernel above the two co-resident workgroups drift freely and a wave's 32-MFMA clump
+// meets its partner's clump as often as its softmax.  Per query row the arithmetic and its order are those of attn_kernel<40, 4, true>:
+// the results are BIT-IDENTICAL (tests/test_hip_kernels.py).  K / V tiles: the same LDS images, four-slot ring, each tile staged once per
+// 512 queries (half the L2 -> LDS bytes of the 256-query workgroup).
+//   VAR bit 0: stagger (waves 4-7 one interval late); bit 1: s_setprio 1 for waves 4-7, once, before the loop; bit 2: ONE wave-uniform
+//   rescale decision per tile for the four query fragments (their row-maximum chains in one basic block); bit 3: lazy reference (below).
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
+    constexpr int D = 40, NQ = 4, KB = 64;
+    using C = ACfg<D>;
+    constexpr bool STAGGER = (VAR & 1) != 0, PRIO = (VAR & 2) != 0, JOINT = (VAR & 4) != 0, LAZY = (VAR & 8) != 0;
+    // LAZY: a row's softmax reference moves only when a score exceeds it by more than 8 log2 units (P <= 256: the same relative precision in
+    // fp16, sums in fp32).  With the eager form the rescale block runs in ~60 % of the (fragment, tile) pairs of a 4096-key row of random
+    // scores (a new maximum among 16 rows x 64 keys has probability ~ min(1, 16 / t) at tile t); lazily, in the first tiles only.
+    constexpr float UP = LAZY ? 8.f : 0.f;
+    constexpr int STAGE = KB * (C::KS + C::VS);          // halfs per ring slot (14 336 B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sbase = reinterpret_cast<half_t*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = pv_wave_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool late = STAGGER && wave >= 4;
+    constexpr int QW = 64 * NQ * 2;                      // 512 queries per workgroup
+    const int nqt = (p.nq + QW - 1) / QW;
+    const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int qt = rid % nqt, h = (rid / nqt) % p.heads, b = rid / (nqt * p.heads);
+    const half_t* Q = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.nq * p.ldq + h * D;
+    const half_t* Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.nk * p.ldk + h * D;
+    const half_t* Vg = reinterpret_cast<const half_t*>(p.v) + (size_t)b * p.nk * p.ldv + h * D;
+
+    // pad columns of the four slots, written once (as in attn_kernel): K pads zero, V pads zero except column D = 1.0 (the softmax
+    // denominator accumulates in the P.V product's spare output column)
+    for (int st = 0; st < 4; ++st) {
+        half_t* sK = sbase + st * STAGE;
+        half_t* sV = sK + KB * C::KS;
+        constexpr int NPC = C::KCH - C::CH, NPV = (C::VS - D) / 8;
+        for (int i = tid; i < KB * NPC; i += 512) {
+            const int r = i / NPC, c = i - r * NPC;
+            *reinterpret_cast<half8_t*>(sK + C::koff(r, C::CH + c)) = zero8();
+        }
+        for (int i = tid; i < KB * NPV; i += 512) {
+            const int r = i / NPV, c = i - r * NPV;
+            half8_t v = zero8();
+            if (c == 0) v[0] = (half_t)1.0f;
+            *reinterpret_cast<half8_t*>(sV + r * C::VS + D + c * 8) = v;
+        }
+    }
+
+    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
+    half8_t qf[NQ][C::KSTEPS];
+    int qrow[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrow[qi] = qt * QW + (wave * NQ + qi) * 16 + fr;
+        const int rc = min(qrow[qi], p.nq - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qi][ks][j] = (half_t)((float)qf[qi][ks][j] * qscale);
+        }
+    }
+
+    float4_t o[C::DVF][NQ];
+#pragma unroll
+    for (int f = 0; f < C::DVF; ++f)
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) m_run[qi] = 0.f;
+    float4_t s[4][NQ];
+    half8_t pb[2][NQ];
+
+    // --- MATRIX segment, first half: S'^T = K.Q'^T - m_run for tile t (slot t & 3)
+    auto qk = [&](int t, const bool FIRST) {
+        const half_t* sK = sbase + (t & 3) * STAGE;
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            const float init = FIRST ? 0.f : -m_run[qi];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[kb][qi] = float4_t{init, init, init, init};
+        }
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+            }
+    };
+    // --- VECTOR segment: online softmax of tile t; leaves P (fp16, the second product's B operand) in pb
+    auto rescale = [&](int qi, float mxq, const bool FIRST) {       // rare after the first tiles: a row exceeded its running maximum
+        const float d = FIRST ? (mxq == -INFINITY ? 0.f : mxq) : fmaxf(mxq, 0.f);
+        const float alpha = FIRST ? 0.f : PV_EXP2(-d);
+        m_run[qi] += d;
+#pragma unroll
+        for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][qi][r] -= d;
+    };
+    auto softmax = [&](int t, const bool MASKED, const bool FIRST) {
+        if (MASKED) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KB + kb * 16 + fq * 4 + r >= p.nk) s[kb][qi][r] = -INFINITY;
+        }
+        float mx[NQ];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kb][qi][r]);
+            mx[qi] = m;
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) mx[qi] = pv_quad_max(mx[qi]);
+        if (JOINT) {
+            if (FIRST || __any(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])) > UP)) {
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) rescale(qi, mx[qi], FIRST);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            if (!JOINT) {
+                if (FIRST || __any(mx[qi] > UP)) rescale(qi, mx[qi], FIRST);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kb][qi][r] = PV_EXP2(s[kb][qi][r]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pb[s2][qi][r] = (half_t)s[2 * s2][qi][r];
+                    pb[s2][qi][r + 4] = (half_t)s[2 * s2 + 1][qi][r];
+                }
+        }
+    };
+    // --- MATRIX segment, second half: O^T += V^T.P^T for tile t
+    auto pv = [&](int t) {
+        const half_t* sV = sbase + (t & 3) * STAGE + KB * C::KS;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) {
+                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
+            }
+    };
+
+    // LDS-DMA pieces of a tile (1 KiB each): K = 8 pieces of 8 swizzled 128-B rows -> wave w stages piece w; V = 6 linear pieces ->
+    // waves 0-5 (lane -> 16-B chunk 64 w + lane of the [64][6] tile; chunk 5 of a row is the pad chunk and stays out of the DMA)
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Kg), 0, ((p.nk - 1) * p.ldk + D) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Vg), 0, ((p.nk - 1) * p.ldv + D) * 2, 0x00020000);
+    unsigned koff, voff;
+    bool vlive;
+    {
+        const int r = 8 * wave + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+        koff = c < C::CH ? (unsigned)(r * p.ldk * 2 + c * 16) : 0x80000000u;
+        const int q = 64 * wave + lane, vr = q / 6, vc = q - vr * 6;
+        voff = (unsigned)(vr * p.ldv * 2 + vc * 16);
+        vlive = vc < C::CH && wave < 6;
+    }
+    auto issue_tile = [&](int t) {
+        char* sK = reinterpret_cast<char*>(sbase + (t & 3) * STAGE);
+        char* sV = sK + KB * C::KS * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, PV_LDS_PTR(sK + wave * 1024), 16, (int)koff, t * KB * p.ldk * 2, 0, 0);
+        if (vlive) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, PV_LDS_PTR(sV + wave * 1024), 16, (int)voff, t * KB * p.ldv * 2, 0, 0);
+    };
+    auto interval = [&]() {                      // segment boundary: nothing crosses it in either direction
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int ntiles = (p.nk + KB - 1) / KB;
+    __syncthreads();                             // the pad columns are visible before any tile is read
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    if (ntiles > 2) issue_tile(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    interval();
+    if (late) interval();                        // waves 4-7: one interval behind
+    qk(0, true);
+    // The segments are pinned: hipcc sinks pure arithmetic (the exponentials, even whole MFMA chains) across s_barrier into the block of
+    // its first use; an empty asm that "modifies" a segment's results keeps them on their side of the barrier.
+    auto pin_s = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) asm volatile("" : "+v"(s[kb][qi]));
+    };
+    auto pin_o = [&]() {
+#pragma unroll
+        for (int f = 0; f < C::DVF; ++f)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) asm volatile("" : "+v"(o[f][qi]));
+    };
+    auto pin_p = [&]() {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) asm volatile("" : "+v"(pb[0][qi]), "+v"(pb[1][qi]), "+v"(m_run[qi]));
+    };
+    pin_s();
+#ifdef PV_ATTN8_STAMPS
+    unsigned long long a8_acc[4] = {0, 0, 0, 0}, a8_t0 = 0, a8_t1, a8_t2, a8_t3, a8_c0 = 0, a8_r0 = 0;
+#endif
+    for (int t = 0; t < ntiles; ++t) {
+#ifdef PV_ATTN8_STAMPS
+        a8_t3 = A8_NOW();                          // end of the matrix segment
+        interval();
+        a8_t1 = A8_NOW();
+        if (t == 8) { a8_c0 = a8_t1; a8_r0 = __builtin_amdgcn_s_memrealtime(); }
+        if (t > 8 && t < ntiles - 8) { a8_acc[2] += a8_t3 - a8_t0; a8_acc[3] += a8_t1 - a8_t3; }
+        softmax(t, (t + 1) * KB > p.nk, t == 0);
+        pin_p();
+        pin_o();
+        a8_t2 = A8_NOW();                          // end of the vector segment
+        interval();
+        a8_t0 = A8_NOW();
+        if (t >= 8 && t < ntiles - 8) { a8_acc[0] += a8_t2 - a8_t1; a8_acc[1] += a8_t0 - a8_t2; }
+        if (t == ntiles - 9) {
+            const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 300 ? 1 : blockIdx.x == 700 ? 2 : -1;
+            if (slot >= 0 && lane == 0) {
+                unsigned long long* o8 = pv_attn8_stamps + (slot * 8 + wave) * 8;
+                o8[0] = a8_acc[0]; o8[1] = a8_acc[1]; o8[2] = a8_acc[2]; o8[3] = a8_acc[3];
+                o8[4] = a8_t0 - a8_c0; o8[5] = __builtin_amdgcn_s_memrealtime() - a8_r0; o8[6] = (unsigned long long)(ntiles - 16);
+            }
+        }
+#else
+        interval();
+        softmax(t, (t + 1) * KB > p.nk, t == 0);
+        pin_p();
+        pin_o();
+        interval();
+#endif
+        // this wave's pieces of tile t + 2 (issued at the end of its previous matrix segment, a whole vector segment ago) have landed
+        // (hipcc would put this wait in front of the first LDS read below anyway: it cannot tell the ring slots apart)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pv(t);
+        qk(t + 1, false);                        // past the last tile: scores of a stale slot that nothing reads (no branch between the
+                                                 // two products, so the K fragments are requested under the P.V MFMAs)
+        pin_o();
+        pin_s();
+        // tile t + 3 goes into the slot of tile t - 1, whose last reader (the late half's P.V) finished one interval ago; it is first
+        // read in matrix segment t + 2, behind every wave's landed-wait at the head of its segment t + 1 and a barrier
+        if (t + 3 < ntiles) issue_tile(t + 3);
+    }
+    if (STAGGER && !late) interval();            // every wave passes the same number of barriers
+
+    half_t* O = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.nq * p.ldo + h * D;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        // the denominator is output column D: fragment D / 16, lanes with fq == (D % 16) / 4, register D % 4
+        const float l = __shfl(o[D / 16][qi][D % 4], fr + 16 * ((D % 16) / 4), 64);
+        const float inv = 1.0f / l;
+        if (p.lse != nullptr && fq == 0 && qrow[qi] < p.nq) p.lse[((size_t)b * p.heads + h) * p.nq + qrow[qi]] = m_run[qi] + __log2f(l);
+        if (qrow[qi] < p.nq) {
+#pragma unroll
+            for (int f = 0; f < C::DVF; ++f) {
+                const int dv = f * 16 + fq * 4;
+                if (dv < D) {
+                    half4_t ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[f][qi][r] * inv);
+                    *reinterpret_cast<half4_t*>(O + (size_t)qrow[qi] * p.ldo + dv) = ov;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dual-branch cross attention.  K/V image rows: [0,nt) text, [IP0, IP0+nip) image tokens, rest zero.
 constexpr int XKEYS = 96;
 constexpr int IP0 = 80;
@@ -568,6 +869,35 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
         static const bool no_dma = getenv("PV_ATTN_NO_DMA") != nullptr;      // A/B switch
         if (!no_dma && (size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < (1ull << 31)) {
             constexpr int smem3 = 4 * smem1;            // 56 KiB: above the 48-KiB default of dynamic LDS
+            // 8-wave staggered form: one 512-query workgroup per CU; taken when the launch fills the chip with them
+            static const int var8 = getenv("PV_ATTN8") ? atoi(getenv("PV_ATTN8")) : PV_ATTN8_DEFAULT;
+            const long wg512 = (long)((p.nq + 511) / 512) * p.heads * p.batch;
+            if (var8 >= 0 && !p.causal && wg512 >= 256) {
+                void (*kern)(const pv_attn_params) = nullptr;
+                switch (var8) {
+                    case 0: kern = attn8_kernel<0>; break;
+                    case 1: kern = attn8_kernel<1>; break;
+                    case 3: kern = attn8_kernel<3>; break;
+                    case 4: kern = attn8_kernel<4>; break;
+                    case 5: kern = attn8_kernel<5>; break;
+                    case 7: kern = attn8_kernel<7>; break;
+                    case 9: kern = attn8_kernel<9>; break;
+                    case 11: kern = attn8_kernel<11>; break;
+                    case 13: kern = attn8_kernel<13>; break;
+                    case 15: kern = attn8_kernel<15>; break;
+                    default: return (int)hipErrorInvalidValue;
+                }
+                static bool attr8_set[64][16] = {};
+                int dev8 = 0;
+                (void)hipGetDevice(&dev8);
+                if (!attr8_set[dev8 & 63][var8]) {
+                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+                    if (e != hipSuccess) return (int)e;
+                    attr8_set[dev8 & 63][var8] = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)wg512), dim3(512), smem3, s, p);
+                return PV_CHECK_LAUNCH();
+            }
             static bool attr_set_dev[64] = {};
             int dev_id = 0;
             (void)hipGetDevice(&dev_id);

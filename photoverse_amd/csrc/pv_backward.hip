@@ -350,7 +350,9 @@ extern "C" int pv_transpose_f16(const void* x, int32_t ldx, int32_t rows, int32_
 
 extern "C" int pv_layernorm_backward(const pv_layernorm_bwd_params* p, void* stream) {
     if (!p->x || !p->dy || !p->dx || !p->gamma || !p->beta || p->rows <= 0 || p->cols <= 0 || p->cols > 2048) return (int)hipErrorInvalidValue;
-    if (!p->dgb_partial && p->cols % 8 == 0 && (p->ldx | p->lddy | p->lddx) % 8 == 0) {
+    if (p->add && p->ldadd < p->cols) return (int)hipErrorInvalidValue;
+    // the vector kernel reads 16 bytes at a time from every operand, the optional accumulated gradient included
+    if (!p->dgb_partial && p->cols % 8 == 0 && (p->ldx | p->lddy | p->lddx | (p->add ? p->ldadd : 0)) % 8 == 0) {
         const int nchunk = p->cols / 8;                      // fewest lanes per row whose (lanes x chunks) cover the row
         hipStream_t st = (hipStream_t)stream;
         if (nchunk <= 40) launch_ln_bwd_vec<8, 5>(*p, st);          // 320 columns

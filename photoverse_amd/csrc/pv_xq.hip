@@ -383,6 +383,12 @@ extern "C" int pv_cross_attention_lnq(const pv_xattn_lnq_params* p, void* stream
     const size_t C = (size_t)p->heads * p->d;
     if (C % D) return (int)hipErrorInvalidValue;
     if (C * C * 2 >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    // the kernel addresses rows through 32-bit buffer offsets (0x80000000 is its out-of-range sentinel): every extent must stay below 2 GiB
+    const size_t rows_m1 = (size_t)p->batch * p->nq - 1;
+    if (rows_m1 * (size_t)p->ld_hs * 2 + C * 2 >= (1ull << 31) || rows_m1 * (size_t)p->ldo * 2 + C * 2 >= (1ull << 31) ||
+        ((size_t)p->batch * p->nt - 1) * (size_t)(p->ldkt > p->ldvt ? p->ldkt : p->ldvt) * 2 + C * 2 >= (1ull << 31) ||
+        (p->nip > 0 && ((size_t)p->batch * p->nip - 1) * (size_t)(p->ldkip > p->ldvip ? p->ldkip : p->ldvip) * 2 + C * 2 >= (1ull << 31)))
+        return (int)hipErrorInvalidValue;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);

@@ -215,6 +215,8 @@ class Recorder:
             cs = self.colstats[key] = colstats_out if colstats_out is not None else self.empty(((M + 63) // 64, 2, N), torch.float32)
             assert cs.shape == ((M + 63) // 64, 2, N) and cs.dtype == torch.float32 and cs.is_contiguous()
         else:
+            if colstats_out is not None and not _NO_COLSTATS:
+                raise ValueError("gemm(colstats_out=...): this launch cannot produce column statistics (GEGLU / fp32 output / strided output)")
             self.colstats.pop(key, None)          # the buffer is being rewritten without statistics
         ln_rowsum = None
         if ln_gamma is not None:

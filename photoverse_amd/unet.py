@@ -405,8 +405,15 @@ class UNetEngine:
         def adopt(t_cs, rows):
             """a tensor written by ANOTHER plan (with its column statistics) becomes this plan's current activation"""
             t, cs = t_cs
-            assert t.shape[0] == rows and cs is not None
-            self.rec.colstats[(t.data_ptr(), rows, t.shape[1])] = cs
+            assert t.shape[0] == rows
+            key = (t.data_ptr(), rows, t.shape[1])
+            # statistics are adopted only when the producing plans really write them: with the PV_NO_COLSTATS A/B switch (ops._NO_COLSTATS)
+            # Recorder.gemm leaves a caller-owned statistics buffer untouched, and GroupNorm must fall back to its own statistics pass
+            # instead of normalising with the zero-initialised buffer
+            if cs is not None and not ops._NO_COLSTATS:
+                self.rec.colstats[key] = cs
+            else:
+                self.rec.colstats.pop(key, None)
             return t
 
         pre = self.prefix_in
@@ -431,7 +438,7 @@ class UNetEngine:
                 res0 = first.resnets[0]
                 xr = self._resnet(res0, x, None, B, h, w, temb_all, toffs[id(res0)])
                 hs = self._transformer("down_blocks.0.attentions.0", first.attentions[0], xr, B, h, w, stop_after_attn1=True)
-                self.prefix_out = {"conv_in": (x, rec.colstats[key(x)]), "res": (xr, rec.colstats[key(xr)]), "hs": hs}
+                self.prefix_out = {"conv_in": (x, rec.colstats.get(key(x))), "res": (xr, rec.colstats.get(key(xr))), "hs": hs}
                 self.out = hs
                 return
         else:

@@ -563,6 +563,8 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     groups = ts.trainable_parameters()
     opt = AdamW([p for grp in groups.values() for p in grp], lr=1e-4, weight_decay=1e-2)
     before = {n: h_params[n].detach().clone() for n in train_names}
+    sign_h = torch.cat([torch.sign(h_params[n].grad.float().cpu()).flatten() for n in train_names])
+    sign_r = torch.cat([torch.sign(r_params[n].grad if r_params[n].grad is not None else torch.zeros_like(r_params[n])).flatten() for n in train_names])
     norms = opt.step(clip_groups=list(groups.values()), max_norm=1.0, grad_scale=S)
     r_all = [r_params[n] for n in train_names]
     want_norms = [float(torch.nn.utils.clip_grad_norm_(list(r_ta.parameters()), 1.0)), float(torch.nn.utils.clip_grad_norm_(list(r_ia.parameters()), 1.0)),
@@ -576,7 +578,14 @@ def test_training_step_backward_matches_oracle_autograd(need_gpu, p_drop, hw):
     upd_r = torch.cat([(r_params[n].detach() - before[n].cpu()).flatten() for n in train_names])
     upd_err = rel_l2(upd_h, upd_r)
     print(f"first AdamW update vs torch.optim.AdamW on the oracle gradients: rel-L2 {upd_err:.3e}")
-    assert upd_err < 0.15          # sign flips of near-zero gradient entries dominate: each flips a full +-lr step
+    # The first AdamW step moves a weight by ~lr * sign(g) whatever |g| is: an entry whose (near-zero) gradient has the other sign in the fp16 device
+    # path flips a FULL +-lr step, and those few entries are the whole unmasked error.  So: the flipped entries are few, and everywhere else the
+    # update agrees to the optimizer's own arithmetic (a 2x error in lr, beta, eps, weight decay or the clip scale shows up at O(1) here).
+    flipped = sign_h != sign_r
+    keep = ~flipped
+    masked_err = rel_l2(upd_h[keep], upd_r[keep])
+    print(f"sign-flipped gradient entries: {flipped.float().mean().item():.3%}; update rel-L2 over the others: {masked_err:.3e}")
+    assert upd_err < 0.15 and flipped.float().mean().item() < 0.02 and masked_err < 2e-2
 
 
 @pytest.mark.parametrize("smooth_face", [False, True])

@@ -18,7 +18,7 @@ def rel_l2(a, b):
 
 
 def _load(golden_dir, name):
-    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+    return torch.load(os.path.join(golden_dir, name), weights_only=True)
 
 
 # fp16-storage tolerance for ONE full-size UNet forward vs the fp32 oracle (measured 1.0-1.2e-3)

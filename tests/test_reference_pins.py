@@ -12,7 +12,7 @@ from oracle.seeded import checksums, fill_state_
 
 
 def _load(golden_dir, name):
-    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+    return torch.load(os.path.join(golden_dir, name), weights_only=True)
 
 
 def _check_sums(module, sums):

@@ -25,7 +25,7 @@ def need_gpu():
 
 
 def _load(golden_dir, name):
-    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+    return torch.load(os.path.join(golden_dir, name), weights_only=True)
 
 
 def _check_sums(module, sums, prefix=""):

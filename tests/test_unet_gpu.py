@@ -260,7 +260,7 @@ def test_fifty_step_loop_latent_tolerance(tiny_pair, golden_dir):
     from oracle.infer_ref import draw_noise_ref
     from photoverse_amd.pipeline import DenoiseLoop
     _ref, hip = tiny_pair
-    fx = torch.load(os.path.join(golden_dir, "full_tiny50.pt"), weights_only=False)
+    fx = torch.load(os.path.join(golden_dir, "full_tiny50.pt"), weights_only=True)
     g = torch.Generator().manual_seed(fx["cond_seed"])
     B, P = 1, 1
     cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
@@ -465,6 +465,37 @@ def test_lowres_merge_of_the_two_cfg_forwards_changes_nothing_per_sample(full_hi
     err = rel_l2(a2, b2)
     print(f"low-resolution CFG merge vs two whole forwards (default split-K): rel-L2 {err:.2e}; launches per step {na} vs {nb}")
     assert err < 4e-3 and na < nb           # measured 4e-4 (64 x 64) .. 2.1e-3 (96 x 96): fp32 summation order of different split-K choices through two random-init UNet steps
+
+
+def test_seam_statistics_are_not_adopted_when_the_gemm_epilogue_does_not_write_them(full_hip_unet, monkeypatch):
+    """with the PV_NO_COLSTATS A/B switch ``Recorder.gemm`` leaves the caller-owned seam statistics buffers of the
+    low-resolution merge untouched (zeros).  The consuming plans must then run GroupNorm's own statistics pass instead of adopting the
+    buffers (mean = var = 0 -> silently wrong latents); the shared prefix must not raise a KeyError either."""
+    from photoverse_amd import ops
+    from photoverse_amd.pipeline import DenoiseLoop
+    hip = full_hip_unet
+    B, S, P, T = 2, 64, 1, 2
+    g = torch.Generator().manual_seed(78)
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, S, S, generator=g)
+
+    def run(**kw):
+        loop = DenoiseLoop(hip, B, S, P, T, 7.5, merge_lowres=True, **kw)
+        loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        loop.reset(noise)
+        out = loop.run().clone().cpu()
+        del loop
+        return out
+
+    want = run()
+    monkeypatch.setattr(ops, "_NO_COLSTATS", True)
+    got = run()
+    got_prefix = run(share_prefix=True)
+    assert torch.isfinite(got).all()
+    err, err_p = rel_l2(got, want), rel_l2(got_prefix, want)
+    print(f"merged loop with GroupNorm statistics by a pass (PV_NO_COLSTATS) vs epilogue statistics: rel-L2 {err:.2e}, with the shared prefix {err_p:.2e}")
+    assert err < 2e-3 and err_p < 2e-3
 
 
 def _two_rank_loop_worker(rank, world, port, q):
