@@ -14,7 +14,10 @@
 #include <type_traits>
 
 #ifndef PV_ATTN8_DEFAULT
-#define PV_ATTN8_DEFAULT (-1)   // variant of attn8_kernel taken by default; -1 = the 4-wave kernel
+// variant of attn8_kernel (its VAR bits) taken where a d = 40 launch has at least one 512-query workgroup per CU; -1 = the 4-wave kernel
+// everywhere.  225 = stagger + exponentiate-first reference check + V-fragment prefetch / C-operand reference + 48-deep score contraction:
+// 394 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch (same box, sustained; profiles/r05_attn8_*.txt).
+#define PV_ATTN8_DEFAULT 225
 #endif
 #ifndef PV_ATTN_ABLATE
 #define PV_ATTN_ABLATE 0   // 1 no exp, 2 no QK MFMA, 3 no PV MFMA: timing-only builds (wrong results)
@@ -383,22 +386,32 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 // ---------------------------------------------------------------------------------------------
 // d = 40 self attention as ONE 8-wave workgroup per CU (512 queries), the two waves of every SIMD STAGGERED by one barrier interval
 // (MI355X_MICROARCH.md, "Two waves per SIMD"): a wave alternates a MATRIX segment - P.V of tile t, then K.Q^T of tile t + 1: 56 MFMAs and
-// the 20 fragment reads, plus its one or two LDS-DMA pieces of tile t + 3 - with a VECTOR segment - the online softmax of tile t + 1: ~180
-// VALU instructions, no LDS, no MFMA.  Waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave holds the matrix pipe while
-// its partner issues the exponentials; in the 4-wave kernel above the two co-resident workgroups drift freely and a wave's 32-MFMA clump
-// meets its partner's clump as often as its softmax.  Per query row the arithmetic and its order are those of attn_kernel<40, 4, true>:
-// the results are BIT-IDENTICAL (tests/test_hip_kernels.py).  K / V tiles: the same LDS images, four-slot ring, each tile staged once per
-// 512 queries (half the L2 -> LDS bytes of the 256-query workgroup).
-//   VAR bit 0: stagger (waves 4-7 one interval late); bit 1: s_setprio 1 for waves 4-7, once, before the loop; bit 2: ONE wave-uniform
-//   rescale decision per tile for the four query fragments (their row-maximum chains in one basic block); bit 3: lazy reference (below).
+// the fragment reads, plus its one or two LDS-DMA pieces of tile t + 3 - with a VECTOR segment - the online softmax of tile t + 1: the
+// exponentials, no MFMA.  Waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave holds the matrix pipe while its partner
+// issues the exponentials; in the 4-wave kernel above the two co-resident workgroups drift freely and a wave's 32-MFMA clump meets its
+// partner's clump as often as its softmax.  K / V tiles: the same LDS images, four-slot ring, each tile staged once per 512 queries (half
+// the L2 -> LDS bytes of the 256-query workgroup).
+//   VAR bit 0 (1): stagger (waves 4-7 one interval late); bit 1 (2): s_setprio 1 for waves 4-7, once, before the loop; bit 2 (4): ONE
+//   wave-uniform rescale decision per tile for the four query fragments; bit 3 (8): lazy reference; bit 4 (16): the wave in its matrix
+//   segment runs at s_setprio 1 (its MFMAs are 8 issue cycles in 16: they delay the partner's VALU by at most that, while a delayed MFMA
+//   stretches the interval for all eight waves); bit 5 (32): the reference check reads the exponentiated scores (below; implies bits 2, 3);
+//   bit 6 (64): the V^T fragments of a tile are requested at the HEAD of the vector segment in front of it (the first three of the six: their LDS latency sits under the
+//   softmax instead of at the head of the matrix segment) and the first score MFMA of a chain takes -m_run as its C operand from a
+//   loop-carried vector (no accumulator-initialising v_mov); bit 7 (128): 48-deep score contraction (16x16x32 + 16x16x16: a quarter fewer
+//   score-MFMA cycles; the d = 40 rows are zero beyond column 40 either way).
+// Variants without bits 3 / 5 compute, per query row, exactly what attn_kernel<40, 4, true> computes, in its order: BIT-IDENTICAL results.
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     constexpr int D = 40, NQ = 4, KB = 64;
     using C = ACfg<D>;
-    constexpr bool STAGGER = (VAR & 1) != 0, PRIO = (VAR & 2) != 0, JOINT = (VAR & 4) != 0, LAZY = (VAR & 8) != 0;
+    constexpr bool STAGGER = (VAR & 1) != 0, PRIO = (VAR & 2) != 0, PCHECK = (VAR & 32) != 0, JOINT = (VAR & 4) != 0 || PCHECK, LAZY = (VAR & 8) != 0 || PCHECK;
+    constexpr bool SEGPRIO = (VAR & 16) != 0, PREF = (VAR & 64) != 0, K48 = (VAR & 128) != 0;
     // LAZY: a row's softmax reference moves only when a score exceeds it by more than 8 log2 units (P <= 256: the same relative precision in
     // fp16, sums in fp32).  With the eager form the rescale block runs in ~60 % of the (fragment, tile) pairs of a 4096-key row of random
     // scores (a new maximum among 16 rows x 64 keys has probability ~ min(1, 16 / t) at tile t); lazily, in the first tiles only.
+    // PCHECK: the lazy test needs no row maximum at all: P = exp2(S') is computed (and rounded to fp16) first, the packed fp16 values are
+    // reduced with v_pk_max_f16 (31 for the wave's 64 x 64 scores instead of 60 fp32 max / lane-swap operations in four dependent chains), and only
+    // a wave that finds a P above 256 goes back to the scores, takes the row maxima and rescales (the scores are still in registers).
     constexpr float UP = LAZY ? 8.f : 0.f;
     constexpr int STAGE = KB * (C::KS + C::VS);          // halfs per ring slot (14 336 B)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -434,18 +447,24 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     }
 
     const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
-    half8_t qf[NQ][C::KSTEPS];
+    half8_t qf[NQ][K48 ? 1 : C::KSTEPS];
+    half4_t qf4[NQ];                                      // K48: the queries' columns 32 + 4 fq .. + 3 (B operand of the 16-deep tail step)
     int qrow[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         qrow[qi] = qt * QW + (wave * NQ + qi) * 16 + fr;
         const int rc = min(qrow[qi], p.nq - 1);
 #pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        for (int ks = 0; ks < (K48 ? 1 : C::KSTEPS); ++ks) {
             const int c = ks * 4 + fq;
             qf[qi][ks] = c < C::CH ? *reinterpret_cast<const half8_t*>(Q + (size_t)rc * p.ldq + c * 8) : zero8();
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[qi][ks][j] = (half_t)((float)qf[qi][ks][j] * qscale);
+        }
+        if (K48) {
+            qf4[qi] = fq < 2 ? *reinterpret_cast<const half4_t*>(Q + (size_t)rc * p.ldq + 32 + fq * 4) : half4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf4[qi][j] = (half_t)((float)qf4[qi][j] * qscale);
         }
     }
 
@@ -455,34 +474,53 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) o[f][qi] = float4_t{0.f, 0.f, 0.f, 0.f};
     float m_run[NQ];
+    float4_t negm[NQ];                                    // PREF: {-m_run} x 4, the C operand of a score chain's first MFMA
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) m_run[qi] = 0.f;
+    for (int qi = 0; qi < NQ; ++qi) {
+        m_run[qi] = 0.f;
+        negm[qi] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
     float4_t s[4][NQ];
     half8_t pb[2][NQ];
+    half8_t vf[C::DVF];                                   // PREF: the first three of the tile's six V^T fragments (keys 0-31)
 
     // --- MATRIX segment, first half: S'^T = K.Q'^T - m_run for tile t (slot t & 3)
     auto qk = [&](int t, const bool FIRST) {
         const half_t* sK = sbase + (t & 3) * STAGE;
+        if (!PREF) {
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            const float init = FIRST ? 0.f : -m_run[qi];
+            for (int qi = 0; qi < NQ; ++qi) {
+                const float init = FIRST ? 0.f : -m_run[qi];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) s[kb][qi] = float4_t{init, init, init, init};
+                for (int kb = 0; kb < 4; ++kb) s[kb][qi] = float4_t{init, init, init, init};
+            }
         }
 #pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ++ks)
+        for (int kb = 0; kb < 4; ++kb) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, fq));
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, ks * 4 + fq));
+            for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][0], PREF ? negm[qi] : s[kb][qi], 0, 0, 0);
+        }
 #pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][ks], s[kb][qi], 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+            if (K48) {
+                // columns 32 + 4 fq .. + 3 of key row kb * 16 + fr: chunk 4 (data) for fq < 2, chunk 5 (zero padding) above
+                const half4_t a = *reinterpret_cast<const half4_t*>(sK + C::koff(kb * 16 + fr, 4 + (fq >> 1)) + (fq & 1) * 4);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, qf4[qi], s[kb][qi], 0, 0, 0);
+            } else {
+                const half8_t a = *reinterpret_cast<const half8_t*>(sK + C::koff(kb * 16 + fr, 4 + fq));
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][K48 ? 0 : 1], s[kb][qi], 0, 0, 0);
             }
+        }
     };
     // --- VECTOR segment: online softmax of tile t; leaves P (fp16, the second product's B operand) in pb
-    auto rescale = [&](int qi, float mxq, const bool FIRST) {       // rare after the first tiles: a row exceeded its running maximum
+    auto rescale = [&](int qi, float mxq, const bool FIRST) {       // a row exceeded its reference (rare after the first tiles when LAZY)
         const float d = FIRST ? (mxq == -INFINITY ? 0.f : mxq) : fmaxf(mxq, 0.f);
         const float alpha = FIRST ? 0.f : PV_EXP2(-d);
         m_run[qi] += d;
+        negm[qi] = float4_t{-m_run[qi], -m_run[qi], -m_run[qi], -m_run[qi]};
 #pragma unroll
         for (int f = 0; f < C::DVF; ++f) o[f][qi] *= alpha;
 #pragma unroll
@@ -490,17 +528,7 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kb][qi][r] -= d;
     };
-    auto softmax = [&](int t, const bool MASKED, const bool FIRST) {
-        if (MASKED) {
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t * KB + kb * 16 + fq * 4 + r >= p.nk) s[kb][qi][r] = -INFINITY;
-        }
-        float mx[NQ];
+    auto row_max = [&](float (&mx)[NQ]) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             float m = -INFINITY;
@@ -512,6 +540,53 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) mx[qi] = pv_quad_max(mx[qi]);
+    };
+    auto exp_pack = [&](int qi) {                                   // pb[.][qi] = fp16(exp2(s[.][qi])); the scores stay in s
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pb[s2][qi][r] = (half_t)PV_EXP2(s[2 * s2][qi][r]);
+                pb[s2][qi][r + 4] = (half_t)PV_EXP2(s[2 * s2 + 1][qi][r]);
+            }
+    };
+    auto softmax = [&](int t, const bool MASKED, const bool FIRST) {
+        if (MASKED) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KB + kb * 16 + fq * 4 + r >= p.nk) s[kb][qi][r] = -INFINITY;
+        }
+        if (PCHECK) {
+            bool redo = FIRST;
+            if (!FIRST) {
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) exp_pack(qi);
+                half2_t m2 = half2_t{(half_t)0.f, (half_t)0.f};
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m2 = __builtin_elementwise_max(m2, half2_t{pb[s2][qi][2 * j], pb[s2][qi][2 * j + 1]});
+                redo = __any(fmaxf((float)m2[0], (float)m2[1]) > 256.f);         // an fp16 overflow (inf) lands here too
+            }
+            if (redo) {
+                float mx[NQ];
+                row_max(mx);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    rescale(qi, mx[qi], FIRST);
+                    exp_pack(qi);
+                }
+            }
+            return;
+        }
+        float mx[NQ];
+        row_max(mx);
         if (JOINT) {
             if (FIRST || __any(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])) > UP)) {
 #pragma unroll
@@ -523,27 +598,22 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
             if (!JOINT) {
                 if (FIRST || __any(mx[qi] > UP)) rescale(qi, mx[qi], FIRST);
             }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[kb][qi][r] = PV_EXP2(s[kb][qi][r]);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pb[s2][qi][r] = (half_t)s[2 * s2][qi][r];
-                    pb[s2][qi][r + 4] = (half_t)s[2 * s2 + 1][qi][r];
-                }
+            exp_pack(qi);
         }
     };
     // --- MATRIX segment, second half: O^T += V^T.P^T for tile t
+    auto load_v = [&](int t) {
+        const half_t* sV = sbase + (t & 3) * STAGE + KB * C::KS;
+#pragma unroll
+        for (int f = 0; f < C::DVF; ++f) vf[f] = vt_frag(sV, C::VS, 0, f * 16, fr, fq);
+    };
     auto pv = [&](int t) {
         const half_t* sV = sbase + (t & 3) * STAGE + KB * C::KS;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int f = 0; f < C::DVF; ++f) {
-                const half8_t a = vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
+                const half8_t a = (PREF && s2 == 0) ? vf[f] : vt_frag(sV, C::VS, s2 * 32, f * 16, fr, fq);
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) o[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[f][qi], 0, 0, 0);
             }
@@ -573,17 +643,6 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-
-    const int ntiles = (p.nk + KB - 1) / KB;
-    __syncthreads();                             // the pad columns are visible before any tile is read
-    issue_tile(0);
-    if (ntiles > 1) issue_tile(1);
-    if (ntiles > 2) issue_tile(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    interval();
-    if (late) interval();                        // waves 4-7: one interval behind
-    qk(0, true);
     // The segments are pinned: hipcc sinks pure arithmetic (the exponentials, even whole MFMA chains) across s_barrier into the block of
     // its first use; an empty asm that "modifies" a segment's results keeps them on their side of the barrier.
     auto pin_s = [&]() {
@@ -602,22 +661,47 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) asm volatile("" : "+v"(pb[0][qi]), "+v"(pb[1][qi]), "+v"(m_run[qi]));
     };
+    auto pin_v = [&]() {
+#pragma unroll
+        for (int f = 0; f < C::DVF; ++f) asm volatile("" : "+v"(vf[f]));
+    };
+
+    const int ntiles = (p.nk + KB - 1) / KB;
+    __syncthreads();                             // the pad columns are visible before any tile is read
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    if (ntiles > 2) issue_tile(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    interval();
+    if (late) interval();                        // waves 4-7: one interval behind
+    if (SEGPRIO) __builtin_amdgcn_s_setprio(1);
+    qk(0, true);
     pin_s();
+    if (SEGPRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef PV_ATTN8_STAMPS
     unsigned long long a8_acc[4] = {0, 0, 0, 0}, a8_t0 = 0, a8_t1, a8_t2, a8_t3, a8_c0 = 0, a8_r0 = 0;
 #endif
     for (int t = 0; t < ntiles; ++t) {
 #ifdef PV_ATTN8_STAMPS
         a8_t3 = A8_NOW();                          // end of the matrix segment
+#endif
         interval();
+#ifdef PV_ATTN8_STAMPS
         a8_t1 = A8_NOW();
         if (t == 8) { a8_c0 = a8_t1; a8_r0 = __builtin_amdgcn_s_memrealtime(); }
         if (t > 8 && t < ntiles - 8) { a8_acc[2] += a8_t3 - a8_t0; a8_acc[3] += a8_t1 - a8_t3; }
+#endif
+        if (PREF) load_v(t);                     // tile t landed three segments ago; nothing waits for these reads before the matrix segment
         softmax(t, (t + 1) * KB > p.nk, t == 0);
         pin_p();
         pin_o();
+        if (PREF) pin_v();
+#ifdef PV_ATTN8_STAMPS
         a8_t2 = A8_NOW();                          // end of the vector segment
+#endif
         interval();
+#ifdef PV_ATTN8_STAMPS
         a8_t0 = A8_NOW();
         if (t >= 8 && t < ntiles - 8) { a8_acc[0] += a8_t2 - a8_t1; a8_acc[1] += a8_t0 - a8_t2; }
         if (t == ntiles - 9) {
@@ -628,13 +712,8 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
                 o8[4] = a8_t0 - a8_c0; o8[5] = __builtin_amdgcn_s_memrealtime() - a8_r0; o8[6] = (unsigned long long)(ntiles - 16);
             }
         }
-#else
-        interval();
-        softmax(t, (t + 1) * KB > p.nk, t == 0);
-        pin_p();
-        pin_o();
-        interval();
 #endif
+        if (SEGPRIO) __builtin_amdgcn_s_setprio(1);
         // this wave's pieces of tile t + 2 (issued at the end of its previous matrix segment, a whole vector segment ago) have landed
         // (hipcc would put this wait in front of the first LDS read below anyway: it cannot tell the ring slots apart)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -646,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         // tile t + 3 goes into the slot of tile t - 1, whose last reader (the late half's P.V) finished one interval ago; it is first
         // read in matrix segment t + 2, behind every wave's landed-wait at the head of its segment t + 1 and a barrier
         if (t + 3 < ntiles) issue_tile(t + 3);
+        if (SEGPRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (STAGGER && !late) interval();            // every wave passes the same number of barriers
 
@@ -870,24 +950,21 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
         if (!no_dma && (size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < (1ull << 31)) {
             constexpr int smem3 = 4 * smem1;            // 56 KiB: above the 48-KiB default of dynamic LDS
             // 8-wave staggered form: one 512-query workgroup per CU; taken when the launch fills the chip with them
-            static const int var8 = getenv("PV_ATTN8") ? atoi(getenv("PV_ATTN8")) : PV_ATTN8_DEFAULT;
+            // (read per call, not cached: tests run several forms in one process; launches are recorded once and replayed from graphs)
+            const char* env8 = getenv("PV_ATTN8");
+            const char* env8min = getenv("PV_ATTN8_MIN");           // fewest 512-query workgroups a launch must have (default: one per CU)
+            const int var8 = env8 ? atoi(env8) : PV_ATTN8_DEFAULT;
             const long wg512 = (long)((p.nq + 511) / 512) * p.heads * p.batch;
-            if (var8 >= 0 && !p.causal && wg512 >= 256) {
+            if (var8 >= 0 && !p.causal && wg512 >= (env8min ? atol(env8min) : 256)) {
                 void (*kern)(const pv_attn_params) = nullptr;
                 switch (var8) {
-                    case 0: kern = attn8_kernel<0>; break;
-                    case 1: kern = attn8_kernel<1>; break;
-                    case 3: kern = attn8_kernel<3>; break;
-                    case 4: kern = attn8_kernel<4>; break;
-                    case 5: kern = attn8_kernel<5>; break;
-                    case 7: kern = attn8_kernel<7>; break;
-                    case 9: kern = attn8_kernel<9>; break;
-                    case 11: kern = attn8_kernel<11>; break;
-                    case 13: kern = attn8_kernel<13>; break;
-                    case 15: kern = attn8_kernel<15>; break;
+#define PV_A8_CASE(V) case V: kern = attn8_kernel<V>; break;
+                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(3) PV_A8_CASE(5) PV_A8_CASE(9) PV_A8_CASE(11) PV_A8_CASE(13) PV_A8_CASE(25) PV_A8_CASE(29)
+                    PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(89) PV_A8_CASE(97) PV_A8_CASE(113) PV_A8_CASE(225) PV_A8_CASE(241) PV_A8_CASE(201)
+#undef PV_A8_CASE
                     default: return (int)hipErrorInvalidValue;
                 }
-                static bool attr8_set[64][16] = {};
+                static bool attr8_set[64][256] = {};
                 int dev8 = 0;
                 (void)hipGetDevice(&dev8);
                 if (!attr8_set[dev8 & 63][var8]) {

@@ -426,6 +426,49 @@ def test_self_attention_spiky_rows(rec_cls):
     assert rel_l2(out, ref) < 2e-3
 
 
+def _attn40(rec_cls, qkv, B, H, n, lse=False):
+    C = H * 40
+    dev = qkv.cuda()
+    rec = rec_cls("cuda")
+    l = rec.empty((B, H, n), torch.float32) if lse else None
+    out = rec.attention(dev[:, :C], dev[:, C:2 * C], dev[:, 2 * C:], batch=B, heads=H, nq=n, nk=n, d=40, lse=l)
+    rec.run()
+    torch.cuda.synchronize()
+    return out.cpu(), (l.cpu() if lse else None)
+
+
+@pytest.mark.parametrize("var", [1, 9, 225, 241])
+@pytest.mark.parametrize("n", [1536, 1000, 100, 64])
+def test_self_attention_8wave_staggered_forms(rec_cls, monkeypatch, var, n):
+    """attn8_kernel (pv_attn.hip: one 512-query workgroup of eight waves, SIMD partners staggered by one barrier interval) in the forms the
+    build ships: 1 = the 4-wave kernel's arithmetic in the staggered structure - BIT-IDENTICAL to it; 9 = lazy softmax reference; 225 (default)
+    / 241 = exponentiate-first reference check, V prefetch, 48-deep score contraction (+ per-segment priorities).  Ragged sizes (query and key
+    tails), one- and two-tile sequences, the log-sum-exp output the training backward reads, and a late dominant key (forces the reference
+    move long after the first tile: the path that goes back to the scores in 225 / 241)."""
+    B, H, d = 2, 8, 40
+    C = H * d
+    qkv = h16(B * n, 3 * C, seed=225 + n)
+    spiky = qkv.clone()
+    spiky[(n * 3) // 5, C:2 * C] *= 12.0
+    monkeypatch.setenv("PV_ATTN8_MIN", "1")                  # these launches are far below one workgroup per CU: take the 8-wave form anyway
+    res = {}
+    for v in (-1, var):
+        monkeypatch.setenv("PV_ATTN8", str(v))
+        res[v] = [_attn40(rec_cls, t, B, H, n, lse=True) for t in (qkv, spiky)]
+    for k, t in enumerate((qkv, spiky)):
+        q, kk, vv = [x.float().view(B, n, H, d).transpose(1, 2) for x in t.split(C, dim=1)]
+        ref = F.scaled_dot_product_attention(q, kk, vv).transpose(1, 2).reshape(B * n, C)
+        out, lse = res[var][k]
+        assert torch.isfinite(out).all()
+        assert rel_l2(out, ref) < 2e-3
+        want_lse = torch.logsumexp((q @ kk.transpose(-1, -2)) / d ** 0.5, -1) / math.log(2.0)
+        assert (lse - want_lse).abs().max() < 2e-2
+        if var == 1:
+            assert torch.equal(out, res[-1][k][0]) and torch.equal(lse, res[-1][k][1])
+        else:
+            assert rel_l2(out, res[-1][k][0]) < 1e-3
+
+
 @pytest.mark.parametrize("d,n,p,wt,wi", [(40, 4096, 1, 1.0, 1.0), (80, 1024, 5, 1.0, 1.0), (160, 256, 6, 1.0, 1.0), (160, 64, 1, 2.0, 0.0),
                                           (40, 200, 5, 0.0, 2.0), (80, 64, 16, 1.0, 1.0)])
 def test_cross_attention_dual_branch(rec_cls, d, n, p, wt, wi):
