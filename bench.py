@@ -23,8 +23,8 @@ UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 #: committed PMC summary `roofline.traffic` is read from (tools/profile_bench.py writes it together with the git blob hashes of the
 #: kernel sources it was measured on; bench.py reports `traffic_stale` when those differ from the sources in the tree)
-PMC_TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"
-KERNEL_SOURCES = ("photoverse_amd/csrc/pv_gemm.hip", "photoverse_amd/csrc/pv_convbig.hip")
+PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
+KERNEL_SOURCES = ("photoverse_amd/csrc/pv_gemm.hip", "photoverse_amd/csrc/pv_convbig.hip", "photoverse_amd/csrc/pv_attn.hip")
 
 
 def git_blob_sha1(path):
@@ -456,34 +456,45 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the launch symbol with the largest share of one step's algorithmic flops (round 4: big_tile_kernel<true, false>,
-        # the 256 x 320-tile 3x3 conv with GroupNorm column statistics of the 64x64 level; the runner-up is the 128-row instantiation that
-        # runs the 32x32 level); replay exactly its launches of one step and time them with HIP events on the launch stream
+        # dominant kernel = the launch SYMBOL with the largest share of one step's algorithmic flops.  Rounds 1-4 that was the 3x3 conv on the big tile
+        # (25 % of a step's flops under one symbol); since round 5 the 64 x 64 convs run on the LDS-resident-patch instantiation (MODE 3, 13.2 %) and the
+        # 32 x 32 convs stay on the gathered one (MODE 0, 12.2 %), so the largest single symbol is the d = 40 self-attention kernel attn8_kernel<225>
+        # (13.4 % of the flops, ~15 % of the time) and the patch conv is the runner-up.  Both get the same measurement: exactly the symbol's launches
+        # of one step, replayed and timed with HIP events on the launch stream.
         engines = loop.all_engines
         by_kernel = {}
         for e in engines:
             for t in e.rec.tags:
                 by_kernel[t[0]] = by_kernel.get(t[0], 0.0) + t[1]
         ranked = sorted(by_kernel, key=by_kernel.get, reverse=True)
-        dom = ranked[0]                                   # the launch symbol with the largest share of a step's algorithmic flops
-        subs = [e.rec.subset(lambda t: t[0] == dom) for e in engines]
-        nl = sum(len(s) for s in subs)
-        flops = sum(t[1] for s in subs for t in s.tags)
-        # as the step schedules it: the two per-branch plans side by side (their launches of this kernel may have 128 one-per-CU workgroups each: half the
-        # chip, by design - pv_gemm_params.big_tile_min), the merged low-resolution plan alone
-        ms = replay(step_schedule(dict(zip(engines, subs))))
-        ach = flops / (ms * 1e-3) / 1e12
-        # the same kernel one launch at a time (what a rocprofv3 per-dispatch duration of an un-overlapped launch shows), over its chip-filling launches only
-        # (>= 256 workgroups: the 64 x 64 level)
-        single = None
-        big_subs = [e.rec.subset(lambda t: t[0] == dom and len(t) > 3 and t[3] >= 256) for e in engines]
-        nb = sum(len(s_) for s_ in big_subs)
-        if nb:
-            fb = sum(t[1] for s_ in big_subs for t in s_.tags)
-            msb = replay([[[r_]] for r_ in big_subs if len(r_)])
-            single = {"what": "launches of this kernel with >= 256 workgroups (they fill the chip alone), replayed one at a time on one stream", "launches_per_step": nb,
-                      "avg_launch_us": round(msb * 1e3 / nb, 2), "achieved": round(fb / (msb * 1e-3) / 1e12, 1), "frac": round(fb / (msb * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
-        # HBM traffic of this kernel from the rocprofv3 PMC passes of the same command (tools/profile_bench.py; counters are
+
+        def kernel_roofline(sym):
+            subs = [e.rec.subset(lambda t: t[0] == sym) for e in engines]
+            nl = sum(len(s_) for s_ in subs)
+            flops = sum(t[1] for s_ in subs for t in s_.tags)
+            # as the step schedules it: the two per-branch plans side by side (their big-tile launches may have 128 one-per-CU workgroups each: half the
+            # chip, by design - pv_gemm_params.big_tile_min), the merged low-resolution plan alone
+            ms = replay(step_schedule(dict(zip(engines, subs))))
+            ach = flops / (ms * 1e-3) / 1e12
+            # the same kernel one launch at a time (what a rocprofv3 per-dispatch duration of an un-overlapped launch shows), over its chip-filling launches
+            # only (>= 256 workgroups)
+            single = None
+            big_subs = [e.rec.subset(lambda t: t[0] == sym and len(t) > 3 and t[3] >= 256) for e in engines]
+            nb = sum(len(s_) for s_ in big_subs)
+            if nb:
+                fb = sum(t[1] for s_ in big_subs for t in s_.tags)
+                msb = replay([[[r_]] for r_ in big_subs if len(r_)])
+                single = {"what": "launches of this kernel with >= 256 workgroups (they fill the chip alone), replayed one at a time on one stream", "launches_per_step": nb,
+                          "avg_launch_us": round(msb * 1e3 / nb, 2), "achieved": round(fb / (msb * 1e-3) / 1e12, 1), "frac": round(fb / (msb * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            return {"kernel": sym, "achieved": round(ach, 1), "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "single_launch": single, "launches_per_step": nl,
+                    "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
+                    "algorithmic_bytes_per_launch": sum(t[2] for s_ in subs for t in s_.tags) / nl,
+                    "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
+
+        dom = ranked[0]
+        first = kernel_roofline(dom)
+        second = kernel_roofline(ranked[1]) if len(ranked) > 1 else None
+        # HBM traffic of the dominant kernel from the rocprofv3 PMC passes of the same command (tools/profile_bench.py; counters are
         # collected in their own runs, so the number is read from the committed summary, not measured in this process)
         traffic, traffic_src, traffic_stale = None, None, None
         try:
@@ -497,31 +508,17 @@ def main():
                 traffic_src = f"{PMC_TRAFFIC_FILE} holds {pmc.get('dominant_kernel')!r}, not this kernel: no traffic figure"
         except (OSError, ValueError):
             pass
-        # runner-up (same measurement), so that both conv instantiations are on the line
-        second = None
-        if len(ranked) > 1:
-            subs2 = [e.rec.subset(lambda t: t[0] == ranked[1]) for e in engines]
-            nl2, fl2 = sum(len(s_) for s_ in subs2), sum(t[1] for s_ in subs2 for t in s_.tags)
-            ms2 = replay(step_schedule(dict(zip(engines, subs2))))
-            second = {"kernel": ranked[1], "launches_per_step": nl2, "avg_launch_us": round(ms2 * 1e3 / nl2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1),
-                      "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                      "share_of_step_flops": round(fl2 / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3)}
-        algo_bytes = sum(t[2] for s in subs for t in s.tags) / nl
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roofline = dict(first)
+        roofline.update({"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "measured": "HIP events around a replay of this kernel's launches of one step AS THE STEP SCHEDULES THEM: the launches of the uncond and cond "
-                                "plans on two streams side by side (per-branch launches of the staggered tile may have 128 one-per-CU workgroups = half the chip each, "
-                                "pv_gemm_params.big_tile_min), the merged low-resolution plan's alone.  achieved = algorithmic flops / elapsed; avg_launch_us = elapsed / "
+                                "plans on two streams side by side, the merged low-resolution plan's alone.  achieved = algorithmic flops / elapsed; avg_launch_us = elapsed / "
                                 "launches (rocprofv3 per-dispatch durations of overlapping dispatches are wall durations: their sum exceeds the elapsed time by the "
-                                "overlap).  `single_launch` is the same kernel one launch at a time",
-                    "single_launch": single,
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                                "overlap).  `single_launch` is the same kernel one launch at a time; `runner_up` the symbol with the next-largest share of the flops, same measurement",
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                     "runner_up": second,
-                    "algorithmic_bytes_per_launch": algo_bytes, "launches_per_step": nl,
-                    "avg_launch_us": round(ms * 1e3 / nl, 2), "flops_per_launch_avg": flops / nl,
-                    "share_of_step_flops": round(flops / (2 * B * UNET_TFLOP_PER_SAMPLE_64 * (S / 64) ** 2 * 1e12), 3),
-                    "real_data_ceiling": {"value": 1700.0, "unit": "TFLOP/s", "frac": round(ach / 1700.0, 4),
-                                          "source": "profiles/r01_mfma_power_probe.txt: this kernel's MFMA + ds_read mix on random fp16 "
-                                                    "operands, no global traffic, holds 1.70 GHz (2.40 GHz / 2.45 PFLOP/s only with zeros)"}}
+                    "real_data_ceiling": {"value": 1700.0, "unit": "TFLOP/s", "frac": round(first["achieved"] / 1700.0, 4),
+                                          "source": "profiles/r01_mfma_power_probe.txt: an MFMA + ds_read mix on random fp16 "
+                                                    "operands, no global traffic, holds 1.70 GHz (2.40 GHz / 2.45 PFLOP/s only with zeros)"}})
 
     # the north_star's named target: MFMA utilisation of the adapter cross-attention kernel.  SURVEY 0.1 #8 defines it as the fused
     # to_q + dual-branch SDPA + to_out kernel.  It exists for the C = 320 layers (pv_xfused.hip); the 640 / 1280-channel layers run four

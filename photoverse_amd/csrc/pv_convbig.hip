@@ -29,6 +29,27 @@
 // widened by v_permlane16_swap, GroupNorm column statistics per 64-row block) are those of pv_gemm.hip.
 #include "pv_gemm_dev.h"
 
+#ifndef PV_PATCH_ABLATE
+#define PV_PATCH_ABLATE 0   // timing-only builds (wrong results): 1 fixed fragment addresses, 2 no patch pieces, 4 no MFMA / VALU interleave
+#endif
+#ifdef PV_CONVBIG_STAMPS
+// diagnostic build only (tools/diag/convbig_seg_stamps.py): per-wave shader-cycle sums of the four parts of a stage (LOAD segment, wait at the barrier
+// behind it, MFMA segment, wait at the barrier behind that) over the whole main loop, for three workgroups
+__device__ unsigned long long pv_convbig_stamps[3 * 8 * 8];
+extern "C" int pv_convbig_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pv_convbig_stamps), sizeof(pv_convbig_stamps)); }
+#define CB_DECL unsigned long long cb_acc[4] = {0, 0, 0, 0}, cb_t = __builtin_amdgcn_s_memtime(), cb_u, cb_r0 = __builtin_amdgcn_s_memrealtime(), cb_c0 = cb_t; int cb_n = 0;
+#define CB_MARK(i) do { cb_u = __builtin_amdgcn_s_memtime(); cb_acc[i] += cb_u - cb_t; cb_t = cb_u; } while (0)
+#define CB_COUNT() (++cb_n)
+#define CB_DUMP() do { const int slot_ = blockIdx.x == 0 ? 0 : blockIdx.x == 50 ? 1 : blockIdx.x == 100 ? 2 : -1; \
+        if (slot_ >= 0 && lane == 0) { unsigned long long* o_ = pv_convbig_stamps + (slot_ * 8 + wave) * 8; \
+            o_[0] = cb_acc[0]; o_[1] = cb_acc[1]; o_[2] = cb_acc[2]; o_[3] = cb_acc[3]; o_[4] = cb_t - cb_c0; o_[5] = __builtin_amdgcn_s_memrealtime() - cb_r0; o_[6] = cb_n; } } while (0)
+#else
+#define CB_DECL
+#define CB_MARK(i)
+#define CB_COUNT()
+#define CB_DUMP()
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -49,6 +70,11 @@ struct BigCfg {
     static constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 36 KiB / 32 KiB
     static constexpr int SMEM_BYTES = NBUF * STAGE_BYTES;   // 144 KiB / 128 KiB: one workgroup per CU either way
+    // PATCH modes (3x3 conv with the LDS-resident input patch): the ring holds weight stages only, the activations of a 32-channel chunk live in one
+    // of two patch buffers of 32 LDS-DMA pieces (512 pixel rows of 64 B; (R + 2) x (W + 2) <= 396 of them are the patch)
+    static constexpr int PATCH_PIECES = 32;
+    static constexpr int PATCH_BYTES = PATCH_PIECES * 16 * ROW_BYTES;                   // 32 KiB
+    static constexpr int SMEM_PATCH_BYTES = NBUF * B_BYTES + 2 * PATCH_BYTES;           // 80 + 64 = 144 KiB
 };
 
 __device__ __forceinline__ float epi_act(float x, int act) {
@@ -82,8 +108,18 @@ struct IC { static constexpr int value = V; };
 template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_dev p, const int tiles_n, const int nblk) {
     constexpr int NF = MODE == 2 ? 4 : 5;
-    constexpr int TAPS = MODE == 0 ? 9 : 1;
+    // MODE 3 / 4: the 3x3 conv (stride 1, pad 1, one image row = 64 / 32 pixels) with the LDS-RESIDENT INPUT PATCH: the tile's 256 output pixels are
+    // R = 4 / 8 whole image rows; per 32-channel chunk the (R + 2) x (W + 2) input pixels they read are staged ONCE (25 KiB at W = 64) and the nine
+    // taps read them at shifted addresses, instead of gathering the shifted 256 rows once per tap (9 x 16 KiB).  L2 -> LDS bytes per chunk:
+    // 25 + 9 x 20 = 205 KiB instead of 9 x 36 = 324 KiB, LDS-DMA instructions per stage and wave 2.9 instead of 4.5.  K order: 32-channel chunk
+    // major, tap minor (the 128-row kernel: 64-channel chunk major) - NOT bit-identical to it.
+    constexpr bool PATCH = MODE >= 3;
+    constexpr bool IS_CONV = MODE == 0 || PATCH;
+    constexpr int LOG2W = MODE == 3 ? 6 : 5, PW = 1 << LOG2W, PR = 256 >> LOG2W, PS = PW + 2, NPIX = (PR + 2) * PS;
+    constexpr int TAPS = IS_CONV ? 9 : 1;
     using Cfg = BigCfg<MI, NF>;
+    static_assert(!PATCH || (MI == 8 && !UPS && !LN), "the patch modes are the plain 256-row conv");
+    static_assert(NPIX <= Cfg::PATCH_PIECES * 16, "the patch fits its 32 pieces");
     constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP, B_PIECES = Cfg::B_PIECES, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
     constexpr int P_HI = AP + BP, P_LO = AP + Cfg::BP_LO;      // LDS-DMA instructions per stage of a wave 0-3 / 4-7
     static_assert(!UPS || MODE == 0, "the upsampling gather belongs to the conv");
@@ -102,99 +138,9 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     const int kb = (int)blockIdx.y * nk_per;
     const int ns = 2 * max(0, min(nk64, kb + nk_per) - kb);   // stages of this workgroup: two per (64-channel chunk, tap); stage index s is relative to kb
 
-    // ---- staging geometry: stride 1, pad 1; UPS: the logical input is the x2 nearest upsample of (hin, win), i.e. tap (ky, kx) of output
-    // pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1) - relative to the centre's source pixel (y >> 1, x >> 1) that is
-    // a row step of -1 / 0 (even y) or 0 / +1 (odd y) for ky = 0 / 2, likewise in x: the per-lane offset is the centre's plus two selects ----
-    const int prow = lane >> 2;                      // row inside a 16-row piece
-    const int lane_cc2 = ((lane & 3) ^ swz((lane >> 4) & 3)) * 16;   // swizzled source chunk: byte offset inside the 32-channel slab
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int hw_out = p.hout * p.wout;
-    unsigned a_off0[AP], a_off1[AP], a_mask[AP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int m = m0 + (wave + i * NW) * 16 + prow;
-        const bool ok = m < p.M;
-        if (MODE != 0) {                               // Linear (single source): the row itself, or out of range past M; no masks, no second source
-            a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
-            a_off1[i] = a_mask[i] = 0;
-            continue;
-        }
-        const int b = m / hw_out;
-        const int rem = m - b * hw_out;
-        const int y = rem / p.wout, x = rem - y * p.wout;
-        const int hl = UPS ? 2 * p.hin : p.hin, wl = UPS ? 2 * p.win : p.win;       // logical input extent
-        unsigned mask = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            mask |= (ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl) ? 1u << t : 0u;
-        }
-        if (UPS) mask |= (unsigned)(y & 1) << 9 | (unsigned)(x & 1) << 10;          // parities select the tap's source step
-        a_mask[i] = mask;
-        const unsigned pix = UPS ? (unsigned)((b * p.hin + (y >> 1)) * p.win + (x >> 1)) : (unsigned)((b * p.hin + y) * p.win + x);
-        a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
-        a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
-    }
-    unsigned w_off[BP];
-#pragma unroll
-    for (int i = 0; i < BP; ++i) w_off[i] = (unsigned)(n0 + min(wave + i * NW, B_PIECES - 1) * 16 + prow) * (unsigned)(K * 2) + lane_cc2;
-    const bool b_full = wave + (BP - 1) * NW < B_PIECES;          // 320-column tile: waves 0-3 (wm == 0) issue a third weight piece
-
-    // K position of a stage: s -> (64-channel chunk, filter tap, 32-deep half), advanced incrementally in the loop (the closed form costs
-    // two divisions by constants = a dozen dependent scalar multiplies per stage in front of every LDS-DMA issue)
-    struct KPos { int s, chunk, tap, ky, kx; };
-    auto kpos_of = [&](int s) {
-        const int g = kb + (s >> 1), chunk = g / TAPS, tap = g - chunk * TAPS, ky = TAPS == 9 ? tap / 3 : 1;
-        return KPos{s, chunk, tap, ky, TAPS == 9 ? tap - ky * 3 : 1};      // Linear: the "centre tap" (ky, kx) = (1, 1): no pixel shift
-    };
-    auto kpos_next = [&](KPos& k) {
-        if (k.s & 1) {                                 // second half done: next tap (kx fastest), then next chunk
-            if (TAPS == 9) {
-                ++k.tap; ++k.kx;
-                if (k.kx == 3) { k.kx = 0; ++k.ky; }
-                if (k.tap == 9) { k.tap = 0; k.ky = 0; ++k.chunk; }
-            } else {
-                ++k.chunk;
-            }
-        }
-        ++k.s;
-    };
-    // pieces [J0, J1) of the stage at K position k into buffer k.s & 3; piece j < AP: activation piece j, else weight piece j - AP
-    auto issue = [&](const KPos& k, auto j0c, auto j1c) {
-        constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-        char* sa = smem + (k.s & (NBUF - 1)) * STAGE_BYTES;
-        char* sb = sa + A_BYTES;
-        const int c = k.chunk * 64 + (k.s & 1) * BK;
-        const bool first = c < p.c0;
-        const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
-        const int ld2 = (first ? p.lda0 : p.lda1) * 2;
-        const int sc2 = (first ? c : c - p.c0) * 2;
-        const int tap_delta = ((k.ky - 1) * p.win + (k.kx - 1)) * ld2 + sc2;
-        // UPS: source step of this tap for even / odd output coordinates
-        const int oy_even = (k.ky == 0 ? -p.win : 0) * ld2, oy_odd = (k.ky == 2 ? p.win : 0) * ld2;
-        const int ox_even = (k.kx == 0 ? -1 : 0) * ld2, ox_odd = (k.kx == 2 ? 1 : 0) * ld2;
-        const unsigned wk2 = (unsigned)(k.tap * cin + c) * 2u;
-        const unsigned tap_bit = 1u << k.tap;
-#pragma unroll
-        for (int j = J0; j < J1; ++j) {
-            if (j < AP && MODE != 0) {
-                const unsigned off = a_off0[j] == OOB ? OOB : a_off0[j] + (unsigned)(c * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
-            } else if (j < AP) {
-                unsigned off = first ? a_off0[j] : a_off1[j];
-                if (UPS) off += (unsigned)(((a_mask[j] >> 9) & 1u ? oy_odd : oy_even) + ((a_mask[j] >> 10) & 1u ? ox_odd : ox_even) + sc2);
-                else off += (unsigned)tap_delta;
-                off = (a_mask[j] & tap_bit) ? off : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
-            } else if (j - AP < BP - 1 || b_full) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + (j - AP) * NW) * 16 * ROW_BYTES), 16, (int)(w_off[j - AP] + wk2), 0, 0, 0);
-            }
-        }
-    };
-
+    const int prow = lane >> 2;                      // row inside a 16-row piece
     float4_t acc[NF][MI];
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni)
@@ -211,65 +157,312 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     float ln_s1[LN ? MI : 1], ln_s2[LN ? MI : 1];
 #pragma unroll
     for (int mi = 0; mi < (LN ? MI : 1); ++mi) ln_s1[mi] = ln_s2[mi] = 0.f;
-    auto read_frags = [&](int s) {                   // all 13 fragments of stage s: 5 column (W) + 8 row (A)
-        const char* sa = smem + (s & (NBUF - 1)) * STAGE_BYTES + wm * (MI * 16) * ROW_BYTES + frag_off;
-        const char* sb = smem + (s & (NBUF - 1)) * STAGE_BYTES + A_BYTES + wn * (NF * 16) * ROW_BYTES + frag_off;
-#pragma unroll
-        for (int ni = 0; ni < NF; ++ni) wb[ni] = *reinterpret_cast<const half8_t*>(sb + ni * 16 * ROW_BYTES);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const half8_t*>(sa + mi * 16 * ROW_BYTES);
-    };
     auto seg_barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // "stage s+1 landed" <=> at most the pieces of the two younger issued stages (s+2, s+3) are outstanding.  A wave counts its own pieces:
-    // P_HI per stage for waves 0-3 (wm == 0), P_LO for waves 4-7 (320-column tile: 5 / 4).  The last stages (nothing younger in flight) drain fully.
-    // ---- prologue: stages 0, 1, 2 (the LOAD segment of stage s issues stage s+3) ----
-    {
-        const int pre = min(ns, 3);
-        for (int s = 0; s < pre; ++s) issue(kpos_of(s), IC<0>{}, IC<AP + BP>{});
-        if (pre == 3) { if (wm == 0) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<2 * P_LO>(); }   // stage 0 landed
-        else wait_vmcnt<0>();
-    }
-    seg_barrier();
-    if (wm == 1) seg_barrier();                      // the stagger: waves 4-7 run one barrier interval behind waves 0-3
-
-    KPos kn = kpos_of(3);                            // the stage the next LOAD segment issues
-    for (int s = 0; s < ns; ++s) {
-        // ---- LOAD(s): waves 0-3 in interval 2s, waves 4-7 in interval 2s+1 (after which buffer s & 3 is free: stage s+4 goes there) ----
-        read_frags(s);
-        if (s + 3 < ns) issue(kn, IC<0>{}, IC<AP + BP>{});
-        kpos_next(kn);
-        if (wm == 1) {                                           // waves 4-7: interval 2s+1 is the one in front of waves 0-3's LOAD(s+1)
-            if (s + 3 < ns) wait_vmcnt<2 * P_LO>(); else wait_vmcnt<0>();
+    if constexpr (!PATCH) {
+        // ---- staging geometry: stride 1, pad 1; UPS: the logical input is the x2 nearest upsample of (hin, win), i.e. tap (ky, kx) of output
+        // pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1) - relative to the centre's source pixel (y >> 1, x >> 1) that is
+        // a row step of -1 / 0 (even y) or 0 / +1 (odd y) for ky = 0 / 2, likewise in x: the per-lane offset is the centre's plus two selects ----
+        const int lane_cc2 = ((lane & 3) ^ swz((lane >> 4) & 3)) * 16;   // swizzled source chunk: byte offset inside the 32-channel slab
+        const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+        unsigned a_off0[AP], a_off1[AP], a_mask[AP];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int m = m0 + (wave + i * NW) * 16 + prow;
+            const bool ok = m < p.M;
+            if (MODE != 0) {                               // Linear (single source): the row itself, or out of range past M; no masks, no second source
+                a_off0[i] = ok ? (unsigned)m * (unsigned)(p.lda0 * 2) + lane_cc2 : OOB;
+                a_off1[i] = a_mask[i] = 0;
+                continue;
+            }
+            const int b = m / hw_out;
+            const int rem = m - b * hw_out;
+            const int y = rem / p.wout, x = rem - y * p.wout;
+            const int hl = UPS ? 2 * p.hin : p.hin, wl = UPS ? 2 * p.win : p.win;       // logical input extent
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                mask |= (ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl) ? 1u << t : 0u;
+            }
+            if (UPS) mask |= (unsigned)(y & 1) << 9 | (unsigned)(x & 1) << 10;          // parities select the tap's source step
+            a_mask[i] = mask;
+            const unsigned pix = UPS ? (unsigned)((b * p.hin + (y >> 1)) * p.win + (x >> 1)) : (unsigned)((b * p.hin + y) * p.win + x);
+            a_off0[i] = pix * (unsigned)(p.lda0 * 2) + lane_cc2;
+            a_off1[i] = pix * (unsigned)(p.lda1 * 2) + lane_cc2;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers BEFORE the barrier: the buffer's reads are retired when it is refilled
-        seg_barrier();
-        // ---- MFMA(s): 40 MFMAs (LN: + the row sums of the fragments, 8 v_dot2 per fragment) ----
+        unsigned w_off[BP];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < NF; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
-            if constexpr (LN) {
-                const half2_t one2 = half2_t{(half_t)1.0f, (half_t)1.0f};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const half2_t x2 = half2_t{xa[mi][2 * j], xa[mi][2 * j + 1]};
-                    ln_s1[mi] = __builtin_amdgcn_fdot2(x2, one2, ln_s1[mi], false);
-                    ln_s2[mi] = __builtin_amdgcn_fdot2(x2, x2, ln_s2[mi], false);
+        for (int i = 0; i < BP; ++i) w_off[i] = (unsigned)(n0 + min(wave + i * NW, B_PIECES - 1) * 16 + prow) * (unsigned)(K * 2) + lane_cc2;
+        const bool b_full = wave + (BP - 1) * NW < B_PIECES;          // 320-column tile: waves 0-3 (wm == 0) issue a third weight piece
+
+        // K position of a stage: s -> (64-channel chunk, filter tap, 32-deep half), advanced incrementally in the loop (the closed form costs
+        // two divisions by constants = a dozen dependent scalar multiplies per stage in front of every LDS-DMA issue)
+        struct KPos { int s, chunk, tap, ky, kx; };
+        auto kpos_of = [&](int s) {
+            const int g = kb + (s >> 1), chunk = g / TAPS, tap = g - chunk * TAPS, ky = TAPS == 9 ? tap / 3 : 1;
+            return KPos{s, chunk, tap, ky, TAPS == 9 ? tap - ky * 3 : 1};      // Linear: the "centre tap" (ky, kx) = (1, 1): no pixel shift
+        };
+        auto kpos_next = [&](KPos& k) {
+            if (k.s & 1) {                                 // second half done: next tap (kx fastest), then next chunk
+                if (TAPS == 9) {
+                    ++k.tap; ++k.kx;
+                    if (k.kx == 3) { k.kx = 0; ++k.ky; }
+                    if (k.tap == 9) { k.tap = 0; k.ky = 0; ++k.chunk; }
+                } else {
+                    ++k.chunk;
                 }
             }
-        }
-        if (wm == 0) {                                           // waves 0-3: stage s+1 is read right behind the next barrier
-            if (s + 3 < ns) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<0>();
+            ++k.s;
+        };
+        // pieces [J0, J1) of the stage at K position k into buffer k.s & 3; piece j < AP: activation piece j, else weight piece j - AP
+        auto issue = [&](const KPos& k, auto j0c, auto j1c) {
+            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+            char* sa = smem + (k.s & (NBUF - 1)) * STAGE_BYTES;
+            char* sb = sa + A_BYTES;
+            const int c = k.chunk * 64 + (k.s & 1) * BK;
+            const bool first = c < p.c0;
+            const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
+            const int ld2 = (first ? p.lda0 : p.lda1) * 2;
+            const int sc2 = (first ? c : c - p.c0) * 2;
+            const int tap_delta = ((k.ky - 1) * p.win + (k.kx - 1)) * ld2 + sc2;
+            // UPS: source step of this tap for even / odd output coordinates
+            const int oy_even = (k.ky == 0 ? -p.win : 0) * ld2, oy_odd = (k.ky == 2 ? p.win : 0) * ld2;
+            const int ox_even = (k.kx == 0 ? -1 : 0) * ld2, ox_odd = (k.kx == 2 ? 1 : 0) * ld2;
+            const unsigned wk2 = (unsigned)(k.tap * cin + c) * 2u;
+            const unsigned tap_bit = 1u << k.tap;
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                if (j < AP && MODE != 0) {
+                    const unsigned off = a_off0[j] == OOB ? OOB : a_off0[j] + (unsigned)(c * 2);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
+                } else if (j < AP) {
+                    unsigned off = first ? a_off0[j] : a_off1[j];
+                    if (UPS) off += (unsigned)(((a_mask[j] >> 9) & 1u ? oy_odd : oy_even) + ((a_mask[j] >> 10) & 1u ? ox_odd : ox_even) + sc2);
+                    else off += (unsigned)tap_delta;
+                    off = (a_mask[j] & tap_bit) ? off : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(sa + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)off, 0, 0, 0);
+                } else if (j - AP < BP - 1 || b_full) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + (j - AP) * NW) * 16 * ROW_BYTES), 16, (int)(w_off[j - AP] + wk2), 0, 0, 0);
+                }
+            }
+        };
+
+        auto read_frags = [&](int s) {                   // all 13 fragments of stage s: 5 column (W) + 8 row (A)
+            const char* sa = smem + (s & (NBUF - 1)) * STAGE_BYTES + wm * (MI * 16) * ROW_BYTES + frag_off;
+            const char* sb = smem + (s & (NBUF - 1)) * STAGE_BYTES + A_BYTES + wn * (NF * 16) * ROW_BYTES + frag_off;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) wb[ni] = *reinterpret_cast<const half8_t*>(sb + ni * 16 * ROW_BYTES);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const half8_t*>(sa + mi * 16 * ROW_BYTES);
+        };
+        // "stage s+1 landed" <=> at most the pieces of the two younger issued stages (s+2, s+3) are outstanding.  A wave counts its own pieces:
+        // P_HI per stage for waves 0-3 (wm == 0), P_LO for waves 4-7 (320-column tile: 5 / 4).  The last stages (nothing younger in flight) drain fully.
+        // ---- prologue: stages 0, 1, 2 (the LOAD segment of stage s issues stage s+3) ----
+        {
+            const int pre = min(ns, 3);
+            for (int s = 0; s < pre; ++s) issue(kpos_of(s), IC<0>{}, IC<AP + BP>{});
+            if (pre == 3) { if (wm == 0) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<2 * P_LO>(); }   // stage 0 landed
+            else wait_vmcnt<0>();
         }
         seg_barrier();
+        if (wm == 1) seg_barrier();                      // the stagger: waves 4-7 run one barrier interval behind waves 0-3
+
+        KPos kn = kpos_of(3);                            // the stage the next LOAD segment issues
+        CB_DECL
+        for (int s = 0; s < ns; ++s) {
+            CB_COUNT();
+            // ---- LOAD(s): waves 0-3 in interval 2s, waves 4-7 in interval 2s+1 (after which buffer s & 3 is free: stage s+4 goes there) ----
+            read_frags(s);
+            if (s + 3 < ns) issue(kn, IC<0>{}, IC<AP + BP>{});
+            kpos_next(kn);
+            if (wm == 1) {                                           // waves 4-7: interval 2s+1 is the one in front of waves 0-3's LOAD(s+1)
+                if (s + 3 < ns) wait_vmcnt<2 * P_LO>(); else wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers BEFORE the barrier: the buffer's reads are retired when it is refilled
+            CB_MARK(0);
+            seg_barrier();
+            CB_MARK(1);
+            // ---- MFMA(s): 40 MFMAs (LN: + the row sums of the fragments, 8 v_dot2 per fragment) ----
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+                if constexpr (LN) {
+                    const half2_t one2 = half2_t{(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const half2_t x2 = half2_t{xa[mi][2 * j], xa[mi][2 * j + 1]};
+                        ln_s1[mi] = __builtin_amdgcn_fdot2(x2, one2, ln_s1[mi], false);
+                        ln_s2[mi] = __builtin_amdgcn_fdot2(x2, x2, ln_s2[mi], false);
+                    }
+                }
+            }
+            if (wm == 0) {                                           // waves 0-3: stage s+1 is read right behind the next barrier
+                if (s + 3 < ns) wait_vmcnt<2 * P_HI>(); else wait_vmcnt<0>();
+            }
+            CB_MARK(2);
+            seg_barrier();
+            CB_MARK(3);
+        }
+        CB_DUMP();
+        if (wm == 0) seg_barrier();                      // waves 0-3 execute as many barriers as waves 4-7
+
+    } else {
+        // ================= 3x3 conv with the LDS-resident input patch (MODE 3: 64-pixel image rows, MODE 4: 32) =================
+        constexpr int B_BYTES = Cfg::B_BYTES, PATCH_BYTES = Cfg::PATCH_BYTES;
+        constexpr int PB_HI = BP, PB_LO = Cfg::BP_LO;              // weight pieces per stage: waves 0-3 / 4-7
+        char* const s_patch = smem + NBUF * B_BYTES;
+        const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a0), 0, (int)p.a0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a1 ? p.a1 : p.a0), 0, (int)p.a1_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+        const int nchunk = cin / BK;                                // 32-channel chunks; stage s = chunk * 9 + tap
+        const int nst = 9 * nchunk;
+        // the tile = PR whole image rows of one image: rows y0 .. y0 + PR - 1; patch pixel (py, px) = image pixel (y0 - 1 + py, px - 1)
+        const int img = m0 / hw_out, y0 = (m0 - img * hw_out) >> LOG2W;
+        // LDS image of a patch buffer: [pixel][64 B], the 16-B chunk of pixel pp at position chunk ^ (2 * ((pp >> 2) & 1)).  This swizzle (period two
+        // pixel quads) keeps a ds_read_b128 fragment of 16 CONSECUTIVE pixels conflict-free at ANY pixel alignment - the taps shift the fragment by
+        // kx + ky * (W + 2) pixels; the F swizzle of the gathered image above is conflict-free at multiples of 16 only.
+        unsigned ppix[4];                                           // this lane's pixel in patch pieces wave, wave + 8, wave + 16, wave + 24
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = 16 * (wave + 8 * i) + prow;
+            const int py = pp / PS, px = pp - py * PS;
+            const int iy = y0 - 1 + py, ix = px - 1;
+            const bool ok = pp < NPIX && iy >= 0 && iy < p.hin && ix >= 0 && ix < PW;
+            ppix[i] = ok ? (unsigned)((img * p.hin + iy) * PW + ix) : OOB;
+        }
+        const unsigned patch_cc = (unsigned)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16);     // (pp >> 2) & 1 == (lane >> 4) & 1: pieces start at multiples of 16
+        const int lane_cc2 = ((lane & 3) ^ swz((lane >> 4) & 3)) * 16;                        // weight pieces: the F swizzle, as above
+        // weight piece wave + 8 j of a stage: ONE per-lane offset (piece `wave`); the piece step (128 weight rows) and the stage's K position ride in the
+        // SCALAR offset - per-lane offsets per piece and tap would be loop invariants that hipcc hoists and then spills next to the 160 accumulators
+        const unsigned w_off = (unsigned)(n0 + wave * 16 + prow) * (unsigned)(K * 2) + lane_cc2;
+        const int w_piece_step = NW * 16 * K * 2;
+        const bool b_full = wave + (BP - 1) * NW < B_PIECES;
+        auto issue_w = [&](int s, int chunk, int tap) {            // the weight stage of (chunk, tap) into ring buffer s & 3
+            char* sb = smem + (s & (NBUF - 1)) * B_BYTES;
+            const int wk2 = (tap * cin + chunk * BK) * 2;
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+                if (j < BP - 1 || b_full)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, PV_LDS_PTR(sb + (wave + j * NW) * 16 * ROW_BYTES), 16, (int)w_off, wk2 + j * w_piece_step, 0, 0);
+        };
+        // (loop invariants pinned in scalar registers: left to itself hipcc re-loads them from the kernel arguments inside the loop, and the
+        // s_waitcnt lgkmcnt(0) in front of their first use also waits for the thirteen fragment reads in flight)
+        int ld2_0 = p.lda0 * 2, ld2_1 = p.lda1 * 2, c0s = p.c0;
+        asm volatile("" : "+s"(ld2_0), "+s"(ld2_1), "+s"(c0s));
+        // piece wave + 8 i of the patch of a chunk.  The pixel of piece i is taken from ppix[0] and the four registers ROTATE (five v_mov): selecting
+        // ppix[i] by the wave-uniform tap compiles to a chain of eight scalar branches, ~400 cycles per piece (ablation: profiles/r05_conv_patch_ablate.txt)
+        auto issue_patch = [&](int chunk, int i) {
+            const int c = chunk * BK;
+            const bool first = c < c0s;
+            const unsigned ld2 = (unsigned)(first ? ld2_0 : ld2_1), sc2 = (unsigned)(first ? c : c - c0s) * 2u;
+            const unsigned px = ppix[0];
+            ppix[0] = ppix[1]; ppix[1] = ppix[2]; ppix[2] = ppix[3]; ppix[3] = px;
+            const unsigned off = px == OOB ? OOB : px * ld2 + sc2 + patch_cc;
+            char* dst = s_patch + (chunk & 1) * PATCH_BYTES + (wave + 8 * i) * 16 * ROW_BYTES;
+            const __amdgpu_buffer_rsrc_t ra = first ? ra0 : ra1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, PV_LDS_PTR(dst), 16, (int)off, 0, 0, 0);
+        };
+        // A fragment mi of this wave = 16 consecutive output pixels of ONE image row: row (wm * 128 + mi * 16) >> LOG2W of the tile, x0 = (mi * 16) & (W - 1);
+        // at tap (ky, kx) lane fr reads patch pixel (row + ky) * PS + x0 + fr + kx, 16-B chunk fq
+        const int lane_pp = (wm * (128 >> LOG2W)) * PS + fr;
+        // the wave's 128 rows = NROW image rows; the fragments of one image row are 16 pixels = 1 KiB apart and share the swizzle bit
+        // (a step of 16 pixels keeps (pp >> 2) & 1): ONE address per image row, the rest are ds_read immediates
+        constexpr int NROW = (MI * 16) >> LOG2W, FPR = PW / 16;    // image rows per wave, fragments per image row
+        unsigned a_row[NROW];                                       // byte addresses of the NEXT stage's A fragments (computed under the MFMAs)
+        auto frag_addrs = [&](int chunk, int tapshift) {           // tapshift = ky * PS + kx
+            const int base = lane_pp + tapshift;
+            const unsigned buf = (unsigned)(NBUF * B_BYTES + (chunk & 1) * PATCH_BYTES);
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+                const int pp = base + r * PS;
+                a_row[r] = buf + (unsigned)pp * ROW_BYTES + (unsigned)((fq ^ ((pp >> 1) & 2)) << 4);
+            }
+        };
+        auto read_frags_p = [&](int s) {
+            const char* sb = smem + (s & (NBUF - 1)) * B_BYTES + wn * (NF * 16) * ROW_BYTES + frag_off;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) wb[ni] = *reinterpret_cast<const half8_t*>(sb + ni * 16 * ROW_BYTES);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const half8_t*>(smem + a_row[mi / FPR] + (mi % FPR) * 16 * ROW_BYTES);
+        };
+        // ---- prologue: the first chunk's patch (all four pieces), weight stages 0, 1, 2 (taps 0-2 of chunk 0: a conv has >= 9 stages) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_patch(0, i);
+        for (int s = 0; s < 3; ++s) issue_w(s, 0, s);
+        if (wm == 0) wait_vmcnt<2 * PB_HI>(); else wait_vmcnt<2 * PB_LO>();       // patch 0 and stage 0 landed
+        frag_addrs(0, 0);
+        seg_barrier();
+        if (wm == 1) seg_barrier();                                 // the stagger: waves 4-7 one interval behind
+
+        // vmcnt bookkeeping: LOAD(s) issues the weight stage s + 3 and THEN, in the first four taps of a chunk, one piece of the NEXT chunk's patch (a patch
+        // buffer is free once the late half finished LOAD of the previous chunk's last tap, i.e. before anybody's LOAD of this chunk's first tap).  "weight
+        // stage s + 1 landed" <=> at most the pieces issued in LOAD(s) and LOAD(s - 1) are outstanding
+        // (the wait is for 2 PB outstanding whatever rode along - up to three patch pieces too many have to land: choosing the exact immediate by
+        // e(s) + e(s - 1) + e(s - 2) costs a chain of scalar branches per stage, ~150 cycles, more than the patch pieces' early landing)
+        int chunk = 0, tap = 0, kx = 0, tapshift = 0;               // K position of stage s: tapshift = ky * PS + kx
+        int c3 = 0, t3 = 3;                                         // ... and of stage s + 3
+        CB_DECL
+        for (int s = 0; s < nst; ++s) {
+            CB_COUNT();
+            // ---- LOAD(s) ----
+            read_frags_p(s);
+#if PV_PATCH_ABLATE == 2
+            const int e_now = 0;
+#else
+            const int e_now = (tap < 4 && chunk + 1 < nchunk) ? 1 : 0;
+#endif
+            if (s + 3 < nst) issue_w(s + 3, c3, t3);
+            if (e_now) issue_patch(chunk + 1, tap);
+            if (++t3 == 9) { t3 = 0; ++c3; }
+            if (wm == 1) {
+                if (s + 3 < nst) wait_vmcnt<2 * PB_LO>(); else wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            CB_MARK(0);
+            seg_barrier();
+            CB_MARK(1);
+            // ---- MFMA(s): 40 MFMAs; the next stage's fragment addresses ride in their shadow ----
+            ++tap; ++kx; ++tapshift;
+            if (kx == 3) { kx = 0; tapshift += PS - 3; }
+            if (tap == 9) { tap = 0; tapshift = 0; ++chunk; }
+#if PV_PATCH_ABLATE != 1
+            frag_addrs(chunk, tapshift);
+#endif
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) asm volatile("" : "+v"(a_row[r]));      // computed HERE (hipcc sinks them behind the vmcnt branches below)
+            // the address arithmetic and the K-position bookkeeping go BETWEEN the MFMAs (an MFMA holds the issue port 8 cycles in 16): left to
+            // itself hipcc puts them behind the fortieth MFMA, where they lengthen the segment by what they cost (stamps: +150 cycles)
+#if PV_PATCH_ABLATE != 4
+#pragma unroll
+            for (int g = 0; g < MI; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+            }
+#endif
+            if (wm == 0) {
+                if (s + 3 < nst) wait_vmcnt<2 * PB_HI>(); else wait_vmcnt<0>();
+            }
+            CB_MARK(2);
+            seg_barrier();
+            CB_MARK(3);
+        }
+        CB_DUMP();
+        if (wm == 0) seg_barrier();
     }
-    if (wm == 0) seg_barrier();                      // waves 0-3 execute as many barriers as waves 4-7
 
     const int nbase = n0 + wn * (NF * 16) + fq * 4;
     if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators into this split's slab
@@ -351,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
             s_bias[i] = p.bias ? p.bias[n0 + i] : 0.f;
             if (LN) s_rs[i] = p.ln_rowsum[n0 + i];
         }
-        if (MODE == 0 && p.rowadd) {
+        if (IS_CONV && p.rowadd) {
             for (int i = tid; i < 2 * (MI / 4) * BN; i += NW * 64) {
                 const int blk = i / BN, c = i - blk * BN;
                 const int img = min(m0 + blk * 64, p.M - 1) / hw_out;
@@ -368,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
         // time-embedding row: one per IMAGE.  When the block's 64 rows lie inside one image (always, for hw_out % 64 == 0) it is the staged one
         // (added AFTER the bias, per element, as pv_gemm.hip does: the results stay bit-identical)
         const int mb0 = m0 + wm * (MI * 16) + hb * 64;
-        const bool one_image = MODE == 0 && p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);   // (the Linear modes keep the per-row form: no UNet Linear has a row term)
+        const bool one_image = IS_CONV && p.rowadd && (mb0 / hw_out) == (min(mb0 + 63, p.M - 1) / hw_out);   // (the Linear modes keep the per-row form: no UNet Linear has a row term)
         const float* s_ra = s_radd + (wm * (MI / 4) + hb) * BN + ncol;
         constexpr int RBUF = CS ? 1 : 2;               // residual rows: one in use (+ one in flight, unless the 40 statistics registers are live too)
         half4_t res[RBUF][NF];
@@ -395,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
                 float4_t v = acc[t][mi];
                 if constexpr (LN) v = ln_fold(v, *reinterpret_cast<const float4_t*>(s_rs + ncol + t * 16), mi);
                 v += *reinterpret_cast<const float4_t*>(s_bias + ncol + t * 16);
-                if (MODE == 0 && one_image) v += *reinterpret_cast<const float4_t*>(s_ra + t * 16);
+                if (IS_CONV && one_image) v += *reinterpret_cast<const float4_t*>(s_ra + t * 16);
                 else if (radd) v += *reinterpret_cast<const float4_t*>(radd + t * 16);
                 if (p.act) {
 #pragma unroll
@@ -462,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
 template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = BigCfg<MI, MODE == 2 ? 4 : 5>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = Cfg::SMEM_BYTES;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = MODE >= 3 ? Cfg::SMEM_PATCH_BYTES : Cfg::SMEM_BYTES;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -518,6 +711,16 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / BN) * splits;
     if (tiles256 < min_tiles) return -1;
     const bool cs = p.colstats && splits == 1;                  // with split-K the reduce launch produces the column statistics
+    // the LDS-resident input patch (MODE 3 / 4): whole 64- / 32-pixel image rows per tile, no split-K; PV_CONV_PATCH=0 keeps the gathered form
+    // PV_CONV_PATCH: 0 never; 64 (default) the 64-pixel-row form only; 1 the 32-pixel-row form too.  Same box, sustained: the 64 x 64 convs 3.7 - 5.3 %
+    // faster than the gathered form; the 32 x 32 convs (128 half-chip workgroups) 4 - 6 % slower alone and level in the loop (profiles/r05_conv_patch_*.txt)
+    const char* penv = getenv("PV_CONV_PATCH");
+    const int pmode = penv ? atoi(penv) : 64;
+    if (pmode != 0 && !p.upsample && splits == 1 && (p.wout == 64 || (p.wout == 32 && pmode != 64)) && ((p.hout * p.wout) % 256) == 0 && (p.M % 256) == 0 &&
+        (p.c0 % 32) == 0 && (cin % 32) == 0) {
+        if (p.wout == 64) return cs ? launch_big<true, false, 8, 3>(p, stream) : launch_big<false, false, 8, 3>(p, stream);
+        return cs ? launch_big<true, false, 8, 4>(p, stream) : launch_big<false, false, 8, 4>(p, stream);
+    }
     if (p.upsample) return cs ? launch_big<true, true, 8, 0>(p, stream) : launch_big<false, true, 8, 0>(p, stream);
     return cs ? launch_big<true, false, 8, 0>(p, stream) : launch_big<false, false, 8, 0>(p, stream);
 }

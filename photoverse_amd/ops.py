@@ -239,7 +239,12 @@ class Recorder:
         # pv_convbig.hip's 256-row tile (pv_conv_big_launch's rules): 3x3 convs, and Linear layers with K >= 640 (GEGLU: 256-column tiles)
         if big_shape and not (out_f32 and splitk == 1) and (splitk == 1 or (kdim // 64) // splitk >= 8):
             if tiles256 * splitk >= big_min:
-                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, 0, false>"
+                # MODE 3 / 4: the LDS-resident input patch (pv_conv_big_launch's rule: whole 64- / 32-pixel image rows per tile, no split-K, no upsampling)
+                pmode = int(os.environ.get("PV_CONV_PATCH", "64"))      # 0: never; 64 (default): the 64-pixel-row form only; 1: the 32-pixel-row form too
+                patch = (pmode != 0 and not geo[6] and splitk == 1 and (geo[4] == 64 or (geo[4] == 32 and pmode != 64)) and (geo[3] * geo[4]) % 256 == 0
+                         and M % 256 == 0 and c0 % 32 == 0 and (c0 + c1) % 32 == 0)
+                mode = (3 if geo[4] == 64 else 4) if patch else 0
+                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, {mode}, false>"
         bn_big = 256 if geglu else 320
         if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
                 and N % bn_big == 0 and not (geglu and cs is not None) and ((M + 255) // 256) * (N // bn_big) >= big_min):
@@ -312,7 +317,17 @@ class Recorder:
         ldo, _ = _rows(out)
         p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal), _ptr(lse))
         self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
-        self._add(self.lib.pv_attention, p, tag=("pv_attention", 4.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (2 * nq + 2 * nk)))
+        # the symbol rocprof shows for this launch (pv_attn.hip: launch_attn's rule), and its workgroup count
+        wg512, wg256 = ((nq + 511) // 512) * heads * batch, ((nq + 255) // 256) * heads * batch
+        var8 = int(os.environ.get("PV_ATTN8", "225"))
+        if d == 40 and not os.environ.get("PV_ATTN_NO_DMA") and var8 >= 0 and not causal and wg512 >= int(os.environ.get("PV_ATTN8_MIN", "256")):
+            name, wgs = f"attn8_kernel<{var8}>", wg512
+        elif d == 40:
+            four = wg256 >= 1024
+            name, wgs = f"attn_kernel<40, {4 if four else 2}, {'false' if os.environ.get('PV_ATTN_NO_DMA') else 'true'}>", (wg256 if four else ((nq + 127) // 128) * heads * batch)
+        else:
+            name, wgs = f"attn_kernel<{d}, 2, false>", ((nq + 127) // 128) * heads * batch
+        self._add(self.lib.pv_attention, p, tag=(name, 4.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (2 * nq + 2 * nk), wgs))
         return out
 
     # ---- backward of the stock blocks the training gradient crosses (pv_train.hip) ----

@@ -280,6 +280,7 @@ def test_conv3x3_256x320_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeyp
     bias + time-embedding row + residual + SiLU epilogue, GroupNorm column statistics, and an M tail (one 24 x 24 image: 576 rows = 2.25 tiles, run on
     the big tile by lowering its minimum tile count)."""
     from photoverse_amd.ops import ACT_SILU
+    monkeypatch.setenv("PV_CONV_PATCH", "0")                 # the GATHERED form of the tile (the LDS-resident patch has its own K order: next test)
     x0 = h16(B, c0, h, h, seed=81)
     x1 = h16(B, c1, h, h, seed=82) if c1 else None
     w = h16(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5, seed=83)
@@ -313,6 +314,48 @@ def test_conv3x3_256x320_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeyp
     blk = outs["big"].float().view(-1, 64, cout)
     torch.testing.assert_close(stats["big"].view(-1, 2, cout)[:, 0], blk.sum(1), rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(stats["big"].view(-1, 2, cout)[:, 1], (blk * blk).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,h,extras,pmode", [(16, 320, 0, 320, 64, True, "64"), (16, 640, 320, 320, 64, False, "64"), (4, 64, 64, 640, 64, True, "64"),
+                                                          (16, 640, 0, 640, 32, True, "1"), (2, 64, 64, 320, 32, False, "1"), (1, 64, 0, 320, 64, True, "64")])
+def test_conv3x3_lds_resident_input_patch(rec_cls, monkeypatch, B, c0, c1, cout, h, extras, pmode):
+    """pv_convbig.hip MODE 3 / 4 (round 5): the tile's 256 output pixels are whole image rows, the (R + 2) x (W + 2) input pixels of a 32-channel chunk are
+    staged ONCE in LDS and the nine taps read them at shifted addresses (chunk ^ 2 * ((pixel >> 2) & 1): conflict-free at any pixel alignment) instead of
+    gathering 256 shifted rows per tap.  Against fp32 conv2d and against the gathered form of the same tile (same products, 32-channel-chunk-major K order:
+    equal to fp32 accumulation order, not to the bit): single / dual source, N = 320 / 640, image borders, bias + time-embedding row + residual + SiLU,
+    GroupNorm column statistics; W = 64 (default) and W = 32 (PV_CONV_PATCH=1); small launches are put on the tile by lowering its minimum tile count."""
+    from photoverse_amd.ops import ACT_SILU
+    x0 = h16(B, c0, h, h, seed=181)
+    x1 = h16(B, c1, h, h, seed=182) if c1 else None
+    w = h16(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5, seed=183)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(184))
+    temb = torch.randn(B, cout, generator=torch.Generator().manual_seed(185))
+    res = h16(B * h * h, cout, seed=186)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * h * h, -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    kw = dict(bias=bias.cuda(), conv=dict(batch=B, hin=h, win=h, hout=h, wout=h), colstats=True)
+    if extras:
+        kw.update(rowadd=temb.cuda(), rowadd_ld=cout, residual=res.cuda(), act=ACT_SILU)
+    outs, stats = {}, {}
+    for name, env in (("patch", pmode), ("gathered", "0")):
+        monkeypatch.setenv("PV_CONV_PATCH", env)             # read at record time (the tag) and at launch time (the kernel): set around both
+        rec = rec_cls("cuda")
+        rec.big_min = 1
+        outs[name] = rec.gemm(rows(x0), wp, a1=rows(x1) if c1 else None, **kw)
+        want_mode = (3 if h == 64 else 4) if name == "patch" else 0
+        assert rec.tags[-1][0] == f"big_tile_kernel<true, false, 8, {want_mode}, false>", rec.tags[-1]
+        stats[name] = rec.colstats.get((outs[name].data_ptr(), B * h * h, cout))
+        rec.run()
+        torch.cuda.synchronize()
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    ref = F.conv2d(xin, w.float(), bias, padding=1)
+    if extras:
+        ref = F.silu(ref + temb[:, :, None, None])
+    ref = ref.permute(0, 2, 3, 1).reshape(B * h * h, cout)
+    if extras:
+        ref = ref + res.float()
+    assert rel_l2(outs["patch"], ref) < 1e-3 and rel_l2(outs["gathered"], ref) < 1e-3
+    assert rel_l2(outs["patch"], outs["gathered"]) < 1e-4 and rel_l2(stats["patch"], stats["gathered"]) < 1e-4
 
 
 @pytest.mark.parametrize("c0,c1,hw,act", [(320, 0, 64 * 64, 1), (640, 320, 16 * 16, 1), (1280, 1280, 64, 0), (2560, 0, 64, 1), (64, 0, 25, 0)])
