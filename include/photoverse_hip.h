@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 14
+#define PV_ABI_VERSION 15
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -89,6 +89,13 @@ typedef struct pv_gemm_params {
     int32_t big_tile_min;  /* (ABI 12) 256-row-tile path (pv_convbig.hip): minimum number of 256-row tiles (x K slices) the launch must have to take it.
                               0 = library default (256 = one workgroup per CU; env PV_CONV_BIG overrides), < 0 = never.  A caller that runs two such
                               launches side by side on two streams (the uncond / cond forwards of a CFG step) passes 128: each fills half the chip. */
+    const float* a_norm;   /* (ABI 15) optional fp32 [batch][2][c0+c1]: per image and INPUT channel (a0's channels, then a1's) the scale and the shift of a
+                              GroupNorm over the conv's input, from pv_groupnorm_scale_shift.  Non-NULL = the launch computes conv( act_a( a * scale + shift ) ):
+                              [EXT] ResnetBlock2D.norm1 / norm2 + SiLU folded into conv1 / conv2 - the conv reads the RAW tensor(s), each input pixel is
+                              normalised once, in LDS, where the LDS-resident input patch of the 256-row tile holds it (zero padding stays zero), the same
+                              fp32 arithmetic and fp16 rounding as pv_groupnorm_apply: results equal the two-launch path bit for bit.  Only that path takes it
+                              (taps == 9, stride 1, no upsampling, 64- or 32-pixel image rows, no split-K): anything else returns hipErrorInvalidValue. */
+    int32_t a_norm_act;    /* PV_ACT_NONE or PV_ACT_SILU, applied after the affine part */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
 
@@ -117,6 +124,11 @@ int pv_groupnorm_stats(const pv_groupnorm_params* p, void* stream);
 /* same result as pv_groupnorm_stats, from the column statistics the producing GEMM epilogues left behind (no pass over x);
  * needs hw % 64 == 0, colstats0 (and colstats1 when c1 > 0); fixed reduction order */
 int pv_groupnorm_stats_from_colstats(const pv_groupnorm_params* p, void* stream);
+/* (ABI 15) the same statistics turned into the per-(image, channel) affine form a consumer can apply by itself:
+ * table[b][0][c] = gamma[c] * rstd(b, group(c)), table[b][1][c] = beta[c] - mean(b, group(c)) * table[b][0][c]   (fp32 [batch][2][c0+c1]),
+ * so that pv_groupnorm_apply's y = act(x * table[b][0][c] + table[b][1][c]) can be folded into the conv that follows (pv_gemm_params.a_norm).
+ * Needs what pv_groupnorm_stats_from_colstats needs; also leaves (mean, rstd) in partial like it.  Fixed reduction order. */
+int pv_groupnorm_scale_shift(const pv_groupnorm_params* p, float* table, void* stream);
 int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream);
 
 /* LayerNorm over the last dim of fp16 rows (BasicTransformerBlock.norm1-3, CLIP layer norms,

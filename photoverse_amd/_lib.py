@@ -19,7 +19,7 @@ class GemmParams(C.Structure):
                 ("ldr", c_int), ("out", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("taps", c_int),
                 ("batch", c_int), ("hin", c_int), ("win", c_int), ("hout", c_int), ("wout", c_int), ("stride", c_int),
                 ("upsample", c_int), ("pad", c_int), ("act", c_int), ("out_f32", c_int), ("geglu", c_int),
-                ("splitk", c_int), ("splitk_ws", c_void_p), ("colstats", c_void_p), ("ln_rowsum", c_void_p), ("ln_eps", c_float), ("big_tile_min", c_int)]
+                ("splitk", c_int), ("splitk_ws", c_void_p), ("colstats", c_void_p), ("ln_rowsum", c_void_p), ("ln_eps", c_float), ("big_tile_min", c_int), ("a_norm", c_void_p), ("a_norm_act", c_int)]
 
 
 class GroupNormParams(C.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "pv_gemm_conv": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "pv_groupnorm_stats": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
     "pv_groupnorm_stats_from_colstats": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
+    "pv_groupnorm_scale_shift": (c_int, [C.POINTER(GroupNormParams), c_void_p, c_void_p]),
     "pv_groupnorm_apply": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
     "pv_layernorm": (c_int, [C.POINTER(LayerNormParams), c_void_p]),
     "pv_attention": (c_int, [C.POINTER(AttnParams), c_void_p]),
@@ -164,7 +165,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

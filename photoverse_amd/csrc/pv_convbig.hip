@@ -75,6 +75,9 @@ struct BigCfg {
     static constexpr int PATCH_PIECES = 32;
     static constexpr int PATCH_BYTES = PATCH_PIECES * 16 * ROW_BYTES;                   // 32 KiB
     static constexpr int SMEM_PATCH_BYTES = NBUF * B_BYTES + 2 * PATCH_BYTES;           // 80 + 64 = 144 KiB
+    // MODE 5 / 6 (GroupNorm + SiLU of the conv's input folded in): the image's scale / shift table, fp32 [2][cin], behind the patch buffers
+    static constexpr int NORM_TABLE_BYTES = 16 * 1024;                                   // cin <= 2048
+    static constexpr int SMEM_NORM_BYTES = SMEM_PATCH_BYTES + NORM_TABLE_BYTES;         // 160 KiB: all of a CU's LDS
 };
 
 __device__ __forceinline__ float epi_act(float x, int act) {
@@ -113,9 +116,13 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
     // taps read them at shifted addresses, instead of gathering the shifted 256 rows once per tap (9 x 16 KiB).  L2 -> LDS bytes per chunk:
     // 25 + 9 x 20 = 205 KiB instead of 9 x 36 = 324 KiB, LDS-DMA instructions per stage and wave 2.9 instead of 4.5.  K order: 32-channel chunk
     // major, tap minor (the 128-row kernel: 64-channel chunk major) - NOT bit-identical to it.
-    constexpr bool PATCH = MODE >= 3;
+    // MODE 5 / 6 = MODE 3 / 4 with the GroupNorm (+ SiLU) of the conv's INPUT folded in (pv_gemm_params.a_norm): the patch is the one place where every
+    // input pixel of a tile passes exactly once, so each wave normalises the pieces it staged, IN PLACE in LDS (ds_read 16 B, pv_groupnorm_apply's fp32
+    // arithmetic, ds_write), four stages after their LDS-DMA and under the MFMAs of a segment; padding pixels stay zero.  The 64 x 64 level's
+    // GroupNorm-apply launches (write + re-read of every conv input) disappear.
+    constexpr bool PATCH = MODE >= 3, NORMA = MODE >= 5;
     constexpr bool IS_CONV = MODE == 0 || PATCH;
-    constexpr int LOG2W = MODE == 3 ? 6 : 5, PW = 1 << LOG2W, PR = 256 >> LOG2W, PS = PW + 2, NPIX = (PR + 2) * PS;
+    constexpr int LOG2W = (MODE == 3 || MODE == 5) ? 6 : 5, PW = 1 << LOG2W, PR = 256 >> LOG2W, PS = PW + 2, NPIX = (PR + 2) * PS;
     constexpr int TAPS = IS_CONV ? 9 : 1;
     using Cfg = BigCfg<MI, NF>;
     static_assert(!PATCH || (MI == 8 && !UPS && !LN), "the patch modes are the plain 256-row conv");
@@ -394,11 +401,44 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const half8_t*>(smem + a_row[mi / FPR] + (mi % FPR) * 16 * ROW_BYTES);
         };
+        // NORMA: normalise, in place, the patch piece this wave staged (its pixel is ppix[0]; the registers rotate as in issue_patch): lane = (pixel,
+        // 16-B position); the position holds data chunk pos ^ swizzle = 8 channels c8 .. c8 + 7 of the chunk; y = act(x * scale + shift) with
+        // pv_groupnorm_apply's expressions; lanes of padding pixels leave the zeros of the LDS-DMA alone
+        float* const s_tab = reinterpret_cast<float*>(smem + Cfg::SMEM_PATCH_BYTES);       // [2][cin]
+        const int lane_dc8 = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 8;
+        auto norm_piece = [&](int chunk, int i) {
+            const unsigned px = ppix[0];
+            ppix[0] = ppix[1]; ppix[1] = ppix[2]; ppix[2] = ppix[3]; ppix[3] = px;
+            char* at = s_patch + (chunk & 1) * PATCH_BYTES + (wave + 8 * i) * 16 * ROW_BYTES + lane * 16;
+            const half8_t v = *reinterpret_cast<const half8_t*>(at);
+            const float* sc = s_tab + chunk * BK + lane_dc8;
+            const float4_t s0 = *reinterpret_cast<const float4_t*>(sc), s1 = *reinterpret_cast<const float4_t*>(sc + 4);
+            const float4_t h0 = *reinterpret_cast<const float4_t*>(sc + cin), h1 = *reinterpret_cast<const float4_t*>(sc + cin + 4);
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j] * (j < 4 ? s0[j & 3] : s1[j & 3]) + (j < 4 ? h0[j & 3] : h1[j & 3]);
+                if (p.a_norm_act == PV_ACT_SILU) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
+                o[j] = (half_t)f;
+            }
+            if (px != OOB) *reinterpret_cast<half8_t*>(at) = o;
+        };
+        if constexpr (NORMA) {
+            // the image's table into LDS (issued FIRST: the oldest vector-memory operations, covered by every later vmcnt wait)
+            const float* tab = p.a_norm + (size_t)img * 2 * cin;
+            for (int i = (int)threadIdx.x; i < 2 * cin; i += NW * 64) s_tab[i] = tab[i];
+        }
         // ---- prologue: the first chunk's patch (all four pieces), weight stages 0, 1, 2 (taps 0-2 of chunk 0: a conv has >= 9 stages) ----
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_patch(0, i);
         for (int s = 0; s < 3; ++s) issue_w(s, 0, s);
         if (wm == 0) wait_vmcnt<2 * PB_HI>(); else wait_vmcnt<2 * PB_LO>();       // patch 0 and stage 0 landed
+        if constexpr (NORMA) {
+            __syncthreads();                                        // the table is in LDS
+#pragma unroll
+            for (int i = 0; i < 4; ++i) norm_piece(0, i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written back before the barrier below releases the readers
+        }
         frag_addrs(0, 0);
         seg_barrier();
         if (wm == 1) seg_barrier();                                 // the stagger: waves 4-7 one interval behind
@@ -437,6 +477,13 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
 #if PV_PATCH_ABLATE != 1
             frag_addrs(chunk, tapshift);
 #endif
+            if constexpr (NORMA) {
+                // taps 4-7 of a chunk (tap was advanced above: 5-8): piece tap - 5 of the NEXT chunk's patch landed at least two stages ago.  In a block of
+                // its own in FRONT of the MFMAs: ~600 cycles per piece (LDS round trip + 75 VALU, nothing under them).  Interleaved with the MFMAs (a
+                // second copy of the MFMA block, sched_group_barrier) the temporaries do not fit next to 160 accumulators + 52 fragment registers:
+                // 536 B of scratch.  This is why the fold is OFF by default (ops.Recorder.GN_FOLD).
+                if (tap >= 5 && chunk + 1 < nchunk) norm_piece(chunk + 1, tap - 5);
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -655,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void big_tile_kernel(const pv_gemm_params_d
 template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = BigCfg<MI, MODE == 2 ? 4 : 5>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = MODE >= 3 ? Cfg::SMEM_PATCH_BYTES : Cfg::SMEM_BYTES;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = MODE >= 5 ? Cfg::SMEM_NORM_BYTES : MODE >= 3 ? Cfg::SMEM_PATCH_BYTES : Cfg::SMEM_BYTES;
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -680,7 +727,7 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     // (read per call, not cached: the parity test runs both kernels in one process; launches are recorded once and replayed from graphs)
     const char* env = getenv("PV_CONV_BIG");
     const int min_tiles = p.big_tile_min ? p.big_tile_min : (env ? atoi(env) : 256);     // the caller's threshold wins (pv_gemm_params.big_tile_min)
-    if (min_tiles <= 0) return -1;
+    if (min_tiles <= 0) return p.a_norm ? -2 : -1;              // (-2: a launch with the GroupNorm fold that this path does not take - no fallback exists)
     const int splits = (p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
     const int cin = p.c0 + p.c1;
     if (p.taps == 1) {
@@ -718,9 +765,15 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
     const int pmode = penv ? atoi(penv) : 64;
     if (pmode != 0 && !p.upsample && splits == 1 && (p.wout == 64 || (p.wout == 32 && pmode != 64)) && ((p.hout * p.wout) % 256) == 0 && (p.M % 256) == 0 &&
         (p.c0 % 32) == 0 && (cin % 32) == 0) {
+        if (p.a_norm) {
+            if (2 * cin * 4 > BigCfg<8, 5>::NORM_TABLE_BYTES) return -2;
+            if (p.wout == 64) return cs ? launch_big<true, false, 8, 5>(p, stream) : launch_big<false, false, 8, 5>(p, stream);
+            return cs ? launch_big<true, false, 8, 6>(p, stream) : launch_big<false, false, 8, 6>(p, stream);
+        }
         if (p.wout == 64) return cs ? launch_big<true, false, 8, 3>(p, stream) : launch_big<false, false, 8, 3>(p, stream);
         return cs ? launch_big<true, false, 8, 4>(p, stream) : launch_big<false, false, 8, 4>(p, stream);
     }
+    if (p.a_norm) return -2;                                    // the fold exists on the patch path only: the caller must not fall back
     if (p.upsample) return cs ? launch_big<true, true, 8, 0>(p, stream) : launch_big<false, true, 8, 0>(p, stream);
     return cs ? launch_big<true, false, 8, 0>(p, stream) : launch_big<false, false, 8, 0>(p, stream);
 }

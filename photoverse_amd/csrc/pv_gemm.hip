@@ -612,6 +612,7 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     {                                                    // the 256-row tile (pv_convbig.hip) where the launch fills the chip with it
         const int rc = pv_conv_big_launch(p, stream);
         if (rc >= 0) return rc;
+        if (rc == -2 || p.a_norm) return (int)hipErrorInvalidValue;     // the GroupNorm fold (a_norm) exists on the LDS-resident-patch path only (header)
     }
     if (p.ln_rowsum) return (int)hipErrorInvalidValue;   // the LayerNorm fold exists on the 256-row-tile Linear path only (header)
     if (p.geglu) return dispatch<4, false, true>(p, stream);

@@ -97,7 +97,7 @@ __global__ void gn_finalize_kernel(const pv_groupnorm_params p) {
 // (mean, rstd) per (image, group) from the per-64-row-block column sums the producing GEMM epilogues wrote
 // (pv_gemm_params.colstats: [block][2][c] fp32).  One wave per (image, group); lanes stride over (block, channel) pairs,
 // fixed shuffle tree: deterministic.  Replaces gn_stats_kernel + gn_finalize_kernel: no pass over the activations.
-__global__ __launch_bounds__(256) void gn_colstats_finalize_kernel(const pv_groupnorm_params p) {
+__global__ __launch_bounds__(256) void gn_colstats_finalize_kernel(const pv_groupnorm_params p, float* table) {
     // one 256-thread workgroup per (image, group): 2-3 independent load pairs per thread instead of 10 dependent trips of one wave
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,6 +133,18 @@ __global__ __launch_bounds__(256) void gn_colstats_finalize_kernel(const pv_grou
         const float var = fmaxf(q / n - mean * mean, 0.f);
         part[0] = mean;
         part[1] = rsqrtf(var + p.eps);
+        red[0] = mean;
+        red[1] = part[1];
+    }
+    if (table == nullptr) return;
+    // pv_groupnorm_scale_shift: the affine form of this (image, group)'s channels, with gn_apply_kernel's own expressions (a = gamma * rstd,
+    // shift = beta - mean * a) so that a consumer applying x * a + shift reproduces pv_groupnorm_apply bit for bit
+    __syncthreads();
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const float a = p.gamma[c] * red[1];
+        table[((size_t)b * 2) * C + c] = a;
+        table[((size_t)b * 2 + 1) * C + c] = p.beta[c] - red[0] * a;
     }
 }
 
@@ -331,7 +343,17 @@ extern "C" int pv_groupnorm_stats_from_colstats(const pv_groupnorm_params* p, vo
         p->ld0 != p->c0 || (p->c1 > 0 && p->ld1 != p->c1))
         return (int)hipErrorInvalidValue;
     const int ng = p->batch * p->groups;
-    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3(ng), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3(ng), dim3(256), 0, (hipStream_t)stream, *p, (float*)nullptr);
+    return PV_CHECK_LAUNCH();
+}
+
+extern "C" int pv_groupnorm_scale_shift(const pv_groupnorm_params* p, float* table, void* stream) {
+    int nchunk, threads, rpp;
+    if (!table || !gn_geometry(*p, nchunk, threads, rpp) || !p->partial || !p->gamma || !p->beta || !p->colstats0 || (p->c1 > 0 && !p->colstats1) || (p->hw % 64) ||
+        p->ld0 != p->c0 || (p->c1 > 0 && p->ld1 != p->c1) || (p->c0 + p->c1) / p->groups > 256)
+        return (int)hipErrorInvalidValue;
+    const int ng = p->batch * p->groups;
+    hipLaunchKernelGGL(gn_colstats_finalize_kernel, dim3(ng), dim3(256), 0, (hipStream_t)stream, *p, table);
     return PV_CHECK_LAUNCH();
 }
 

@@ -159,14 +159,17 @@ class Recorder:
     def gemm(self, a: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowadd=None,
              rowadd_ld: int = 0, rows_per_image: Optional[int] = None, residual=None, out=None, act=ACT_NONE,
              out_f32=False, geglu=False, conv: Optional[dict] = None, splitk: Optional[int] = None,
-             colstats: bool = False, colstats_out: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None, ln_eps: float = 1e-5) -> torch.Tensor:
+             colstats: bool = False, colstats_out: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None, ln_eps: float = 1e-5,
+             a_norm: Optional[torch.Tensor] = None, a_norm_act: int = ACT_NONE) -> torch.Tensor:
         """out = epilogue(A @ W^T).  ``a`` (and ``a1``): 2-D fp16 row views; ``w``: fp16 [N, taps*Cin].
         ``colstats``: the output feeds a GroupNorm - let the epilogue leave its per-column (sum, sum of squares) behind so that
         ``groupnorm`` needs no statistics pass over the tensor (ignored where the epilogue cannot: fp32, GEGLU; with split-K the
         reduce launch produces them).
         ``ln_gamma`` / ``ln_beta``: ``out = epilogue(LayerNorm(a) @ W^T + bias)`` in ONE launch (``gemm_ln_supported`` says where): the affine part is
         folded here, at plan-build time (gamma scales the columns of w - for ``geglu`` BEFORE the caller's ``pack_geglu``, so pass the packed weight
-        of an already scaled matrix via ``fold_layernorm`` -, w . beta joins the bias), the kernel normalises through its epilogue."""
+        of an already scaled matrix via ``fold_layernorm`` -, w . beta joins the bias), the kernel normalises through its epilogue.
+        ``a_norm`` (``groupnorm_table``'s result) / ``a_norm_act``: ``out = epilogue(conv(act(GroupNorm(a | a1))))`` in ONE launch on the raw tensors
+        (``gn_conv_supported`` says where): the 3x3 conv normalises its LDS-resident input patch in place."""
         lda0, c0 = _rows(a)
         lda1, c1 = _rows(a1) if a1 is not None else (0, 0)
         taps = 9 if conv is not None else 1
@@ -222,9 +225,13 @@ class Recorder:
         if ln_gamma is not None:
             assert Recorder.gemm_ln_supported(M, N, kdim, geglu, self.big_min) and conv is None and a1 is None and not colstats and splitk == 1
             ln_rowsum = w.float().sum(1).contiguous()            # of the fp16 values the MFMAs see (w already carries gamma: fold_layernorm)
+        if a_norm is not None:
+            assert conv is not None and a_norm.dtype == torch.float32 and a_norm.is_contiguous() and a_norm.shape == (geo[0], 2, c0 + c1), a_norm.shape
+            assert Recorder.gn_conv_supported(geo, M, N, c0, c1, big_min, splitk), "gemm(a_norm=...) needs the LDS-resident-patch conv (gn_conv_supported)"
         p = GemmParams(_ptr(a), _ptr(a1), c0, c1, lda0, lda1, _ptr(w), _ptr(bias), _ptr(rowadd), rowadd_ld, _ptr(residual), ldr,
-                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps), big_min if big_min > 0 else -1)
-        self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum) if t is not None)
+                       _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps), big_min if big_min > 0 else -1,
+                       _ptr(a_norm), int(a_norm_act))
+        self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum, a_norm) if t is not None)
         nf = 4 if geglu else (5 if N % 160 == 0 else 4)
         # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MI>
         # (MULTI = the tile-loop instantiation pv_gemm.hip's choose_tpw picks for the short-K GEGLU layers with >= 1024 workgroups)
@@ -243,7 +250,7 @@ class Recorder:
                 pmode = int(os.environ.get("PV_CONV_PATCH", "64"))      # 0: never; 64 (default): the 64-pixel-row form only; 1: the 32-pixel-row form too
                 patch = (pmode != 0 and not geo[6] and splitk == 1 and (geo[4] == 64 or (geo[4] == 32 and pmode != 64)) and (geo[3] * geo[4]) % 256 == 0
                          and M % 256 == 0 and c0 % 32 == 0 and (c0 + c1) % 32 == 0)
-                mode = (3 if geo[4] == 64 else 4) if patch else 0
+                mode = ((3 if geo[4] == 64 else 4) if patch else 0) + (2 if a_norm is not None else 0)
                 name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, {mode}, false>"
         bn_big = 256 if geglu else 320
         if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
@@ -266,6 +273,40 @@ class Recorder:
         bn = 256 if geglu else 320
         return (Recorder.GEMM_LN and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and K >= 640 and N % bn == 0
                 and ((M + 255) // 256) * (N // bn) >= big_min)
+
+    #: GroupNorm + SiLU folded into the 3x3 conv behind it (pv_gemm_params.a_norm, round 5): exact (bit-identical to GroupNorm-apply + conv), removes the
+    #: 64 x 64 level's 20 GroupNorm-apply launches per step - and measures 32.3 -> 32.1 steps/s same box (three rounds): the conv pays ~600 cycles per
+    #: normalised patch piece (+15 % per conv: 116.5 vs 101.5 us), as much as the launches it removes (profiles/r05_gnfold_*.txt).  OFF by default;
+    #: PV_GN_FOLD=1 enables it; the entry point stays tested.
+    GN_FOLD = os.environ.get("PV_GN_FOLD", "0") != "0"
+
+    @staticmethod
+    def gn_conv_supported(geo, M: int, N: int, c0: int, c1: int, big_min: int, splitk: int = 1) -> bool:
+        """Where ``gemm(a_norm=...)`` exists: the launches pv_conv_big_launch puts on the LDS-resident-patch modes (its rule, restated), whose inputs carry
+        column statistics (whole 64-row blocks per image) and whose scale / shift table fits the kernel's LDS slot."""
+        pmode = int(os.environ.get("PV_CONV_PATCH", "64"))
+        hw = geo[3] * geo[4]
+        up = 2 if geo[6] else 1
+        shape = (big_min > 0 and geo[5] == 1 and geo[7] == 1 and not geo[6] and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
+        patch = (pmode != 0 and splitk == 1 and (geo[4] == 64 or (geo[4] == 32 and pmode != 64)) and hw % 256 == 0 and M % 256 == 0 and c0 % 32 == 0 and (c0 + c1) % 32 == 0)
+        return bool(Recorder.GN_FOLD and shape and patch and ((M + 255) // 256) * (N // 320) >= big_min and 2 * (c0 + c1) * 4 <= 16 * 1024)
+
+    def groupnorm_table(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5, groups=32) -> Optional[torch.Tensor]:
+        """The GroupNorm of ``x`` (| ``x1``) as a per-(image, channel) scale / shift table, fp32 [batch][2][C], for ``gemm(a_norm=...)``; None when the inputs
+        carry no column statistics (the caller then runs ``groupnorm``)."""
+        ld0, c0 = _rows(x)
+        ld1, c1 = _rows(x1) if x1 is not None else (0, 0)
+        cs0 = self.colstats.get((x.data_ptr(), batch * hw, c0)) if ld0 == c0 else None
+        cs1 = self.colstats.get((x1.data_ptr(), batch * hw, c1)) if (x1 is not None and ld1 == c1) else None
+        if not (hw % 64 == 0 and cs0 is not None and (x1 is None or cs1 is not None)):
+            return None
+        partial = self.empty((batch, 1, groups, 2), torch.float32)
+        table = self.empty((batch, 2, c0 + c1), torch.float32)
+        p = GroupNormParams(_ptr(x), _ptr(x1), c0, c1, ld0, ld1, batch, hw, groups, 1, _ptr(partial), _ptr(gamma), _ptr(beta),
+                            float(eps), ACT_NONE, None, _ptr(cs0), _ptr(cs1))
+        self.keep.extend(t for t in (x, x1, gamma, beta) if t is not None)
+        self._add(self.lib.pv_groupnorm_scale_shift, p, _ptr(table))
+        return table
 
     @staticmethod
     def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):

@@ -269,18 +269,29 @@ class UNetEngine:
     def _resnet(self, m: ResnetBlock2D, x, x1, b, h, w, temb_all, toff):
         rec = self.rec
         cout = m.conv1.out_channels
-        hn = rec.groupnorm(x, _f32(m.norm1.weight), _f32(m.norm1.bias), batch=b, hw=h * w, x1=x1, eps=m.norm1.eps, act=ACT_SILU)
         geo = dict(batch=b, hin=h, win=w, hout=h, wout=w)
-        h1 = rec.gemm(hn, _conv3_w(m.conv1.weight), bias=_f32(m.conv1.bias), rowadd=temb_all[:, toff:toff + cout],
-                      rowadd_ld=(temb_all.stride(0) if self.t_rows > 1 else 0), conv=geo, colstats=True)
-        h2 = rec.groupnorm(h1, _f32(m.norm2.weight), _f32(m.norm2.bias), batch=b, hw=h * w, eps=m.norm2.eps, act=ACT_SILU)
+        geo_t = (b, h, w, h, w, 1, 0, 1)
+
+        def norm_conv(norm, xin, xin1, weight, **kw):
+            """conv(silu(GroupNorm(xin | xin1))): where the conv runs on the LDS-resident input patch (the 64 x 64 level), the norm is folded into it -
+            ONE statistics launch for the scale / shift table, no pass that writes and re-reads the normalised tensor; otherwise GroupNorm, then the conv."""
+            cin0, cin1 = xin.shape[1], (xin1.shape[1] if xin1 is not None else 0)
+            if Recorder.gn_conv_supported(geo_t, b * h * w, weight.shape[0], cin0, cin1, rec.big_min):
+                tab = rec.groupnorm_table(xin, _f32(norm.weight), _f32(norm.bias), batch=b, hw=h * w, x1=xin1, eps=norm.eps)
+                if tab is not None:
+                    return rec.gemm(xin, _conv3_w(weight), a1=xin1, conv=geo, colstats=True, a_norm=tab, a_norm_act=ACT_SILU, splitk=0, **kw)
+            hn = rec.groupnorm(xin, _f32(norm.weight), _f32(norm.bias), batch=b, hw=h * w, x1=xin1, eps=norm.eps, act=ACT_SILU)
+            return rec.gemm(hn, _conv3_w(weight), conv=geo, colstats=True, **kw)
+
+        h1 = norm_conv(m.norm1, x, x1, m.conv1.weight, bias=_f32(m.conv1.bias), rowadd=temb_all[:, toff:toff + cout],
+                       rowadd_ld=(temb_all.stride(0) if self.t_rows > 1 else 0))
         if m.conv_shortcut is not None:
             sc = rec.gemm(x, _conv1_w(m.conv_shortcut.weight), a1=x1, bias=_f32(m.conv_shortcut.bias), rows_per_image=h * w)
         else:
             assert x1 is None
             sc = x
         # every block output feeds a GroupNorm (next norm1 / Transformer2D.norm / conv_norm_out, directly or as a skip)
-        return rec.gemm(h2, _conv3_w(m.conv2.weight), bias=_f32(m.conv2.bias), residual=sc, conv=geo, colstats=True)
+        return norm_conv(m.norm2, h1, None, m.conv2.weight, bias=_f32(m.conv2.bias), residual=sc)
 
     def _transformer(self, name: str, m: Transformer2DModel, x, b, h, w, stop_after_attn1: bool = False, resume_hs=None):
         """``stop_after_attn1``: record norm -> proj_in -> attn1 only and return the hidden states (the conditioning-independent half of the block);

@@ -316,6 +316,54 @@ def test_conv3x3_256x320_tile_equals_the_128_row_kernel_bitwise(rec_cls, monkeyp
     torch.testing.assert_close(stats["big"].view(-1, 2, cout)[:, 1], (blk * blk).sum(1), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("B,c0,c1,cout,h,pmode", [(16, 320, 0, 320, 64, "64"), (16, 640, 320, 320, 64, "64"), (2, 128, 128, 640, 64, "64"), (16, 640, 0, 640, 32, "1"),
+                                                   (1, 128, 0, 320, 64, "64")])
+def test_groupnorm_silu_folded_into_the_patch_conv(rec_cls, monkeypatch, B, c0, c1, cout, h, pmode):
+    """pv_gemm_params.a_norm (ABI 15): ResnetBlock2D.norm1 / norm2 + SiLU folded into conv1 / conv2 where the conv runs on the LDS-resident input patch -
+    pv_groupnorm_scale_shift turns the producers' column statistics into a per-(image, channel) scale / shift table, the conv reads the RAW tensor(s) and
+    normalises each staged pixel once, in LDS, with pv_groupnorm_apply's arithmetic.  Against fp32 torch (group_norm -> silu -> conv2d) and, BIT FOR BIT,
+    against the two launches it replaces (GroupNorm-apply, then the same patch conv on the normalised tensor): single / dual source (the norm spans the
+    concatenation), image borders (padding stays zero, not silu(shift)), W = 64 and 32, column statistics of the output."""
+    from photoverse_amd.ops import ACT_SILU
+    monkeypatch.setenv("PV_CONV_PATCH", pmode)
+    monkeypatch.setattr(rec_cls, "GN_FOLD", True)            # (off by default: break-even alone, -0.5 % in the loop; the entry point stays tested)
+    C = c0 + c1
+    g = torch.Generator().manual_seed(300 + C)
+    # the inputs are themselves conv outputs in the plan (that is where their column statistics come from): produce them with a 1x1 GEMM here
+    src0, src1 = h16(B * h * h, 64, seed=301), h16(B * h * h, 64, seed=302)
+    wp0, wp1 = h16(c0, 64, scale=0.2, seed=303), (h16(c1, 64, scale=0.3, seed=304) if c1 else None)
+    b0 = torch.randn(c0, generator=g) * 0.5
+    w = h16(cout, C, 3, 3, scale=(9 * C) ** -0.5, seed=305)
+    bias = torch.randn(cout, generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    wpk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    geo = dict(batch=B, hin=h, win=h, hout=h, wout=h)
+    rec = rec_cls("cuda")
+    rec.big_min = 1
+    x0 = rec.gemm(src0.cuda(), wp0.cuda(), bias=b0.cuda(), rows_per_image=h * h, colstats=True, splitk=0)
+    x1 = rec.gemm(src1.cuda(), wp1.cuda(), rows_per_image=h * h, colstats=True, splitk=0) if c1 else None
+    assert rec_cls.gn_conv_supported((B, h, h, h, h, 1, 0, 1), B * h * h, cout, c0, c1, rec.big_min)
+    tab = rec.groupnorm_table(x0, gamma.cuda(), beta.cuda(), batch=B, hw=h * h, x1=x1)
+    assert tab is not None
+    fused = rec.gemm(x0, wpk, a1=x1, bias=bias.cuda(), conv=geo, colstats=True, a_norm=tab, a_norm_act=ACT_SILU, splitk=0)
+    want_mode = 5 if h == 64 else 6
+    assert rec.tags[-1][0] == f"big_tile_kernel<true, false, 8, {want_mode}, false>", rec.tags[-1]
+    cs_f = rec.colstats[(fused.data_ptr(), B * h * h, cout)]
+    hn = rec.groupnorm(x0, gamma.cuda(), beta.cuda(), batch=B, hw=h * h, x1=x1, act=ACT_SILU)
+    two = rec.gemm(hn, wpk, bias=bias.cuda(), conv=geo, colstats=True, splitk=0)
+    assert rec.tags[-1][0] == f"big_tile_kernel<true, false, 8, {want_mode - 2}, false>", rec.tags[-1]
+    cs_t = rec.colstats[(two.data_ptr(), B * h * h, cout)]
+    rec.run()
+    torch.cuda.synchronize()
+    xin = torch.cat([x0.float().cpu(), x1.float().cpu()], 1) if c1 else x0.float().cpu()
+    xin = xin.view(B, h, h, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.silu(F.group_norm(xin, 32, gamma, beta, 1e-5)), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(B * h * h, cout)
+    e_f, e_t = rel_l2(fused, ref), rel_l2(two, ref)
+    print(f"GroupNorm + SiLU folded into the patch conv ({c0}+{c1} -> {cout} @ {h}): vs fp32 {e_f:.2e} (two launches {e_t:.2e}), fused == two launches: {torch.equal(fused, two)}")
+    assert e_f < 1.5e-3 and e_t < 1.5e-3
+    assert torch.equal(fused, two) and torch.equal(cs_f, cs_t)
+
+
 @pytest.mark.parametrize("B,c0,c1,cout,h,extras,pmode", [(16, 320, 0, 320, 64, True, "64"), (16, 640, 320, 320, 64, False, "64"), (4, 64, 64, 640, 64, True, "64"),
                                                           (16, 640, 0, 640, 32, True, "1"), (2, 64, 64, 320, 32, False, "1"), (1, 64, 0, 320, 64, True, "64")])
 def test_conv3x3_lds_resident_input_patch(rec_cls, monkeypatch, B, c0, c1, cout, h, extras, pmode):
