@@ -19,6 +19,9 @@
 // 394 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch (same box, sustained; profiles/r05_attn8_*.txt).
 #define PV_ATTN8_DEFAULT 225
 #endif
+#ifndef PV_ATTN_LAZY_UP
+#define PV_ATTN_LAZY_UP 8.f    // attn_kernel: how far (log2 units) a score may exceed its row's softmax reference before the reference moves; 0 = eager
+#endif
 #ifndef PV_ATTN_ABLATE
 #define PV_ATTN_ABLATE 0   // 1 no exp, 2 no QK MFMA, 3 no PV MFMA: timing-only builds (wrong results)
 #endif
@@ -235,8 +238,10 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
             // mx = (tile row max) - m_run.  Fast path (wave-uniform, the common case after the first tiles): no row of the
             // wave exceeded its running maximum -> P = exp2(S') with no per-score subtraction at all.
             // Slow path: shift the reference by d = max(mx, 0), rescale the running output by exp2(-d).
+            // (lazy since round 5, as in attn8_kernel: the reference moves only when a score exceeds it by more than 8 log2 units - P <= 256 keeps its
+            // relative precision in fp16, the sums are fp32; with the eager form this block ran in ~60 % of the (fragment, tile) pairs of a long row)
             float d = 0.f;
-            if (FIRST || __any(mx > 0.f)) {
+            if (FIRST || __any(mx > PV_ATTN_LAZY_UP)) {
                 d = FIRST ? (mx == -INFINITY ? 0.f : mx) : fmaxf(mx, 0.f);
                 const float alpha = FIRST ? 0.f : PV_EXP2(-d);
                 m_run[qi] += d;
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 //   softmax instead of at the head of the matrix segment) and the first score MFMA of a chain takes -m_run as its C operand from a
 //   loop-carried vector (no accumulator-initialising v_mov); bit 7 (128): 48-deep score contraction (16x16x32 + 16x16x16: a quarter fewer
 //   score-MFMA cycles; the d = 40 rows are zero beyond column 40 either way).
-// Variants without bits 3 / 5 compute, per query row, exactly what attn_kernel<40, 4, true> computes, in its order: BIT-IDENTICAL results.
+// Variant 9 (stagger + lazy reference, decided per query fragment) computes, per query row, exactly what attn_kernel<40, 4, true> computes, in its
+// order: BIT-IDENTICAL results (tests/test_hip_kernels.py); variants 1 / 3 are that kernel's round-4 (eager) arithmetic.
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     constexpr int D = 40, NQ = 4, KB = 64;

@@ -532,8 +532,9 @@ def _attn40(rec_cls, qkv, B, H, n, lse=False):
 @pytest.mark.parametrize("n", [1536, 1000, 100, 64])
 def test_self_attention_8wave_staggered_forms(rec_cls, monkeypatch, var, n):
     """attn8_kernel (pv_attn.hip: one 512-query workgroup of eight waves, SIMD partners staggered by one barrier interval) in the forms the
-    build ships: 1 = the 4-wave kernel's arithmetic in the staggered structure - BIT-IDENTICAL to it; 9 = lazy softmax reference; 225 (default)
-    / 241 = exponentiate-first reference check, V prefetch, 48-deep score contraction (+ per-segment priorities).  Ragged sizes (query and key
+    build ships: 1 = the eager online softmax (round 4's arithmetic) in the staggered structure; 9 = lazy softmax reference, decided per query fragment -
+    the 4-wave kernel's arithmetic, BIT-IDENTICAL to it; 225 (default) / 241 = exponentiate-first reference check, V prefetch, 48-deep score contraction
+    (+ per-segment priorities).  Ragged sizes (query and key
     tails), one- and two-tile sequences, the log-sum-exp output the training backward reads, and a late dominant key (forces the reference
     move long after the first tile: the path that goes back to the scores in 225 / 241)."""
     B, H, d = 2, 8, 40
@@ -554,7 +555,7 @@ def test_self_attention_8wave_staggered_forms(rec_cls, monkeypatch, var, n):
         assert rel_l2(out, ref) < 2e-3
         want_lse = torch.logsumexp((q @ kk.transpose(-1, -2)) / d ** 0.5, -1) / math.log(2.0)
         assert (lse - want_lse).abs().max() < 2e-2
-        if var == 1:
+        if var == 9:
             assert torch.equal(out, res[-1][k][0]) and torch.equal(lse, res[-1][k][1])
         else:
             assert rel_l2(out, res[-1][k][0]) < 1e-3
