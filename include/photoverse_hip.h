@@ -348,6 +348,11 @@ typedef struct pv_row_gemm_params {
     int32_t ln; float ln_eps;
     int32_t geglu;
     void* out; int32_t ld_out;                 /* fp16 [M][N or N/2] */
+    const float* x_norm;                       /* (ABI 15) optional fp32 [images][2][K]: a GroupNorm of the rows as a per-(image, channel) scale / shift
+                                                  (pv_groupnorm_scale_shift): the launch computes epi( (x * scale + shift) . w^T + bias ) - [EXT]
+                                                  Transformer2DModel.norm folded into proj_in on the raw tensor, the normalised rows rounded to fp16 exactly as
+                                                  pv_groupnorm_apply writes them.  Needs rows_per_image % 128 == 0; not together with ln */
+    int32_t rows_per_image;
 } pv_row_gemm_params;
 int pv_row_gemm(const pv_row_gemm_params* p, void* stream);
 

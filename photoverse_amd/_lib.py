@@ -79,7 +79,7 @@ class XAttnLnqParams(C.Structure):
 
 class RowGemmParams(C.Structure):
     _fields_ = [("x", c_void_p), ("ld_x", c_int), ("M", c_int), ("K", c_int), ("N", c_int), ("w", c_void_p), ("bias", c_void_p),
-                ("ln", c_int), ("ln_eps", c_float), ("geglu", c_int), ("out", c_void_p), ("ld_out", c_int)]
+                ("ln", c_int), ("ln_eps", c_float), ("geglu", c_int), ("out", c_void_p), ("ld_out", c_int), ("x_norm", c_void_p), ("rows_per_image", c_int)]
 
 
 class XAttnBwdParams(C.Structure):

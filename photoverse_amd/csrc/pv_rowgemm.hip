@@ -91,6 +91,21 @@ __global__ __launch_bounds__(256, 2) void row_gemm_kernel(const pv_rowgemm_param
     }
     issue_stage(0);
     issue_stage(1);
+    if (p.x_norm) {
+        // GroupNorm of the rows in its affine form (pv_groupnorm_scale_shift's table): x * scale[image][c] + shift[image][c], rounded to fp16 as
+        // pv_groupnorm_apply rounds what it writes.  The workgroup's 128 rows lie in one image; the 16 lanes of a k-group read the same 8 channels
+        // (one request per wave instruction)
+        const float* tab = p.x_norm + (size_t)(m0 / p.rows_per_image) * 2 * C + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const float4_t s0 = *reinterpret_cast<const float4_t*>(tab + kk * 32), s1 = *reinterpret_cast<const float4_t*>(tab + kk * 32 + 4);
+            const float4_t h0 = *reinterpret_cast<const float4_t*>(tab + C + kk * 32), h1 = *reinterpret_cast<const float4_t*>(tab + C + kk * 32 + 4);
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[kk][qi][j] = (half_t)((float)xf[kk][qi][j] * (j < 4 ? s0[j & 3] : s1[j & 3]) + (j < 4 ? h0[j & 3] : h1[j & 3]));
+        }
+    }
     if (p.ln) {
         // LayerNorm without its affine part (gamma is folded into the columns of W, beta into the bias): statistics by v_dot2_f32_f16, the
         // centred sum of squares from packed fp16 differences with an exact correction for the rounded mean (as in pv_xfused.hip)
@@ -214,7 +229,7 @@ extern "C" int pv_row_gemm(const pv_row_gemm_params* pp, void* stream) {
     pv_rowgemm_params_dev p;
     static_cast<pv_row_gemm_params&>(p) = *pp;
     if (!p.x || !p.w || !p.out || p.M <= 0 || p.K != RG_K || p.N <= 0 || (p.N % (2 * RG_CHUNK)) || (p.ld_x % 8) || (p.ld_out % 8) || p.ld_x < RG_K ||
-        p.ld_out < (p.geglu ? p.N / 2 : p.N))
+        p.ld_out < (p.geglu ? p.N / 2 : p.N) || (p.x_norm && (p.ln || p.rows_per_image <= 0 || (p.rows_per_image % 128) || (p.M % p.rows_per_image))))
         return (int)hipErrorInvalidValue;
     if ((size_t)p.N * RG_K * 2 >= (1ull << 31)) return (int)hipErrorInvalidValue;
     p.w_bytes = (uint32_t)p.N * RG_K * 2;

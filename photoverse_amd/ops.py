@@ -631,11 +631,14 @@ class Recorder:
     def row_gemm_supported(K: int, N: int) -> bool:
         return K == 320 and N % 320 == 0
 
-    def row_gemm(self, x, w, *, bias=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5, geglu=False, out=None):
+    def row_gemm(self, x, w, *, bias=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5, geglu=False, out=None, x_norm=None, rows_per_image=0):
         """``out = epi(LayerNorm(x) . w^T + bias)``: ``w`` fp16 [N][320] (for ``geglu``: rows and bias already in ``pack_geglu_rows`` order).
         With ``ln_gamma`` / ``ln_beta`` the kernel normalises the rows in registers; the affine part is folded here, once at plan-build
-        time: gamma scales the columns of w, w . beta joins the bias."""
+        time: gamma scales the columns of w, w . beta joins the bias.  ``x_norm`` (``groupnorm_table``'s result) + ``rows_per_image``: the rows are
+        GroupNorm-ed in registers instead (Transformer2DModel.norm -> proj_in on the raw block output)."""
         M, K = x.shape
+        if x_norm is not None:
+            assert ln_gamma is None and rows_per_image % 128 == 0 and M % rows_per_image == 0 and x_norm.shape == (M // rows_per_image, 2, K) and x_norm.dtype == torch.float32
         N = w.shape[0]
         assert Recorder.row_gemm_supported(K, N) and w.shape[1] == K and w.dtype == torch.float16
         ln = ln_gamma is not None
@@ -650,8 +653,9 @@ class Recorder:
         n_out = N // 2 if geglu else N
         if out is None:
             out = self.empty((M, n_out), torch.float16)
-        p = _lib.RowGemmParams(_ptr(x), _rows(x)[0], M, K, N, _ptr(w), _ptr(b32), 1 if ln else 0, float(ln_eps), 1 if geglu else 0, _ptr(out), _rows(out)[0])
-        self.keep.extend(t for t in (x, w, b32, out) if t is not None)
+        p = _lib.RowGemmParams(_ptr(x), _rows(x)[0], M, K, N, _ptr(w), _ptr(b32), 1 if ln else 0, float(ln_eps), 1 if geglu else 0, _ptr(out), _rows(out)[0],
+                               _ptr(x_norm), int(rows_per_image))
+        self.keep.extend(t for t in (x, w, b32, out, x_norm) if t is not None)
         self._add(self.lib.pv_row_gemm, p, tag=("row_gemm_kernel<%s>" % ("true" if geglu else "false"), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out)))
         return out
 

@@ -168,6 +168,7 @@ class TimestepEmbedding(_Holder):
 #: A/B switch: PV_NO_XFUSED=1 runs attn2 as the four separate launches (LayerNorm, to_q GEMM, dual-branch SDPA, to_out GEMM)
 USE_XFUSED = not os.environ.get("PV_NO_XFUSED")
 USE_ROWGEMM = not os.environ.get("PV_NO_ROWGEMM")     # A/B switch: LayerNorm + K = 320 Linear as one row-owning launch (pv_rowgemm.hip)
+GN_PROJ_IN = os.environ.get("PV_GN_PROJ_IN", "1") != "0"   # A/B switch: Transformer2DModel.norm folded into proj_in on the row-owning launch (round 5)
 
 
 def _f16(t: torch.Tensor) -> torch.Tensor:
@@ -304,8 +305,16 @@ class UNetEngine:
         d = C // heads
         if resume_hs is not None:
             return self._transformer_tail(name, m, x, resume_hs, b, h, w)
-        g = rec.groupnorm(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=b, hw=n, eps=m.norm.eps, act=ACT_NONE)
-        hs = rec.gemm(g, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), rows_per_image=n)
+        tab = None
+        if GN_PROJ_IN and USE_ROWGEMM and Recorder.row_gemm_supported(x.shape[1], C) and n % 128 == 0:
+            # Transformer2DModel.norm folded into proj_in (64 x 64 level, K = 320): one statistics launch for the scale / shift table, then the row-owning
+            # GEMM on the RAW block output - the GroupNorm-apply pass (write + re-read of the normalised tensor) disappears
+            tab = rec.groupnorm_table(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=b, hw=n, eps=m.norm.eps)
+        if tab is not None:
+            hs = rec.row_gemm(x, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), x_norm=tab, rows_per_image=n)
+        else:
+            g = rec.groupnorm(x, _f32(m.norm.weight), _f32(m.norm.bias), batch=b, hw=n, eps=m.norm.eps, act=ACT_NONE)
+            hs = rec.gemm(g, _conv1_w(m.proj_in.weight), bias=_f32(m.proj_in.bias), rows_per_image=n)
         # --- attn1 (stock AttnProcessor2_0, models/unet.py:20-24) ---
         a1 = blk.attn1
         wqkv = torch.cat([_f16(a1.to_q.weight), _f16(a1.to_k.weight), _f16(a1.to_v.weight)], 0).contiguous()

@@ -726,6 +726,35 @@ def test_cross_attention_lnq_one_pass_statistics_bound(rec_cls, shift, tol):
     assert torch.isfinite(out).all() and err_hi < tol and err_lo < 2e-3
 
 
+@pytest.mark.parametrize("B,hw", [(16, 4096), (3, 256)])
+def test_row_gemm_groupnorm_folded_into_proj_in(rec_cls, B, hw):
+    """pv_row_gemm_params.x_norm (ABI 15): Transformer2DModel.norm (GroupNorm 32, eps 1e-6, no activation) folded into proj_in at K = 320 - the row-owning
+    launch reads the RAW block output and normalises the rows in registers with pv_groupnorm_scale_shift's per-(image, channel) table - against fp32 torch
+    and against the two launches it replaces (GroupNorm-apply, then the tiled GEMM)."""
+    C = 320
+    src = h16(B * hw, 64, seed=401)
+    wp = h16(C, 64, scale=0.2, seed=402)
+    b0 = torch.randn(C, generator=torch.Generator().manual_seed(403)) * 0.5
+    w = h16(C, C, scale=C ** -0.5, seed=404)
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(405))
+    gamma = 1.0 + 0.3 * torch.randn(C, generator=torch.Generator().manual_seed(406))
+    beta = 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(407))
+    rec = rec_cls("cuda")
+    x = rec.gemm(src.cuda(), wp.cuda(), bias=b0.cuda(), rows_per_image=hw, colstats=True, splitk=0)
+    tab = rec.groupnorm_table(x, gamma.cuda(), beta.cuda(), batch=B, hw=hw, eps=1e-6)
+    assert tab is not None
+    fused = rec.row_gemm(x, w.cuda(), bias=bias.cuda(), x_norm=tab, rows_per_image=hw)
+    g = rec.groupnorm(x, gamma.cuda(), beta.cuda(), batch=B, hw=hw, eps=1e-6)
+    two = rec.gemm(g, w.cuda(), bias=bias.cuda(), rows_per_image=hw)
+    rec.run()
+    torch.cuda.synchronize()
+    xin = x.float().cpu().view(B, hw, C).permute(0, 2, 1)
+    ref = F.group_norm(xin, 32, gamma, beta, 1e-6).permute(0, 2, 1).reshape(B * hw, C) @ w.float().t() + bias
+    e_f, e_t = rel_l2(fused, ref), rel_l2(two, ref)
+    print(f"GroupNorm folded into proj_in (B={B}, hw={hw}): vs fp32 {e_f:.2e} (two launches {e_t:.2e}); fused vs two launches {rel_l2(fused, two):.2e}")
+    assert e_f < 1e-3 and e_t < 1e-3 and rel_l2(fused, two) < 5e-4
+
+
 @pytest.mark.parametrize("M,N,geglu,ln,bias", [(1000, 960, False, True, False), (256, 320, False, False, True), (4096, 2560, True, True, True),
                                               (130, 640, True, False, False)])
 def test_row_gemm_layernorm_linear_geglu(rec_cls, M, N, geglu, ln, bias):
