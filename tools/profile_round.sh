@@ -10,4 +10,4 @@ find gpurun_out/prof_one -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} 
 python3 bench.py > gpurun_out/round/bench_default.json 2> gpurun_out/round/bench_default.err
 tail -3 gpurun_out/prof_bench_stdout.txt; tail -1 gpurun_out/round/bench_default.json | cut -c1-400
 python3 tools/kbench.py > gpurun_out/round/kbench.txt 2>&1
-python3 tools/diag/convbig_stamps.py 2>&1 | grep "launch\|wave\|stage" > gpurun_out/round/convbig_stamps.txt
+python3 tools/diag/convbig_seg_stamps.py 2>&1 | grep -v "^   [12] " > gpurun_out/round/convbig_stamps.txt
