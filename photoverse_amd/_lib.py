@@ -178,6 +178,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: PyTorch-ROCm bundles its own libamdhip64.so; a library dlopen-ed before it binds to /opt/rocm's copy, the process ends up with two HIP
+    # runtimes and every launch from this one fails with hipErrorNoDevice (100) - seen with `build(); smoke()` in one process
+    import torch  # noqa: F401
     if not os.path.exists(LIB):
         raise HipExtensionMissing(
             f"{LIB} not found: build it with `python -m photoverse_amd.build` (needs hipcc). "
