@@ -412,9 +412,6 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     using C = ACfg<D>;
     constexpr bool STAGGER = (VAR & 1) != 0, PRIO = (VAR & 2) != 0, PCHECK = (VAR & 32) != 0, JOINT = (VAR & 4) != 0 || PCHECK, LAZY = (VAR & 8) != 0 || PCHECK;
     constexpr bool SEGPRIO = (VAR & 16) != 0, PREF = (VAR & 64) != 0, K48 = (VAR & 128) != 0;
-    // bits 8-11 (256, 512, 1024, 2048): s_setprio 1 in the early half's matrix / vector segment, the late half's matrix / vector segment (experiments:
-    // the late half loses the issue arbitration in BOTH of its segments - stamps: 1650 + 1970 cycles against 1250 + 1226 for the early half)
-    constexpr int PRIO4 = (VAR >> 8) & 15;
     // LAZY: a row's softmax reference moves only when a score exceeds it by more than 8 log2 units (P <= 256: the same relative precision in
     // fp16, sums in fp32).  With the eager form the rescale block runs in ~60 % of the (fragment, tile) pairs of a 4096-key row of random
     // scores (a new maximum among 16 rows x 64 keys has probability ~ min(1, 16 / t) at tile t); lazily, in the first tiles only.
@@ -723,7 +720,6 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         }
 #endif
         if (SEGPRIO) __builtin_amdgcn_s_setprio(1);
-        if (PRIO4) { if (wave < 4 ? (PRIO4 & 1) : (PRIO4 & 4)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // this wave's pieces of tile t + 2 (issued at the end of its previous matrix segment, a whole vector segment ago) have landed
         // (hipcc would put this wait in front of the first LDS read below anyway: it cannot tell the ring slots apart)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -736,7 +732,6 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         // read in matrix segment t + 2, behind every wave's landed-wait at the head of its segment t + 1 and a barrier
         if (t + 3 < ntiles) issue_tile(t + 3);
         if (SEGPRIO) __builtin_amdgcn_s_setprio(0);
-        if (PRIO4) { if (wave < 4 ? (PRIO4 & 2) : (PRIO4 & 8)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     }
     if (STAGGER && !late) interval();            // every wave passes the same number of barriers
 
@@ -970,13 +965,12 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
                 void (*kern)(const pv_attn_params) = nullptr;
                 switch (var8) {
 #define PV_A8_CASE(V) case V: kern = attn8_kernel<V>; break;
-                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(3) PV_A8_CASE(5) PV_A8_CASE(9) PV_A8_CASE(11) PV_A8_CASE(13) PV_A8_CASE(25) PV_A8_CASE(29)
-                    PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(89) PV_A8_CASE(97) PV_A8_CASE(113) PV_A8_CASE(225) PV_A8_CASE(241) PV_A8_CASE(201)
-                    PV_A8_CASE(227) PV_A8_CASE(1249) PV_A8_CASE(2273) PV_A8_CASE(2785) PV_A8_CASE(3297) PV_A8_CASE(737) PV_A8_CASE(1761)
+                    // the forms of EXPERIMENTS.md's round-5 table (the seven per-segment priority schemes measured there were removed again)
+                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(9) PV_A8_CASE(13) PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(201) PV_A8_CASE(225) PV_A8_CASE(241)
 #undef PV_A8_CASE
                     default: return (int)hipErrorInvalidValue;
                 }
-                static bool attr8_set[64][4096] = {};
+                static bool attr8_set[64][256] = {};
                 int dev8 = 0;
                 (void)hipGetDevice(&dev8);
                 if (!attr8_set[dev8 & 63][var8]) {
