@@ -405,7 +405,11 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 //   loop-carried vector (no accumulator-initialising v_mov); bit 7 (128): 48-deep score contraction (16x16x32 + 16x16x16: a quarter fewer
 //   score-MFMA cycles; the d = 40 rows are zero beyond column 40 either way).
 // Variant 9 (stagger + lazy reference, decided per query fragment) computes, per query row, exactly what attn_kernel<40, 4, true> computes, in its
-// order: BIT-IDENTICAL results (tests/test_hip_kernels.py); variants 1 / 3 are that kernel's round-4 (eager) arithmetic.
+// order: BIT-IDENTICAL results (tests/test_hip_kernels.py); variant 1 is that kernel's round-4 (eager) arithmetic.
+// Measured (EXPERIMENTS.md, round 5; same box, sustained): the stagger alone ties the 4-wave kernel (483 us: its free-running workgroups de-phase by
+// themselves) and beats the same workgroup without it by 5 %; the lazy reference is what moves the launch (435 us), the exponentiate-first check,
+// the prefetch and the 48-deep contraction take it to 392 us (225, the default).  Per-segment priorities (241) remove another 14 % of the CYCLES
+// and none of the time: the launch runs at the package power limit (2.17 instead of 2.29 GHz).
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     constexpr int D = 40, NQ = 4, KB = 64;
