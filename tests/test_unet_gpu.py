@@ -505,6 +505,43 @@ def test_seam_statistics_are_not_adopted_when_the_gemm_epilogue_does_not_write_t
     assert err < 2e-3 and err_p < 2e-3
 
 
+def test_groupnorm_folds_change_nothing_in_the_loop(full_hip_unet, monkeypatch):
+    """Round 5's two GroupNorm folds at full size: Transformer2DModel.norm -> proj_in on the row-owning launch (default ON: compared with the two-launch
+    path to rounding - the GEMM behind the norm changes kernel) and ResnetBlock2D.norm1 / norm2 + SiLU -> conv1 / conv2 on the LDS-resident patch
+    (``Recorder.GN_FOLD``, default OFF: the conv consumes the same fp16 values either way, so the latents are BIT-IDENTICAL with and without it)."""
+    from photoverse_amd import ops, unet as unet_mod
+    from photoverse_amd.pipeline import DenoiseLoop
+    hip = full_hip_unet
+    B, S, P, T = 8, 64, 1, 2                 # 8 samples: the 64 x 64 convs are 128 tiles per branch = on the 256-row tile
+    g = torch.Generator().manual_seed(79)
+    cond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    uncond = (torch.randn(B, 77, 768, generator=g), torch.randn(B, P, 768, generator=g))
+    noise = torch.randn(B, 4, S, S, generator=g)
+
+    def run():
+        loop = DenoiseLoop(hip, B, S, P, T, 7.5)
+        loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+        loop.reset(noise)
+        out = loop.run().clone().cpu()
+        syms = {t[0] for e in loop.all_engines for t in e.rec.tags}
+        n = loop.launches_per_step
+        del loop
+        return out, syms, n
+
+    base, syms0, n0 = run()
+    assert any(s_.startswith("big_tile_kernel<true, false, 8, 3") for s_ in syms0) and not any(", 8, 5, false>" in s_ for s_ in syms0)
+    monkeypatch.setattr(ops.Recorder, "GN_FOLD", True)
+    fold, syms1, n1 = run()
+    assert any(", 8, 5, false>" in s_ for s_ in syms1) and n1 < n0
+    assert torch.isfinite(base).all() and torch.equal(fold, base)
+    monkeypatch.undo()
+    monkeypatch.setattr(unet_mod, "GN_PROJ_IN", False)
+    plain, _, n2 = run()
+    err = rel_l2(base, plain)
+    print(f"GroupNorm folds: conv fold bit-identical ({n1} vs {n0} launches per step); proj_in fold vs two launches rel-L2 {err:.2e} ({n0} vs {n2} launches)")
+    assert n0 < n2 and err < 2e-3
+
+
 def _two_rank_loop_worker(rank, world, port, q):
     """One rank of the batch-sharded path on the REAL HIP loop: shard of the CPU-drawn global batch -> DenoiseLoop -> the single
     gather (gloo here: both test ranks share the box's one GPU, where RCCL refuses duplicate devices)."""
