@@ -458,7 +458,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the launch SYMBOL with the largest share of one step's algorithmic flops.  Rounds 1-4 that was the 3x3 conv on the big tile
         # (25 % of a step's flops under one symbol); since round 5 the 64 x 64 convs run on the LDS-resident-patch instantiation (MODE 3, 13.2 %) and the
-        # 32 x 32 convs stay on the gathered one (MODE 0, 12.2 %), so the largest single symbol is the d = 40 self-attention kernel attn8_kernel<225>
+        # 32 x 32 convs stay on the gathered one (MODE 0, 12.2 %), so the largest single symbol is the d = 40 self-attention kernel attn8_kernel<497>
         # (13.4 % of the flops, ~15 % of the time) and the patch conv is the runner-up.  Both get the same measurement: exactly the symbol's launches
         # of one step, replayed and timed with HIP events on the launch stream.
         engines = loop.all_engines

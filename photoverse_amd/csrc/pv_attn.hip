@@ -15,9 +15,10 @@
 
 #ifndef PV_ATTN8_DEFAULT
 // variant of attn8_kernel (its VAR bits) taken where a d = 40 launch has at least one 512-query workgroup per CU; -1 = the 4-wave kernel
-// everywhere.  225 = stagger + exponentiate-first reference check + V-fragment prefetch / C-operand reference + 48-deep score contraction:
-// 394 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch (same box, sustained; profiles/r05_attn8_*.txt).
-#define PV_ATTN8_DEFAULT 225
+// everywhere.  497 = stagger + exponentiate-first reference check + V-fragment prefetch / C-operand reference + 48-deep score contraction (225:
+// 392-404 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch, same box, sustained) + the tile's LDS-DMA issued behind
+// the prefetch reads + per-segment priority (388-390 us where 225 takes 404; +1.0 % of a step over 225, profiles/r05_attn8_ab7*.txt).
+#define PV_ATTN8_DEFAULT 497
 #endif
 #ifndef PV_ATTN_LAZY_UP
 #define PV_ATTN_LAZY_UP 8.f    // attn_kernel: how far (log2 units) a score may exceed its row's softmax reference before the reference moves; 0 = eager
@@ -403,19 +404,23 @@ __global__ __launch_bounds__(256, attn_min_waves<D>()) void attn_kernel(const pv
 //   bit 6 (64): the V^T fragments of a tile are requested at the HEAD of the vector segment in front of it (the first three of the six: their LDS latency sits under the
 //   softmax instead of at the head of the matrix segment) and the first score MFMA of a chain takes -m_run as its C operand from a
 //   loop-carried vector (no accumulator-initialising v_mov); bit 7 (128): 48-deep score contraction (16x16x32 + 16x16x16: a quarter fewer
-//   score-MFMA cycles; the d = 40 rows are zero beyond column 40 either way).
+//   score-MFMA cycles; the d = 40 rows are zero beyond column 40 either way); bit 8 (256, with bit 6): the tile's LDS-DMA pieces are issued at the head of the
+//   vector segment BEHIND the prefetch reads instead of at the end of the matrix segment in front of them.
 // Variant 9 (stagger + lazy reference, decided per query fragment) computes, per query row, exactly what attn_kernel<40, 4, true> computes, in its
 // order: BIT-IDENTICAL results (tests/test_hip_kernels.py); variant 1 is that kernel's round-4 (eager) arithmetic.
 // Measured (EXPERIMENTS.md, round 5; same box, sustained): the stagger alone ties the 4-wave kernel (483 us: its free-running workgroups de-phase by
 // themselves) and beats the same workgroup without it by 5 %; the lazy reference is what moves the launch (435 us), the exponentiate-first check,
 // the prefetch and the 48-deep contraction take it to 392 us (225, the default).  Per-segment priorities (241) remove another 14 % of the CYCLES
-// and none of the time: the launch runs at the package power limit (2.17 instead of 2.29 GHz).
+// and none of the time: the launch runs at the package power limit (2.17 instead of 2.29 GHz).  What does come back as time is removing the
+// stall hipcc put at the head of every vector segment (its vmcnt(0) between the LDS-DMA issue and the prefetch reads: bit 8) TOGETHER with
+// the priorities: 497 = 225 + 16 + 256 takes 389 us where 225 and 241 take 404 and 481 (bit 8 alone) 414.
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     constexpr int D = 40, NQ = 4, KB = 64;
     using C = ACfg<D>;
     constexpr bool STAGGER = (VAR & 1) != 0, PRIO = (VAR & 2) != 0, PCHECK = (VAR & 32) != 0, JOINT = (VAR & 4) != 0 || PCHECK, LAZY = (VAR & 8) != 0 || PCHECK;
     constexpr bool SEGPRIO = (VAR & 16) != 0, PREF = (VAR & 64) != 0, K48 = (VAR & 128) != 0;
+    constexpr bool DMA_IN_VEC = PREF && (VAR & 256) != 0;     // bit 8 (256): with PREF, the tile's LDS-DMA is issued behind the prefetch reads (below)
     // LAZY: a row's softmax reference moves only when a score exceeds it by more than 8 log2 units (P <= 256: the same relative precision in
     // fp16, sums in fp32).  With the eager form the rescale block runs in ~60 % of the (fragment, tile) pairs of a 4096-key row of random
     // scores (a new maximum among 16 rows x 64 keys has probability ~ min(1, 16 / t) at tile t); lazily, in the first tiles only.
@@ -702,7 +707,14 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         if (t == 8) { a8_c0 = a8_t1; a8_r0 = __builtin_amdgcn_s_memrealtime(); }
         if (t > 8 && t < ntiles - 8) { a8_acc[2] += a8_t3 - a8_t0; a8_acc[3] += a8_t1 - a8_t3; }
 #endif
-        if (PREF) load_v(t);                     // tile t landed three segments ago; nothing waits for these reads before the matrix segment
+        if (PREF) {
+            load_v(t);                           // tile t landed three segments ago; nothing waits for these reads before the matrix segment
+            // ... and THEN this wave's LDS-DMA pieces of tile t + 2: hipcc waits vmcnt(0) in front of the first LDS read behind an LDS-DMA issue (it
+            // cannot tell the ring slots apart) - issued at the end of the matrix segment, as without PREF, that wait sat in front of the reads
+            // above and exposed the DMA's L2 latency at the head of every vector segment.  Slot (t + 2) & 3 held tile t - 2, last read two
+            // matrix segments ago; landed-wait at the head of matrix segment t, first read (K) in matrix segment t + 1
+            if (DMA_IN_VEC && t >= 1 && t + 2 < ntiles) issue_tile(t + 2);
+        }
         softmax(t, (t + 1) * KB > p.nk, t == 0);
         pin_p();
         pin_o();
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         pin_s();
         // tile t + 3 goes into the slot of tile t - 1, whose last reader (the late half's P.V) finished one interval ago; it is first
         // read in matrix segment t + 2, behind every wave's landed-wait at the head of its segment t + 1 and a barrier
-        if (t + 3 < ntiles) issue_tile(t + 3);
+        if (!DMA_IN_VEC && t + 3 < ntiles) issue_tile(t + 3);
         if (SEGPRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (STAGGER && !late) interval();            // every wave passes the same number of barriers
@@ -970,11 +982,11 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
                 switch (var8) {
 #define PV_A8_CASE(V) case V: kern = attn8_kernel<V>; break;
                     // the forms of EXPERIMENTS.md's round-5 table (the seven per-segment priority schemes measured there were removed again)
-                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(9) PV_A8_CASE(13) PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(201) PV_A8_CASE(225) PV_A8_CASE(241)
+                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(9) PV_A8_CASE(13) PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(201) PV_A8_CASE(225) PV_A8_CASE(241) PV_A8_CASE(481) PV_A8_CASE(497)
 #undef PV_A8_CASE
                     default: return (int)hipErrorInvalidValue;
                 }
-                static bool attr8_set[64][256] = {};
+                static bool attr8_set[64][512] = {};
                 int dev8 = 0;
                 (void)hipGetDevice(&dev8);
                 if (!attr8_set[dev8 & 63][var8]) {

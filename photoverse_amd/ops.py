@@ -360,7 +360,7 @@ class Recorder:
         self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
         # the symbol rocprof shows for this launch (pv_attn.hip: launch_attn's rule), and its workgroup count
         wg512, wg256 = ((nq + 511) // 512) * heads * batch, ((nq + 255) // 256) * heads * batch
-        var8 = int(os.environ.get("PV_ATTN8", "225"))
+        var8 = int(os.environ.get("PV_ATTN8", "497"))
         if d == 40 and not os.environ.get("PV_ATTN_NO_DMA") and var8 >= 0 and not causal and wg512 >= int(os.environ.get("PV_ATTN8_MIN", "256")):
             name, wgs = f"attn8_kernel<{var8}>", wg512
         elif d == 40:

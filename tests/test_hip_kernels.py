@@ -528,13 +528,13 @@ def _attn40(rec_cls, qkv, B, H, n, lse=False):
     return out.cpu(), (l.cpu() if lse else None)
 
 
-@pytest.mark.parametrize("var", [1, 9, 225, 241])
+@pytest.mark.parametrize("var", [1, 9, 225, 497])
 @pytest.mark.parametrize("n", [1536, 1000, 100, 64])
 def test_self_attention_8wave_staggered_forms(rec_cls, monkeypatch, var, n):
     """attn8_kernel (pv_attn.hip: one 512-query workgroup of eight waves, SIMD partners staggered by one barrier interval) in the forms the
     build ships: 1 = the eager online softmax (round 4's arithmetic) in the staggered structure; 9 = lazy softmax reference, decided per query fragment -
-    the 4-wave kernel's arithmetic, BIT-IDENTICAL to it; 225 (default) / 241 = exponentiate-first reference check, V prefetch, 48-deep score contraction
-    (+ per-segment priorities).  Ragged sizes (query and key
+    the 4-wave kernel's arithmetic, BIT-IDENTICAL to it; 225 / 497 (default) = exponentiate-first reference check, V prefetch, 48-deep score contraction
+    (497: + per-segment priorities, LDS-DMA issued behind the prefetch reads).  Ragged sizes (query and key
     tails), one- and two-tile sequences, the log-sum-exp output the training backward reads, and a late dominant key (forces the reference
     move long after the first tile: the path that goes back to the scores in 225 / 241)."""
     B, H, d = 2, 8, 40
