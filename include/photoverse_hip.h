@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 15
+#define PV_ABI_VERSION 16
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -174,6 +174,8 @@ typedef struct pv_attn_bwd_params {
     int32_t lddq, lddk, lddv;
     int32_t batch, heads, nq, nk, d;
     int32_t causal;
+    void* ws; int64_t ws_bytes;      /* optional workspace: with >= 2 * batch * heads * nq * 96 bytes the d = 40 / unmasked / nq, nk % 512 == 0
+                                      * launches take the 8-wave staggered kernels (pv_attnbwd.hip); NULL = the 4-wave kernels */
 } pv_attn_bwd_params;
 int pv_attention_backward(const pv_attn_bwd_params* p, void* stream);
 

@@ -44,7 +44,7 @@ class AttnBwdParams(C.Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("ldq", c_int), ("ldk", c_int), ("ldv", c_int),
                 ("out", c_void_p), ("ldo", c_int), ("dout", c_void_p), ("lddo", c_int), ("lse", c_void_p), ("delta", c_void_p), ("qs", c_void_p), ("ldqs", c_int),
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p), ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
-                ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nk", c_int), ("d", c_int), ("causal", c_int)]
+                ("batch", c_int), ("heads", c_int), ("nq", c_int), ("nk", c_int), ("d", c_int), ("causal", c_int), ("ws", c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class GroupNormBwdParams(C.Structure):
@@ -165,7 +165,7 @@ SIGNATURES = {
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

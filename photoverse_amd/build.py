@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libphotoverse_hip.so")
-SOURCES = ["pv_gemm.hip", "pv_convbig.hip", "pv_norm.hip", "pv_attn.hip", "pv_misc.hip", "pv_xfused.hip", "pv_xq.hip", "pv_rowgemm.hip", "pv_backward.hip", "pv_train.hip"]
+SOURCES = ["pv_gemm.hip", "pv_convbig.hip", "pv_norm.hip", "pv_attn.hip", "pv_misc.hip", "pv_xfused.hip", "pv_xq.hip", "pv_rowgemm.hip", "pv_backward.hip", "pv_train.hip", "pv_attnbwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 #: per-source extra flags.  The attention kernels keep MFMA results in VGPRs (the softmax VALU work reads them directly;
 #: AGPR-form costs ~200 v_accvgpr moves per tile); the 256-row GEMM variant needs the AGPR half for its accumulators.
@@ -24,7 +24,8 @@ EXTRA_FLAGS = {"pv_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-n
 
                "pv_xq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
                "pv_rowgemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "pv_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}   # attention backward: 136 accvgpr moves per tile otherwise
+               "pv_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+               "pv_attnbwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}   # attention backward: 136 accvgpr moves per tile otherwise
 
 
 def _hipcc() -> str:

@@ -516,6 +516,10 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][0], PREF ? negm[qi] : s[kb][qi], 0, 0, 0);
         }
+        // prologue call only (its own basic block): keep the 16-deep tail steps behind ALL the 32-deep ones.  hipcc is free to put a tail step two
+        // slots behind the 16x16x32 whose result it accumulates onto; in the backward passes (pv_attnbwd.hip, same two-shape chain) that schedule
+        // returned wrong sums, non-deterministically, once the wave ran at s_setprio 1.  The loop's copy is already in this order (the pins).
+        if (K48 && FIRST) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             if (K48) {

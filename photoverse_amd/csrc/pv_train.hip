@@ -14,6 +14,10 @@
 // Data gradients of every Linear / 3x3 convolution are the forward MFMA GEMM (pv_gemm_conv) on transposed / tap-flipped weights.
 #include "pv_common.h"
 
+// pv_attnbwd.hip: the 8-wave staggered form of the two passes at d = 40
+bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p);
+int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s);
+
 namespace {
 
 __device__ __forceinline__ half8_t tz8() { return half8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -1385,7 +1389,9 @@ extern "C" int pv_attention_backward(const pv_attn_bwd_params* p, void* stream) 
     if (!p || !p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->delta || !p->qs || !p->dq || !p->dk || !p->dv) return (int)hipErrorInvalidValue;
     if (p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nk <= 0) return (int)hipErrorInvalidValue;
     if ((p->ldq | p->ldk | p->ldv | p->ldo | p->lddo | p->lddq | p->lddk | p->lddv | p->ldqs) % 8) return (int)hipErrorInvalidValue;
+    if (p->ws != nullptr && p->ws_bytes < 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
+    if (pv_attn8_bwd_eligible(*p)) return pv_attn8_bwd_launch(*p, s);
     switch (p->d) {
         case 40: return launch_attn_bwd<40>(*p, s);
         case 64: return launch_attn_bwd<64>(*p, s);

@@ -380,9 +380,11 @@ class Recorder:
         dv = self.empty((batch * nk, C_)) if dv is None else dv
         delta = self.empty((batch, heads, nq), torch.float32)
         qs = self.empty((batch * nq, C_))
+        # workspace of the 8-wave staggered passes (pv_attnbwd.hip): scaled queries and dO head-major in 48-column rows
+        ws = self.empty((2 * batch * heads * nq, 48)) if (d == 40 and not causal and nq % 512 == 0 and nk % 512 == 0) else None
         p = AttnBwdParams(_ptr(q), _ptr(k), _ptr(v), _rows(q)[0], _rows(k)[0], _rows(v)[0], _ptr(out), _rows(out)[0], _ptr(dout), _rows(dout)[0],
                           _ptr(lse), _ptr(delta), _ptr(qs), C_, _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
-                          int(causal))
+                          int(causal), _ptr(ws), 0 if ws is None else ws.numel() * 2)
         self.keep.extend((q, k, v, out, dout, lse, dq, dk, dv))
         # five matrix products of 2 nq nk d each (S, dP, dV, dK, dQ): the usual algorithmic count of a flash backward
         self._add(self.lib.pv_attention_backward, p, tag=("pv_attention_backward", 10.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (4 * nq + 4 * nk)))

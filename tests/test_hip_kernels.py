@@ -933,6 +933,47 @@ def test_self_attention_backward(rec_cls, B, H, N, d, causal):
         assert rel_l2(dqkv[:, i * C:(i + 1) * C].float().cpu(), want[i]) < 4e-3, name
 
 
+@pytest.mark.parametrize("var", [0, 1, 81])
+@pytest.mark.parametrize("B,H,N,spiky", [(2, 2, 1024, False), (1, 3, 512, True)])
+def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, var, B, H, N, spiky):
+    """The d = 40 backward as 8-wave staggered dK/dV and dQ passes (pv_attnbwd.hip: -lse / -delta ride in the padding columns of the 48-deep
+    contractions as fp16 (hi, lo) pairs) against autograd through fp32 SDPA, and against the 4-wave kernels of pv_train.hip on the same input.
+    ``spiky``: one key row scaled by 12 - log-sum-exps of ~ +-60 log2 units, the range the (hi, lo) split has to carry."""
+    d = 40
+    g = torch.Generator().manual_seed(N + var)
+    C = H * d
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    if spiky:
+        qkv[(N * 3) // 5, C:2 * C] *= 12.0
+    dout = torch.randn(B * N, C, generator=g)
+    q32, k32, v32 = (qkv[:, i * C:(i + 1) * C].half().float().view(B, N, H, d).transpose(1, 2).clone().requires_grad_() for i in range(3))
+    ref = F.scaled_dot_product_attention(q32, k32, v32)
+    ref.backward(dout.half().float().view(B, N, H, d).transpose(1, 2))
+    want = [t.grad.transpose(1, 2).reshape(B * N, C) for t in (q32, k32, v32)]
+    x, do = qkv.half().cuda(), dout.half().cuda()
+    got = {}
+    for form in (var, -1):
+        monkeypatch.setenv("PV_ATTN8_BWD", str(form))
+        monkeypatch.setenv("PV_ATTN8_BWD_MIN", "1")
+        rec = rec_cls("cuda")
+        lse = rec.empty((B, H, N), torch.float32)
+        o = rec.attention(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], batch=B, heads=H, nq=N, nk=N, d=d, lse=lse)
+        dqkv = rec.empty((B * N, 3 * C))
+        dqkv.fill_(float("nan"))
+        rec.attention_backward(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], o, do, lse, batch=B, heads=H, nq=N, nk=N, d=d,
+                               dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+        rec.run()
+        torch.cuda.synchronize()
+        got[form] = dqkv.float().cpu()
+        assert torch.isfinite(got[form]).all()
+    for i, name in enumerate("qkv"):
+        sl = slice(i * C, (i + 1) * C)
+        e8, e4 = rel_l2(got[var][:, sl], want[i]), rel_l2(got[-1][:, sl], want[i])
+        assert e8 < 4e-3, (name, e8)
+        assert e8 < 1.5 * e4 + 2e-4, (name, e8, e4)          # no worse than the 4-wave kernels' fp16 operand rounding
+        assert rel_l2(got[var][:, sl], got[-1][:, sl]) < 2e-3, name
+
+
 @pytest.mark.parametrize("B,hw,c0,c1,act,with_add", [(2, 256, 320, 0, "silu", False), (1, 64, 640, 320, "silu", True), (2, 144, 320, 0, "none", True),
                                                       (1, 16, 1280, 1280, "silu", False)])
 def test_groupnorm_backward(rec_cls, B, hw, c0, c1, act, with_add):
