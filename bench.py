@@ -264,7 +264,23 @@ def train_step_leg(unet, B, S, dev, reps=3, with_face=True):
             o = one_face()
         torch.cuda.synchronize()
         fms = (time.perf_counter() - t1) * 1e3 / 2
-        face = {"ms_per_iteration": round(fms, 2), "face_samples": ns, "infer_steps": 10, "guidance_scale": 2.0,
+        # where the branch's time goes: its four launch plans replayed alone between events (eager launches on the current stream)
+        fb = ts.face
+
+        def plan_ms(rec, reps, state0):
+            fb.state.copy_(torch.tensor([state0, fb.T, 0, 0], dtype=torch.int32))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            rec.run()
+            fb.state.copy_(torch.tensor([state0, fb.T, 0, 0], dtype=torch.int32))
+            e0.record()
+            for _ in range(reps):
+                rec.run()
+            e1.record()
+            torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) / reps, 2)
+        pieces = {"conditioning": plan_ms(fb.rec_cond, 2, 0), "no_grad_step": plan_ms(fb.loop_tape.rf, 4, 0),
+                  "last_step_decode_loss": plan_ms(fb.rec_last, 2, fb.T - 1), "backward": plan_ms(fb.tape.rb, 2, fb.T - 1)}
+        face = {"ms_per_iteration": round(fms, 2), "plans_ms": pieces, "face_samples": ns, "infer_steps": 10, "guidance_scale": 2.0,
                 "face_loss": round(float(o["face_loss"]), 5), "loss": round(float(o["loss"]), 5), "finite": bool(torch.isfinite(o["loss"]).all().item()),
                 "launches": {"conditioning": len(ts.face.rec_cond), "no_grad_step": len(ts.face.loop_tape.rf), "last_step_decode_loss": len(ts.face.rec_last),
                              "backward": len(ts.face.tape.rb)}}

@@ -421,7 +421,8 @@ int launch_attn_bwd(const pv_attn_bwd_params& p, hipStream_t s) {
     const long bh = (long)p.batch * p.heads;
     static const int nf_env = getenv("PV_ATTN_BWD_NF") ? atoi(getenv("PV_ATTN_BWD_NF")) : -1;      // experiments: bit 0 = dK/dV, bit 1 = dQ
     const bool big = NFMAX == 2 && bh * ((p.nk + 127) / 128) >= 1024 && bh * ((p.nq + 127) / 128) >= 1024;
-    const bool two_kv = big && (nf_env < 0 ? D == 40 : (nf_env & 1)), two_q = big && (nf_env < 0 ? D == 40 : (nf_env & 2));
+    // d = 80 (N = 1024, B = 16): two fragments in the dQ pass only 343 -> 320 us, in both 327, in the dK/dV pass only 350 (profiles/r05_attn_bwd_d80_nf.txt)
+    const bool two_kv = big && (nf_env < 0 ? D == 40 : (nf_env & 1)), two_q = big && (nf_env < 0 ? (D == 40 || D == 80) : (nf_env & 2));
     if (two_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, NFMAX>), dim3((unsigned)(((p.nk + 127) / 128) * bh)), dim3(256), smem_dkv, s, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, 1>), dim3((unsigned)(((p.nk + 63) / 64) * bh)), dim3(256), smem_dkv, s, p);
     if (two_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, NFMAX>), dim3((unsigned)(((p.nq + 127) / 128) * bh)), dim3(256), smem_dq, s, p);
