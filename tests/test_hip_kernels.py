@@ -974,6 +974,42 @@ def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, va
         assert rel_l2(got[var][:, sl], got[-1][:, sl]) < 2e-3, name
 
 
+@pytest.mark.parametrize("B,N", [(16, 4096), (4, 4608), (3, 1536)])
+def test_self_attention_8wave_kernels_repeat_bit_for_bit_under_load(rec_cls, B, N):
+    """Race screen for the LDS-DMA rings and the segment schedules of attn8_kernel and attn8_bwd_kernel at the sizes that fill the chip: the kernels
+    have a fixed summation order, so 40 replays of forward + backward must return the same bits every time (the one wrong schedule hipcc produced for
+    these kernels returned different sums from run to run: EXPERIMENTS.md), and a sample of the rows is checked against fp32 autograd."""
+    H, d = 8, 40
+    C = H * d
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B * N, 3 * C, generator=g).half().cuda()
+    do = torch.randn(B * N, C, generator=g).half().cuda()
+    rec = rec_cls("cuda")
+    lse = rec.empty((B, H, N), torch.float32)
+    o = rec.attention(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], batch=B, heads=H, nq=N, nk=N, d=d, lse=lse)
+    dqkv = rec.empty((B * N, 3 * C))
+    rec.attention_backward(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], o, do, lse, batch=B, heads=H, nq=N, nk=N, d=d,
+                           dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+    rec.run()
+    torch.cuda.synchronize()
+    first = (o.clone(), dqkv.clone(), lse.clone())
+    for _ in range(40):
+        o.fill_(float("nan"))
+        dqkv.fill_(float("nan"))
+        rec.run()
+        torch.cuda.synchronize()
+        assert torch.equal(o, first[0]) and torch.equal(dqkv, first[1]) and torch.equal(lse, first[2])
+    # one (sample, head) against fp32 autograd
+    b, h = B - 1, H - 1
+    rows = slice(b * N, (b + 1) * N)
+    q32, k32, v32 = (x[rows, i * C + h * d:i * C + (h + 1) * d].float().clone().requires_grad_() for i in range(3))
+    ref = F.scaled_dot_product_attention(q32[None], k32[None], v32[None])[0]
+    ref.backward(do[rows, h * d:(h + 1) * d].float())
+    assert rel_l2(o[rows, h * d:(h + 1) * d].float().cpu(), ref.detach().cpu()) < 2e-3
+    for i, t in enumerate((q32, k32, v32)):
+        assert rel_l2(dqkv[rows, i * C + h * d:i * C + (h + 1) * d].float().cpu(), t.grad.cpu()) < 4e-3, "qkv"[i]
+
+
 @pytest.mark.parametrize("B,hw,c0,c1,act,with_add", [(2, 256, 320, 0, "silu", False), (1, 64, 640, 320, "silu", True), (2, 144, 320, 0, "none", True),
                                                       (1, 16, 1280, 1280, "silu", False)])
 def test_groupnorm_backward(rec_cls, B, hw, c0, c1, act, with_add):
