@@ -31,12 +31,25 @@
 
 namespace {
 
-constexpr int BD = 40;                 // head dimension
-constexpr int BRS = 48;                // LDS / workspace row stride in halfs (96 B: conflict-free ds_read_b64_tr_b16, ACfg<40>::VS)
-constexpr int BTILE = 64 * BRS;        // halfs of one 64-row tile image (6 KiB = six 1-KiB LDS-DMA pieces)
-constexpr int BSTAGE = 2 * BTILE;      // ring slot: matrix 0 (K | scaled Q) then matrix 1 (V | dO)
-constexpr int BNF = 4;                 // 16-row fragments of the owned side per wave
-constexpr int BDT = 3;                 // 16-row fragments of the d-major gradient accumulators (48 rows, 40 stored)
+// Per head dimension: row stride RS of the LDS / workspace images in halfs (a multiple of 8 x odd dwords: conflict-free ds_read_b64_tr_b16, ACfg::VS),
+// fragments per wave NF (owned rows per workgroup = 8 waves x NF x 16), d-major accumulator fragments DT, contraction = KS32 32-deep steps (+ a
+// 16-deep TAIL).  The statistics columns sit right behind the data: d = 40: columns 40 / 41 inside the 16-deep tail (48-deep contraction);
+// d = 80: columns 80 / 81 inside a third 32-deep step (96-deep; 64 + 16 + a fourth 16-deep step for the two columns would cost the same cycles).
+template <int D> struct BW;
+template <> struct BW<40> { static constexpr int RS = 48, NF = 4, DT = 3, KS32 = 1; static constexpr bool TAIL = true; };
+template <> struct BW<80> { static constexpr int RS = 112, NF = 2, DT = 5, KS32 = 3; static constexpr bool TAIL = false; };
+template <int D> struct BWD : BW<D> {
+    using B = BW<D>;
+    static constexpr int CPR = B::RS / 8;                 // 16-byte chunks per image row
+    static constexpr int DCH = D / 8;                     // data chunks; chunk DCH = {1 | -stat hi, 1 | -stat lo, 0 x 6}
+    static constexpr int KCH = (B::KS32 * 32 + (B::TAIL ? 16 : 0)) / 8;      // chunks the contractions read (the ones behind DCH are zero)
+    static constexpr int TILE = 64 * B::RS;               // halfs of a 64-row tile image
+    static constexpr int PPM = TILE * 2 / 1024;           // 1-KiB LDS-DMA pieces per matrix
+    static constexpr int STAGE = 2 * TILE;                // ring slot: matrix 0 (K | scaled Q) then matrix 1 (V | dO)
+    static constexpr int OWN = 8 * B::NF * 16;            // owned rows per workgroup
+    static constexpr int NIT = (2 * PPM + 7) / 8;         // LDS-DMA instructions per wave and tile
+    static_assert(TILE * 2 % 1024 == 0 && D % 8 == 0 && KCH <= CPR && DCH < KCH, "image layout");
+};
 
 #ifdef PV_ATTN8_BWD_STAMPS
 __device__ unsigned long long pv_attn8_bwd_stamps[2 * 8 * 8];
@@ -44,8 +57,15 @@ __device__ unsigned long long pv_attn8_bwd_stamps[2 * 8 * 8];
 #endif
 
 __device__ __forceinline__ half8_t bz8() { return half8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ half8_t bone8() {
+    half8_t v = bz8();
+    v[0] = (half_t)1.0f;
+    v[1] = (half_t)1.0f;
+    return v;
+}
 
-// fp16 (hi, lo) pair of a float: hi + lo == x to ~2^-22 relative for normal-range x (exact products with the 1.0 columns, fp32 accumulate)
+// fp16 (hi, lo) pair of a float in columns 0 / 1 of a chunk: hi + lo == x to ~2^-22 relative for normal-range x (exact products with the 1.0
+// columns, fp32 accumulate)
 __device__ __forceinline__ half8_t split_hi_lo(float x) {
     half8_t t = bz8();
     t[0] = (half_t)x;
@@ -53,25 +73,27 @@ __device__ __forceinline__ half8_t split_hi_lo(float x) {
     return t;
 }
 
-// qs48[b][h][q][48] = {fp16(q * scale * log2 e) (the forward kernel's rounding), -lse (hi, lo), 0 x 6};  do48 = {dO, -delta (hi, lo), 0 x 6};
-// delta[b][h][q] = sum_c dO[q][c] O[q][c].  One thread per (row, head), heads fastest: a wave reads eight whole 640-B rows.
-__global__ __launch_bounds__(256) void attn8_bwd_prep_kernel(const pv_attn_bwd_params p, half_t* __restrict__ qs48, half_t* __restrict__ do48) {
+// qs[b][h][q][RS] = {fp16(q * scale * log2 e) (the forward kernel's rounding), -lse (hi, lo), zeros up to the contraction length};
+// dos = {dO, -delta (hi, lo), zeros};  delta[b][h][q] = sum_c dO[q][c] O[q][c].  One thread per (row, head), heads fastest: a wave reads whole rows.
+template <int D>
+__global__ __launch_bounds__(256) void attn8_bwd_prep_kernel(const pv_attn_bwd_params p, half_t* __restrict__ qs_ws, half_t* __restrict__ do_ws) {
+    using C = BWD<D>;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.batch * p.nq * p.heads;
     if (idx >= total) return;
     const int h = (int)(idx % p.heads);
     const long row = idx / p.heads;                                  // b * nq + q
     const int q = (int)(row % p.nq), b = (int)(row / p.nq);
-    const half_t* o = reinterpret_cast<const half_t*>(p.out) + (size_t)row * p.ldo + h * BD;
-    const half_t* g = reinterpret_cast<const half_t*>(p.dout) + (size_t)row * p.lddo + h * BD;
-    const half_t* qr = reinterpret_cast<const half_t*>(p.q) + (size_t)row * p.ldq + h * BD;
+    const half_t* o = reinterpret_cast<const half_t*>(p.out) + (size_t)row * p.ldo + h * D;
+    const half_t* g = reinterpret_cast<const half_t*>(p.dout) + (size_t)row * p.lddo + h * D;
+    const half_t* qr = reinterpret_cast<const half_t*>(p.q) + (size_t)row * p.ldq + h * D;
     const size_t bhq = ((size_t)b * p.heads + h) * p.nq + q;
-    half_t* qs = qs48 + bhq * BRS;
-    half_t* ds = do48 + bhq * BRS;
-    const float qscale = rsqrtf((float)BD) * 1.4426950408889634f;
+    half_t* qs = qs_ws + bhq * C::RS;
+    half_t* ds = do_ws + bhq * C::RS;
+    const float qscale = rsqrtf((float)D) * 1.4426950408889634f;
     float a = 0.f;
 #pragma unroll
-    for (int c = 0; c < BD; c += 8) {
+    for (int c = 0; c < D; c += 8) {
         const half8_t x = *reinterpret_cast<const half8_t*>(o + c), y = *reinterpret_cast<const half8_t*>(g + c);
         const half8_t qv = *reinterpret_cast<const half8_t*>(qr + c);
         half8_t sv;
@@ -84,15 +106,21 @@ __global__ __launch_bounds__(256) void attn8_bwd_prep_kernel(const pv_attn_bwd_p
         *reinterpret_cast<half8_t*>(ds + c) = y;
     }
     p.delta[bhq] = a;
-    *reinterpret_cast<half8_t*>(qs + BD) = split_hi_lo(-p.lse[bhq]);
-    *reinterpret_cast<half8_t*>(ds + BD) = split_hi_lo(-a);
+    *reinterpret_cast<half8_t*>(qs + D) = split_hi_lo(-p.lse[bhq]);
+    *reinterpret_cast<half8_t*>(ds + D) = split_hi_lo(-a);
+#pragma unroll
+    for (int ch = C::DCH + 1; ch < C::KCH; ++ch) {
+        *reinterpret_cast<half8_t*>(qs + ch * 8) = bz8();
+        *reinterpret_cast<half8_t*>(ds + ch * 8) = bz8();
+    }
 }
 
-// A fragment of the TRANSPOSE of a [rows][48] image: output rows d = dv0 + fr.., the 8 contraction slots {r0 + 4 fq .. + 3, r0 + 16 + 4 fq .. + 3}
+// A fragment of the TRANSPOSE of a [rows][RS] image: output rows d = dv0 + fr.., the 8 contraction slots {r0 + 4 fq .. + 3, r0 + 16 + 4 fq .. + 3}
+template <int RS>
 __device__ __forceinline__ half8_t bt_frag(const half_t* sR, int r0, int dv0, int fr, int fq) {
-    const half_t* a = sR + (r0 + fq * 4 + (fr >> 2)) * BRS + dv0 + (fr & 3) * 4;
+    const half_t* a = sR + (r0 + fq * 4 + (fr >> 2)) * RS + dv0 + (fr & 3) * 4;
     const fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
-    const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * BRS));
+    const fp16x4_t t2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a + 16 * RS));
     const half4_t h1 = __builtin_bit_cast(half4_t, t1), h2 = __builtin_bit_cast(half4_t, t2);
     return __builtin_shufflevector(h1, h2, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -103,8 +131,11 @@ __device__ __forceinline__ half8_t bt_frag(const half_t* sR, int r0, int dv0, in
 // already gives that schedule).  Measured (EXPERIMENTS.md round 5, B = 16, N = 4096, sustained, same box): 4-wave passes 2 035 us; 0: 1 580;
 // 1: 1 480 -> 1 396 with the three-pass vector segment; 81 (default): 1 276-1 310; static priority for waves 4-7, priority in the VECTOR segment
 // and a prefetch of the dQ pass's K^T fragments at the head of the vector segment (attn8_kernel's bits 6 + 8): 1 362 / 1 506 / +2 % - removed.
-template <bool KV, int VAR>
+template <int BD, bool KV, int VAR>
 __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_params p, const half_t* __restrict__ qs48, const half_t* __restrict__ do48) {
+    using C = BWD<BD>;
+    constexpr int BRS = C::RS, BNF = C::NF, BDT = C::DT, BTILE = C::TILE, BSTAGE = C::STAGE, KS32 = C::KS32;
+    constexpr bool TAIL = C::TAIL;
     constexpr bool STAGGER = (VAR & 1) != 0, SEGPRIO = (VAR & 16) != 0, PRO_PRIO = SEGPRIO;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sbase = reinterpret_cast<half_t*>(smem);
@@ -112,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
     const int fr = lane & 15, fq = lane >> 4;
     const bool late = STAGGER && wave >= 4;
     const int n_own = KV ? p.nk : p.nq, n_walk = KV ? p.nq : p.nk;
-    const int nwt = n_own / 512;
+    const int nwt = n_own / C::OWN;
     const int rid = pv_xcd_remap((int)blockIdx.x, (int)gridDim.x);     // the workgroups of one (sample, head) share an XCD: its L2 holds the walked side once
     const int ot = rid % nwt, h = (rid / nwt) % p.heads, b = rid / (nwt * p.heads);
     const size_t bh = (size_t)b * p.heads + h;
@@ -122,37 +153,44 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
     const half_t* DOs = do48 + bh * p.nq * BRS;
 
     if (!KV) {
-        // columns 40 / 41 of every K and V row in the ring = 1.0 (they meet -lse / -delta of the query rows), 42-47 = 0; the LDS-DMA leaves this chunk alone
+        // columns D / D + 1 of every K and V row in the ring = 1.0 (they meet -lse / -delta of the query rows), the rest of the contraction length = 0;
+        // the LDS-DMA leaves these chunks alone
         for (int i = tid; i < 4 * 2 * 64; i += 512) {
-            half8_t v = bz8();
-            v[0] = (half_t)1.0f;
-            v[1] = (half_t)1.0f;
-            *reinterpret_cast<half8_t*>(sbase + (i >> 7) * BSTAGE + ((i >> 6) & 1) * BTILE + (i & 63) * BRS + BD) = v;
+            half_t* row = sbase + (i >> 7) * BSTAGE + ((i >> 6) & 1) * BTILE + (i & 63) * BRS;
+            *reinterpret_cast<half8_t*>(row + BD) = bone8();
+#pragma unroll
+            for (int ch = C::DCH + 1; ch < C::KCH; ++ch) *reinterpret_cast<half8_t*>(row + ch * 8) = bz8();
         }
     }
 
-    // ---- the owned side: B operands (column = own row fr of fragment i; k slots: 8 fq .. + 7 of the 32-deep step, 32 + 4 fq .. + 3 of the tail)
-    half8_t b0[BNF], b1[BNF];          // matrix 0 (K | scaled Q), matrix 1 (V | dO)
-    half4_t t0[BNF], t1[BNF];
+    // ---- the owned side: B operands (column = own row fr of fragment i; k slots: 32 ks + 8 fq .. + 7 of a 32-deep step, 32 KS32 + 4 fq .. + 3 of the tail)
+    half8_t b0[BNF][KS32], b1[BNF][KS32];          // matrix 0 (K | scaled Q), matrix 1 (V | dO)
+    half4_t t0[TAIL ? BNF : 1], t1[TAIL ? BNF : 1];
     int orow[BNF];
 #pragma unroll
     for (int i = 0; i < BNF; ++i) {
-        orow[i] = ot * 512 + (wave * BNF + i) * 16 + fr;
-        if constexpr (KV) {
-            const half_t* kr = Kg + (size_t)orow[i] * p.ldk;
-            const half_t* vr = Vg + (size_t)orow[i] * p.ldv;
-            b0[i] = *reinterpret_cast<const half8_t*>(kr + fq * 8);
-            b1[i] = *reinterpret_cast<const half8_t*>(vr + fq * 8);
+        orow[i] = ot * C::OWN + (wave * BNF + i) * 16 + fr;
+        const half_t* r0p = KV ? Kg + (size_t)orow[i] * p.ldk : Qs + (size_t)orow[i] * BRS;
+        const half_t* r1p = KV ? Vg + (size_t)orow[i] * p.ldv : DOs + (size_t)orow[i] * BRS;
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            const int ch = ks * 4 + fq;                  // K / V rows end at column D: the statistics chunk is 1.0 there, zeros behind it
+            if (!KV || ch < C::DCH) {
+                b0[i][ks] = *reinterpret_cast<const half8_t*>(r0p + ch * 8);
+                b1[i][ks] = *reinterpret_cast<const half8_t*>(r1p + ch * 8);
+            } else {
+                b0[i][ks] = b1[i][ks] = ch == C::DCH ? bone8() : bz8();
+            }
+        }
+        if constexpr (TAIL) {
+            const int col = KS32 * 32 + fq * 4;
             const half4_t one = half4_t{(half_t)1.0f, (half_t)1.0f, 0, 0}, zero = half4_t{0, 0, 0, 0};
-            t0[i] = fq < 2 ? *reinterpret_cast<const half4_t*>(kr + 32 + fq * 4) : (fq == 2 ? one : zero);
-            t1[i] = fq < 2 ? *reinterpret_cast<const half4_t*>(vr + 32 + fq * 4) : (fq == 2 ? one : zero);
-        } else {
-            const half_t* qr = Qs + (size_t)orow[i] * BRS;
-            const half_t* dr = DOs + (size_t)orow[i] * BRS;
-            b0[i] = *reinterpret_cast<const half8_t*>(qr + fq * 8);
-            b1[i] = *reinterpret_cast<const half8_t*>(dr + fq * 8);
-            t0[i] = *reinterpret_cast<const half4_t*>(qr + 32 + fq * 4);
-            t1[i] = *reinterpret_cast<const half4_t*>(dr + 32 + fq * 4);
+            if (!KV || col < BD) {
+                t0[i] = *reinterpret_cast<const half4_t*>(r0p + col);
+                t1[i] = *reinterpret_cast<const half4_t*>(r1p + col);
+            } else {
+                t0[i] = t1[i] = col == BD ? one : zero;
+            }
         }
     }
     float4_t accA[KV ? BNF : 1][BDT], accB[BNF][BDT];
@@ -170,34 +208,44 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
     auto sdp = [&](int j) {
         const half_t* s0 = sbase + ((j >> 1) & 3) * BSTAGE + (j & 1) * 32 * BRS;
         const half_t* s1 = s0 + BTILE;
-        half8_t a0[2], a1[2];
+        half8_t a0[2][KS32], a1[2][KS32];
         half4_t c0[2], c1[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int off = (rb * 16 + fr) * BRS;
-            a0[rb] = *reinterpret_cast<const half8_t*>(s0 + off + fq * 8);
-            a1[rb] = *reinterpret_cast<const half8_t*>(s1 + off + fq * 8);
-            c0[rb] = *reinterpret_cast<const half4_t*>(s0 + off + 32 + fq * 4);
-            c1[rb] = *reinterpret_cast<const half4_t*>(s1 + off + 32 + fq * 4);
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+                a0[rb][ks] = *reinterpret_cast<const half8_t*>(s0 + off + ks * 32 + fq * 8);
+                a1[rb][ks] = *reinterpret_cast<const half8_t*>(s1 + off + ks * 32 + fq * 8);
+            }
+            if constexpr (TAIL) {
+                c0[rb] = *reinterpret_cast<const half4_t*>(s0 + off + KS32 * 32 + fq * 4);
+                c1[rb] = *reinterpret_cast<const half4_t*>(s1 + off + KS32 * 32 + fq * 4);
+            }
         }
         const float4_t z = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int ks = 0; ks < KS32; ++ks) {
 #pragma unroll
-            for (int i = 0; i < BNF; ++i) {
-                s[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[rb], b0[i], z, 0, 0, 0);
-                dp[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[rb], b1[i], z, 0, 0, 0);
-            }
-        // the sixteen tail steps stay BEHIND the sixteen 32-deep ones (a tail step scheduled right behind the MFMA whose result it accumulates onto
-        // waits for that MFMA's eight passes)
-        __builtin_amdgcn_sched_barrier(0);
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+                for (int i = 0; i < BNF; ++i) {
+                    s[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[rb][ks], b0[i][ks], ks == 0 ? z : s[rb][i], 0, 0, 0);
+                    dp[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[rb][ks], b1[i][ks], ks == 0 ? z : dp[rb][i], 0, 0, 0);
+                }
+            // every step of a chain stays a whole group of independent MFMAs behind the one it accumulates onto: a 16x16x16 tail that hipcc put
+            // ONE instruction behind its 16x16x32 returned wrong sums (EXPERIMENTS.md, round 5)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TAIL) {
 #pragma unroll
-            for (int i = 0; i < BNF; ++i) {
-                s[rb][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(c0[rb], t0[i], s[rb][i], 0, 0, 0);
-                dp[rb][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(c1[rb], t1[i], dp[rb][i], 0, 0, 0);
-            }
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int i = 0; i < BNF; ++i) {
+                    s[rb][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(c0[rb], t0[i], s[rb][i], 0, 0, 0);
+                    dp[rb][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(c1[rb], t1[i], dp[rb][i], 0, 0, 0);
+                }
+        }
     };
     // ---- vector segment: P = exp2(S'), dS = P dP' -> fp16 B operands (k slots {4 fq + r, 16 + 4 fq + r} of the step's 32 walked rows: the
     //      order the transposed fragment reads below use)
@@ -234,9 +282,9 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
         const int r0 = (j & 1) * 32;
 #pragma unroll
         for (int f = 0; f < BDT; ++f) {
-            const half8_t x0 = bt_frag(s0, r0, f * 16, fr, fq);
+            const half8_t x0 = bt_frag<BRS>(s0, r0, f * 16, fr, fq);
             if constexpr (KV) {
-                const half8_t x1 = bt_frag(s1, r0, f * 16, fr, fq);
+                const half8_t x1 = bt_frag<BRS>(s1, r0, f * 16, fr, fq);
 #pragma unroll
                 for (int i = 0; i < BNF; ++i) accA[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, pb[i], accA[i][f], 0, 0, 0);
             }
@@ -245,30 +293,35 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
         }
     };
 
-    // ---- LDS-DMA: a tile = 12 pieces of 1 KiB (6 per matrix); wave w stages piece w, waves 0-3 also piece w + 8
+    // ---- LDS-DMA: a tile = 2 PPM pieces of 1 KiB (PPM per matrix); wave w stages pieces w, w + 8, ...
     const __amdgpu_buffer_rsrc_t r0 = KV ? __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Qs), 0, p.nq * BRS * 2, 0x00020000)
                                          : __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Kg), 0, ((p.nk - 1) * p.ldk + BD) * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = KV ? __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(DOs), 0, p.nq * BRS * 2, 0x00020000)
                                          : __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Vg), 0, ((p.nk - 1) * p.ldv + BD) * 2, 0x00020000);
-    // piece pc (0-5) of a matrix: lane -> 16-B chunk 64 pc + lane of the [64][6] image
-    auto lane_off = [&](int pc, int ld, bool& live) -> unsigned {
-        const int c = 64 * pc + lane, row = c / 6, ch = c - row * 6;
-        live = KV || ch < 5;                              // K / V: chunk 5 of a row is the constant pad chunk
-        return KV ? (unsigned)(c * 16) : (unsigned)(row * ld * 2 + ch * 16);
-    };
-    const bool first_m1 = wave >= 6;                      // pieces 6, 7 are matrix 1's pieces 0, 1
-    bool liveA, liveB;
-    const unsigned offA = lane_off(first_m1 ? wave - 6 : wave, first_m1 ? p.ldv : p.ldk, liveA);
-    const unsigned offB = lane_off(wave + 2, p.ldv, liveB);          // waves 0-3: piece w + 8 = matrix 1's piece w + 2
-    const int ldsA = (first_m1 ? BTILE * 2 + (wave - 6) * 1024 : wave * 1024), ldsB = BTILE * 2 + (wave + 2) * 1024;
+    // piece pc of matrix m: lane -> 16-byte chunk 64 pc + lane of the [64][CPR] image; K / V rows bring their data chunks only (the constant chunks
+    // were written once), workspace rows everything the contractions read
+    unsigned poff[C::NIT];
+    int plds[C::NIT];
+    bool plive[C::NIT];
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+        const int pc = wave + 8 * it, m = pc >= C::PPM ? 1 : 0, pcl = pc - m * C::PPM;
+        const int c = 64 * pcl + lane, row = c / C::CPR, ch = c - row * C::CPR;
+        plive[it] = pc < 2 * C::PPM && ch < (KV ? C::KCH : C::DCH);
+        poff[it] = KV ? (unsigned)(c * 16) : (unsigned)(row * (m ? p.ldv : p.ldk) * 2 + ch * 16);
+        plds[it] = m * BTILE * 2 + pcl * 1024;
+    }
     const int step0 = KV ? BTILE * 2 : 64 * p.ldk * 2, step1 = KV ? BTILE * 2 : 64 * p.ldv * 2;     // bytes per tile in the source
     auto issue_tile = [&](int t) {
         char* slot = reinterpret_cast<char*>(sbase + (t & 3) * BSTAGE);
-        if (liveA) {
-            if (first_m1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, PV_LDS_PTR(slot + ldsA), 16, (int)offA, t * step1, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, PV_LDS_PTR(slot + ldsA), 16, (int)offA, t * step0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const bool m1 = wave + 8 * it >= C::PPM;      // wave-uniform
+            if (plive[it]) {
+                if (m1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, PV_LDS_PTR(slot + plds[it]), 16, (int)poff[it], t * step1, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, PV_LDS_PTR(slot + plds[it]), 16, (int)poff[it], t * step0, 0, 0);
+            }
         }
-        if (wave < 4 && liveB) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, PV_LDS_PTR(slot + ldsB), 16, (int)offB, t * step1, 0, 0);
     };
     auto interval = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -399,38 +452,59 @@ extern "C" int pv_attn8_bwd_read_stamps(unsigned long long* out) {
 }
 #endif
 
-// bytes of workspace pv_attention_backward needs to take this path
-size_t pv_attn8_bwd_ws_bytes(const pv_attn_bwd_params& p) { return (size_t)2 * p.batch * p.heads * p.nq * BRS * sizeof(half_t); }
+namespace {
+template <int D>
+int launch_attn8_bwd(const pv_attn_bwd_params& p, hipStream_t s, int var) {
+    using C = BWD<D>;
+    void (*kq)(const pv_attn_bwd_params, const half_t*, const half_t*) = nullptr;
+    void (*kkv)(const pv_attn_bwd_params, const half_t*, const half_t*) = nullptr;
+    switch (var) {
+#define PV_B8_CASE(V) case V: kq = attn8_bwd_kernel<D, false, V>; kkv = attn8_bwd_kernel<D, true, V>; break;
+        PV_B8_CASE(0) PV_B8_CASE(1) PV_B8_CASE(65) PV_B8_CASE(81)
+#undef PV_B8_CASE
+        default: return (int)hipErrorInvalidValue;
+    }
+    constexpr int smem = 4 * C::STAGE * 2;                // d = 40: 48 KiB; d = 80: 112 KiB
+    static bool attr_set[64][128] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63][var & 127]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev & 63][var & 127] = true;
+    }
+    half_t* qs = reinterpret_cast<half_t*>(p.ws);
+    half_t* dos = qs + (size_t)p.batch * p.heads * p.nq * C::RS;
+    const long rows = (long)p.batch * p.nq * p.heads;
+    hipLaunchKernelGGL(attn8_bwd_prep_kernel<D>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p, qs, dos);
+    const unsigned bh = (unsigned)(p.batch * p.heads);
+    hipLaunchKernelGGL(kkv, dim3(bh * (unsigned)(p.nk / C::OWN)), dim3(512), smem, s, p, (const half_t*)qs, (const half_t*)dos);
+    hipLaunchKernelGGL(kq, dim3(bh * (unsigned)(p.nq / C::OWN)), dim3(512), smem, s, p, (const half_t*)qs, (const half_t*)dos);
+    return PV_CHECK_LAUNCH();
+}
+}  // namespace
+
+// bytes of workspace pv_attention_backward needs to take this path: scaled queries and dO head-major in RS-column rows
+size_t pv_attn8_bwd_ws_bytes(const pv_attn_bwd_params& p) {
+    return (size_t)2 * p.batch * p.heads * p.nq * (p.d == 80 ? BWD<80>::RS : BWD<40>::RS) * sizeof(half_t);
+}
 
 bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p) {
-    if (p.d != BD || p.causal || p.nq % 512 || p.nk % 512 || !p.ws) return false;
+    if ((p.d != 40 && p.d != 80) || p.causal || !p.ws) return false;
+    const int own = p.d == 80 ? BWD<80>::OWN : BWD<40>::OWN, rs = p.d == 80 ? BWD<80>::RS : BWD<40>::RS;
+    if (p.nq % own || p.nk % own) return false;
     if ((size_t)p.ws_bytes < pv_attn8_bwd_ws_bytes(p)) return false;
-    if ((size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 >= (1ull << 31) || (size_t)p.nq * BRS * 2 >= (1ull << 31)) return false;
+    if ((size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 >= (1ull << 31) || (size_t)p.nq * rs * 2 >= (1ull << 31)) return false;
     const char* env = getenv("PV_ATTN8_BWD");             // read per call (tests run both forms in one process); -1 = the 4-wave kernels
     if (env && atoi(env) < 0) return false;
-    const char* envmin = getenv("PV_ATTN8_BWD_MIN");      // fewest 512-row workgroups a pass must have (default: half the CUs)
-    const long wgs = (long)p.batch * p.heads * ((p.nq < p.nk ? p.nq : p.nk) / 512);
+    const char* envmin = getenv("PV_ATTN8_BWD_MIN");      // fewest workgroups a pass must have (default: half the CUs)
+    const long wgs = (long)p.batch * p.heads * ((p.nq < p.nk ? p.nq : p.nk) / own);
     return wgs >= (envmin ? atol(envmin) : 128);
 }
 
 int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s) {
     const char* env = getenv("PV_ATTN8_BWD");
     const int var = env ? atoi(env) : PV_ATTN8_BWD_DEFAULT;
-    void (*kq)(const pv_attn_bwd_params, const half_t*, const half_t*) = nullptr;
-    void (*kkv)(const pv_attn_bwd_params, const half_t*, const half_t*) = nullptr;
-    switch (var) {
-#define PV_B8_CASE(V) case V: kq = attn8_bwd_kernel<false, V>; kkv = attn8_bwd_kernel<true, V>; break;
-        PV_B8_CASE(0) PV_B8_CASE(1) PV_B8_CASE(65) PV_B8_CASE(81)
-#undef PV_B8_CASE
-        default: return (int)hipErrorInvalidValue;
-    }
-    constexpr int smem = 4 * BSTAGE * 2;                  // 48 KiB
-    half_t* qs48 = reinterpret_cast<half_t*>(p.ws);
-    half_t* do48 = qs48 + (size_t)p.batch * p.heads * p.nq * BRS;
-    const long rows = (long)p.batch * p.nq * p.heads;
-    hipLaunchKernelGGL(attn8_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p, qs48, do48);
-    const unsigned bh = (unsigned)(p.batch * p.heads);
-    hipLaunchKernelGGL(kkv, dim3(bh * (unsigned)(p.nk / 512)), dim3(512), smem, s, p, (const half_t*)qs48, (const half_t*)do48);
-    hipLaunchKernelGGL(kq, dim3(bh * (unsigned)(p.nq / 512)), dim3(512), smem, s, p, (const half_t*)qs48, (const half_t*)do48);
-    return PV_CHECK_LAUNCH();
+    return p.d == 80 ? launch_attn8_bwd<80>(p, s, var) : launch_attn8_bwd<40>(p, s, var);
 }

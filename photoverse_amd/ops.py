@@ -380,8 +380,9 @@ class Recorder:
         dv = self.empty((batch * nk, C_)) if dv is None else dv
         delta = self.empty((batch, heads, nq), torch.float32)
         qs = self.empty((batch * nq, C_))
-        # workspace of the 8-wave staggered passes (pv_attnbwd.hip): scaled queries and dO head-major in 48-column rows
-        ws = self.empty((2 * batch * heads * nq, 48)) if (d == 40 and not causal and nq % 512 == 0 and nk % 512 == 0) else None
+        # workspace of the 8-wave staggered passes (pv_attnbwd.hip, d = 40 / 80): scaled queries and dO head-major in 48- / 112-column rows
+        ws_cols, own = {40: (48, 512), 80: (112, 256)}.get(d, (0, 1))
+        ws = self.empty((2 * batch * heads * nq, ws_cols)) if (ws_cols and not causal and nq % own == 0 and nk % own == 0) else None
         p = AttnBwdParams(_ptr(q), _ptr(k), _ptr(v), _rows(q)[0], _rows(k)[0], _rows(v)[0], _ptr(out), _rows(out)[0], _ptr(dout), _rows(dout)[0],
                           _ptr(lse), _ptr(delta), _ptr(qs), C_, _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
                           int(causal), _ptr(ws), 0 if ws is None else ws.numel() * 2)

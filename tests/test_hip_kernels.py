@@ -934,12 +934,12 @@ def test_self_attention_backward(rec_cls, B, H, N, d, causal):
 
 
 @pytest.mark.parametrize("var", [0, 1, 81])
-@pytest.mark.parametrize("B,H,N,spiky", [(2, 2, 1024, False), (1, 3, 512, True)])
-def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, var, B, H, N, spiky):
-    """The d = 40 backward as 8-wave staggered dK/dV and dQ passes (pv_attnbwd.hip: -lse / -delta ride in the padding columns of the 48-deep
+@pytest.mark.parametrize("B,H,N,d,spiky", [(2, 2, 1024, 40, False), (1, 3, 512, 40, True), (2, 2, 768, 80, False), (1, 2, 256, 80, True)])
+def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, var, B, H, N, d, spiky):
+    """The d = 40 / 80 backward as 8-wave staggered dK/dV and dQ passes (pv_attnbwd.hip: -lse / -delta ride in the padding columns of the 48-deep
     contractions as fp16 (hi, lo) pairs) against autograd through fp32 SDPA, and against the 4-wave kernels of pv_train.hip on the same input.
-    ``spiky``: one key row scaled by 12 - log-sum-exps of ~ +-60 log2 units, the range the (hi, lo) split has to carry."""
-    d = 40
+    ``spiky``: one key row scaled by 12 - log-sum-exps of ~ +-60 log2 units, the range the (hi, lo) split has to carry.  d = 80: two fragments per wave,
+    256 owned rows per workgroup, 96-deep contractions with the statistics in columns 80 / 81."""
     g = torch.Generator().manual_seed(N + var)
     C = H * d
     qkv = torch.randn(B * N, 3 * C, generator=g)
@@ -974,12 +974,13 @@ def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, va
         assert rel_l2(got[var][:, sl], got[-1][:, sl]) < 2e-3, name
 
 
-@pytest.mark.parametrize("B,N", [(16, 4096), (4, 4608), (3, 1536)])
-def test_self_attention_8wave_kernels_repeat_bit_for_bit_under_load(rec_cls, B, N):
+@pytest.mark.parametrize("B,N,d", [(16, 4096, 40), (4, 4608, 40), (3, 1536, 40), (16, 1024, 80), (5, 2304, 80)])
+def test_self_attention_8wave_kernels_repeat_bit_for_bit_under_load(rec_cls, B, N, d):
     """Race screen for the LDS-DMA rings and the segment schedules of attn8_kernel and attn8_bwd_kernel at the sizes that fill the chip: the kernels
     have a fixed summation order, so 40 replays of forward + backward must return the same bits every time (the one wrong schedule hipcc produced for
-    these kernels returned different sums from run to run: EXPERIMENTS.md), and a sample of the rows is checked against fp32 autograd."""
-    H, d = 8, 40
+    these kernels returned different sums from run to run: EXPERIMENTS.md), and a sample of the rows is checked against fp32 autograd.  (d = 80: the
+    backward passes only are 8-wave kernels.)"""
+    H = 8
     C = H * d
     g = torch.Generator().manual_seed(N)
     x = torch.randn(B * N, 3 * C, generator=g).half().cuda()

@@ -2,7 +2,7 @@
 """Self-attention backward d = 40: the 4-wave passes of pv_train.hip (PV_ATTN8_BWD=-1) against the 8-wave staggered passes of pv_attnbwd.hip
 (variant bits: 1 stagger, 16 s_setprio 1 in the matrix segments), one process per variant, several rounds on ONE box, sustained timing.
 
-usage (GPU box): python tools/diag/attn8_bwd_ab.py [rounds] [variants, comma separated; -1 = the 4-wave kernels] [batch] [n]"""
+usage (GPU box): python tools/diag/attn8_bwd_ab.py [rounds] [variants, comma separated; -1 = the 4-wave kernels] [batch] [n] [d]"""
 import os
 import subprocess
 import sys
@@ -15,7 +15,7 @@ import torch.nn.functional as F
 sys.path.insert(0, %r)
 from photoverse_amd.ops import Recorder
 dev = torch.device("cuda")
-B, n, H, d = int(sys.argv[2]), int(sys.argv[3]), 8, 40
+B, n, H, d = int(sys.argv[2]), int(sys.argv[3]), 8, int(sys.argv[4])
 C = H * d
 g = torch.Generator().manual_seed(7)
 qkv = torch.randn(B * n, 3 * C, generator=g).half().cuda()
@@ -56,14 +56,15 @@ def main():
     variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["-1", "0", "1", "17"])]
     B = sys.argv[3] if len(sys.argv) > 3 else "16"
     n = sys.argv[4] if len(sys.argv) > 4 else "4096"
+    d = sys.argv[5] if len(sys.argv) > 5 else "40"
     for v in variants:
         env = dict(os.environ, PV_ATTN8_BWD=str(v))
-        r = subprocess.run([sys.executable, "-c", CHILD, "check", B, n], env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", CHILD, "check", B, n, d], env=env, capture_output=True, text=True, timeout=900)
         print("== variant %d  (check)\n%s%s" % (v, r.stdout, r.stderr[-2000:] if r.returncode else ""), flush=True)
     for i in range(rounds):
         for v in variants:
             env = dict(os.environ, PV_ATTN8_BWD=str(v))
-            r = subprocess.run([sys.executable, "-c", CHILD, "time", B, n], env=env, capture_output=True, text=True, timeout=900)
+            r = subprocess.run([sys.executable, "-c", CHILD, "time", B, n, d], env=env, capture_output=True, text=True, timeout=900)
             print("round %d  variant %2d  %s" % (i, v, r.stdout.strip() or r.stderr[-500:]), flush=True)
 
 
