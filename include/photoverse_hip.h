@@ -174,8 +174,9 @@ typedef struct pv_attn_bwd_params {
     int32_t lddq, lddk, lddv;
     int32_t batch, heads, nq, nk, d;
     int32_t causal;
-    void* ws; int64_t ws_bytes;      /* optional workspace: with >= 2 * batch * heads * nq * 96 bytes the d = 40 / unmasked / nq, nk % 512 == 0
-                                      * launches take the 8-wave staggered kernels (pv_attnbwd.hip); NULL = the 4-wave kernels */
+    void* ws; int64_t ws_bytes;      /* optional workspace: with >= 2 * batch * heads * nq * 96 bytes (d = 40; * 224 at d = 80) the unmasked launches
+                                      * with nq, nk % 512 == 0 (d = 40) / % 256 == 0 (d = 80) take the 8-wave staggered kernels (pv_attnbwd.hip);
+                                      * NULL = the 4-wave kernels */
 } pv_attn_bwd_params;
 int pv_attention_backward(const pv_attn_bwd_params* p, void* stream);
 
