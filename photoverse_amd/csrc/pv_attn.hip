@@ -19,6 +19,9 @@
 // 392-404 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch, same box, sustained) + the tile's LDS-DMA issued behind
 // the prefetch reads + per-segment priority (388-390 us where 225 takes 404; +1.0 % of a step over 225, profiles/r05_attn8_ab7*.txt).
 #define PV_ATTN8_DEFAULT 497
+#ifndef PV_ATTN8_LOOP_PAD
+#define PV_ATTN8_LOOP_PAD 3      // -1: no alignment directive
+#endif
 #endif
 #ifndef PV_ATTN_LAZY_UP
 #define PV_ATTN_LAZY_UP 8.f    // attn_kernel: how far (log2 units) a score may exceed its row's softmax reference before the reference moves; 0 = eager
@@ -700,6 +703,12 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
     if (SEGPRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef PV_ATTN8_STAMPS
     unsigned long long a8_acc[4] = {0, 0, 0, 0}, a8_t0 = 0, a8_t1, a8_t2, a8_t3, a8_c0 = 0, a8_r0 = 0;
+#endif
+#if PV_ATTN8_LOOP_PAD >= 0
+    // Where the tile loop's code sits relative to the instruction-fetch lines moves the whole launch by 2.5 % (period 32 bytes: 372.5 us at the best
+    // offset, 376 next to it, 380-382 at the other six; an edit to the PROLOGUE that moved the loop by 12 bytes cost 382.7 -> 392.5 us on another box;
+    // profiles/r05_attn8_loop_alignment.txt).  Pinned: align to 32 bytes here, then PV_ATTN8_LOOP_PAD words - executed once, in front of the loop.
+    asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(PV_ATTN8_LOOP_PAD));
 #endif
     for (int t = 0; t < ntiles; ++t) {
 #ifdef PV_ATTN8_STAMPS

@@ -28,6 +28,12 @@
 #ifndef PV_ATTN8_BWD_DEFAULT
 #define PV_ATTN8_BWD_DEFAULT 81
 #endif
+#ifndef PV_ATTN8_BWD_PAD_KV
+#define PV_ATTN8_BWD_PAD_KV 1      // words behind a 32-byte alignment in front of the step loop; -1: no directive (1 / 3 / 5: -0.6 % of the launch)
+#endif
+#ifndef PV_ATTN8_BWD_PAD_Q
+#define PV_ATTN8_BWD_PAD_Q 7       // (-0.4 %)
+#endif
 
 namespace {
 
@@ -367,6 +373,9 @@ __global__ __launch_bounds__(512, 2) void attn8_bwd_kernel(const pv_attn_bwd_par
 #ifdef PV_ATTN8_BWD_STAMPS
     unsigned long long st_acc[4] = {0, 0, 0, 0}, st_t0 = 0, st_t1, st_t2, st_t3, st_c0 = 0, st_r0 = 0;
 #endif
+    // the step loop's offset inside the 32-byte instruction-fetch windows, pinned (pv_attn.hip, attn8_kernel: 2.5 % between the best and the worst offset)
+    constexpr int LOOP_PAD = KV ? PV_ATTN8_BWD_PAD_KV : PV_ATTN8_BWD_PAD_Q;
+    if constexpr (LOOP_PAD >= 0) asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(LOOP_PAD));
     for (int j = 0; j < nsteps; ++j) {
 #ifdef PV_ATTN8_BWD_STAMPS
         st_t3 = B8_NOW();
