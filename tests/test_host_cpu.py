@@ -74,6 +74,10 @@ def test_cabi_rejects_bad_parameter_blocks_before_touching_the_device(lib):
                               dict(ld_hs=320, ld_out=320, batch=2, nq=256, heads=8, d=40, nt=77, nip=1, w_text=1.0, w_ip=1.0), **kw)
     for bad in (dict(d=48), dict(nq=200), dict(heads=4), dict(nip=0), dict(nt=60), dict(nip=17)):                # C in {320, 640}; nq % 128; 8 heads; 64 < nt <= 80; 1 <= nip <= 16
         assert fused(**bad) == INVALID, bad
+    abw = lambda **kw: call(lib.pv_attention_backward, _lib.AttnBwdParams, ("q", "k", "v", "out", "dout", "lse", "delta", "qs", "dq", "dk", "dv"),
+                            dict(ldq=960, ldk=960, ldv=960, ldo=320, lddo=320, ldqs=320, lddq=960, lddk=960, lddv=960, batch=2, heads=8, nq=512, nk=512, d=40), **kw)
+    for bad in (dict(ldq=324), dict(nq=0), dict(d=48), dict(ws=FAKE, ws_bytes=-1)):       # 16-byte rows; d in {40, 64, 80, 160}; a workspace has a size
+        assert abw(**bad) == INVALID, bad
     rowg = lambda **kw: call(lib.pv_row_gemm, _lib.RowGemmParams, ("x", "w", "out"), dict(ld_x=320, M=4096, K=320, N=960, ln=1, ln_eps=1e-5, geglu=0, ld_out=960), **kw)
     for bad in (dict(K=640, ld_x=640), dict(N=1000, ld_out=1000), dict(ld_out=320), dict(M=0)):                   # K == 320; N % 320 == 0; ld_out >= N
         assert rowg(**bad) == INVALID, bad
@@ -85,7 +89,10 @@ def test_struct_layouts_match_header():
     header = open(os.path.join(ROOT, "include", "photoverse_hip.h")).read()
     for cname, cls in (("pv_gemm_params", _lib.GemmParams), ("pv_groupnorm_params", _lib.GroupNormParams),
                        ("pv_layernorm_params", _lib.LayerNormParams), ("pv_attn_params", _lib.AttnParams),
-                       ("pv_xattn_params", _lib.XAttnParams)):
+                       ("pv_xattn_params", _lib.XAttnParams), ("pv_xattn_fused_params", _lib.XAttnFusedParams),
+                       ("pv_xattn_lnq_params", _lib.XAttnLnqParams), ("pv_row_gemm_params", _lib.RowGemmParams),
+                       ("pv_attn_bwd_params", _lib.AttnBwdParams), ("pv_groupnorm_bwd_params", _lib.GroupNormBwdParams),
+                       ("pv_xattn_bwd_params", _lib.XAttnBwdParams), ("pv_layernorm_bwd_params", _lib.LayerNormBwdParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
