@@ -1,5 +1,5 @@
-// Self-attention backward at d = 40 (attn1 of the 64 x 64 level of the UNet, train.py:505-536 of the reference: the gradient crosses the
-// frozen stock AttnProcessor2_0 blocks) as 8-wave workgroups whose SIMD partners alternate matrix and vector segments - the structure of
+// Self-attention backward at d = 40 / 80 (attn1 of the 64 x 64 / 32 x 32 levels of the UNet, train.py:505-536 of the reference: the gradient crosses
+// the frozen stock AttnProcessor2_0 blocks; written out below for d = 40, the d = 80 parameters are in BW<80>) as 8-wave workgroups whose SIMD partners alternate matrix and vector segments - the structure of
 // attn8_kernel (pv_attn.hip) applied to the two passes of pv_attention_backward (pv_train.hip):
 //
 //   pass dKV: a workgroup OWNS 512 keys (wave: 64 = four 16-key MFMA columns, K / V fragments in registers) and WALKS the queries
@@ -21,7 +21,8 @@
 // The scaled queries and dO are first copied head-major into 48-column rows (`prep`, one launch: it also computes delta), so a walked
 // 64-row tile of the dKV pass is 6 KiB of contiguous memory.
 //
-// Taken by pv_attention_backward (pv_train.hip) for d = 40, no mask, nq and nk multiples of 512, when the caller passes the workspace.
+// Taken by pv_attention_backward (pv_train.hip) for d = 40 (nq and nk multiples of 512) and d = 80 (multiples of 256), no mask, when the caller passes
+// the workspace.
 #include "pv_common.h"
 
 // variant taken when PV_ATTN8_BWD is not set (bits: attn8_bwd_kernel)
