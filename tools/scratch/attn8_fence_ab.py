@@ -23,7 +23,8 @@ print("%%s  %%.1f us" %% (sys.argv[1], e0.elapsed_time(e1) / 400 * 1e3))
 """ % ROOT
 import photoverse_amd.build as b
 libs = []
-for name, extra in (("fence", []), ("nofence", ["-DPV_ATTN8_NO_PRO_FENCE"])):
+MACRO = sys.argv[1] if len(sys.argv) > 1 else "PV_ATTN8_NO_PRO_FENCE"
+for name, extra in (("fence", []), ("nofence", ["-D" + MACRO])):
     objs = []
     for f in b.SOURCES:
         o = "/tmp/fab_%s_%s.o" % (name, f)
