@@ -496,11 +496,11 @@ int launch_attn8_bwd(const pv_attn_bwd_params& p, hipStream_t s, int var) {
 }  // namespace
 
 // bytes of workspace pv_attention_backward needs to take this path: scaled queries and dO head-major in RS-column rows
-size_t pv_attn8_bwd_ws_bytes(const pv_attn_bwd_params& p) {
+__attribute__((visibility("hidden"))) size_t pv_attn8_bwd_ws_bytes(const pv_attn_bwd_params& p) {
     return (size_t)2 * p.batch * p.heads * p.nq * (p.d == 80 ? BWD<80>::RS : BWD<40>::RS) * sizeof(half_t);
 }
 
-bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p) {
+__attribute__((visibility("hidden"))) bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p) {
     if ((p.d != 40 && p.d != 80) || p.causal || !p.ws) return false;
     const int own = p.d == 80 ? BWD<80>::OWN : BWD<40>::OWN, rs = p.d == 80 ? BWD<80>::RS : BWD<40>::RS;
     if (p.nq % own || p.nk % own) return false;
@@ -513,7 +513,7 @@ bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p) {
     return wgs >= (envmin ? atol(envmin) : 128);
 }
 
-int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s) {
+__attribute__((visibility("hidden"))) int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s) {
     const char* env = getenv("PV_ATTN8_BWD");
     const int var = env ? atoi(env) : PV_ATTN8_BWD_DEFAULT;
     return p.d == 80 ? launch_attn8_bwd<80>(p, s, var) : launch_attn8_bwd<40>(p, s, var);

@@ -10,7 +10,8 @@ struct pv_gemm_params_dev : pv_gemm_params {
 // pv_convbig.hip: 256 x 320 tile, one 8-wave workgroup per CU, for the stride-1 / pad-1 3x3 convs (optionally x2-upsampling) whose launch has
 // >= 256 such tiles (no split-K, fp16 output).  Returns -1 when the shape is not one it takes (the caller falls back to the 128-row kernel), -2 when in addition the launch asks for the GroupNorm fold
 // (a_norm: no fallback exists), else a hipError_t.
-int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream);
+__attribute__((visibility("hidden"))) int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream);            // library-internal
+
 
 // pv_gemm.hip: the fixed-order reduction of split-K slabs + GEMM epilogue (+ column statistics) as its own launch
-int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStream_t stream);
+__attribute__((visibility("hidden"))) int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStream_t stream);

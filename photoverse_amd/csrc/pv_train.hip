@@ -15,8 +15,8 @@
 #include "pv_common.h"
 
 // pv_attnbwd.hip: the 8-wave staggered form of the two passes at d = 40
-bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p);
-int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s);
+__attribute__((visibility("hidden"))) bool pv_attn8_bwd_eligible(const pv_attn_bwd_params& p);
+__attribute__((visibility("hidden"))) int pv_attn8_bwd_launch(const pv_attn_bwd_params& p, hipStream_t s);
 
 namespace {
 
