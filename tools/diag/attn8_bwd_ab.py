@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Self-attention backward d = 40: the 4-wave passes of pv_train.hip (PV_ATTN8_BWD=-1) against the 8-wave staggered passes of pv_attnbwd.hip
-(variant bits: 1 stagger, 16 s_setprio 1 in the matrix segments), one process per variant, several rounds on ONE box, sustained timing.
+(variant bits: 1 stagger, 16 s_setprio 1 in the matrix segments, 64 fenced vector-segment passes; instantiated: 0, 1, 65, 81), one process per variant, several rounds on ONE box, sustained timing.
 
 usage (GPU box): python tools/diag/attn8_bwd_ab.py [rounds] [variants, comma separated; -1 = the 4-wave kernels] [batch] [n] [d]"""
 import os
@@ -53,7 +53,7 @@ else:
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["-1", "0", "1", "17"])]
+    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["-1", "0", "1", "65", "81"])]
     B = sys.argv[3] if len(sys.argv) > 3 else "16"
     n = sys.argv[4] if len(sys.argv) > 4 else "4096"
     d = sys.argv[5] if len(sys.argv) > 5 else "40"

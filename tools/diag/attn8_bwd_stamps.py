@@ -56,7 +56,7 @@ for ps in range(2):
 
 def main():
     import photoverse_amd.build as b
-    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "17"]
+    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "81"]
     objs = []
     for f in b.SOURCES:
         o = "/tmp/b8st_%s.o" % f
