@@ -60,7 +60,7 @@ else:
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["-1", "0", "1", "3", "4", "5", "7"])]
+    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["-1", "1", "9", "225", "497"])]
     for v in variants:
         env = dict(os.environ, PV_ATTN8=str(v))
         r = subprocess.run([sys.executable, "-c", CHILD, "check"], env=env, capture_output=True, text=True, timeout=600)
