@@ -753,8 +753,7 @@ int launch_xattn_bwd(const pv_xattn_bwd_params& p, hipStream_t s) {
 // GroupNorm (+ SiLU) backward.  y = act(z), z = gamma xhat + beta, xhat = (x - mean) rstd, statistics per (image, group):
 //   dxhat = dy act'(z) gamma;  dx = rstd (dxhat - mean_g(dxhat) - xhat mean_g(dxhat xhat))
 // Thread = one 8-channel chunk x one pixel lane; grid (pixel splits, images, 64-chunk blocks).
-constexpr int GB_CPB = 64;    // channel chunks per workgroup
-constexpr int GB_ROWS = 4;    // pixel lanes per workgroup
+constexpr int GB_CPB = 64;    // most channel chunks a workgroup takes
 
 struct GnbCoef {
     float a[8], bsh[8], g[8], rstd[8], m1[8], m2[8];
@@ -795,12 +794,14 @@ __device__ __forceinline__ float gnb_dxhat(float xhat, float dy, float gamma, fl
     return dz * gamma;
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const pv_groupnorm_bwd_params p) {
-    __shared__ float red[GB_ROWS][GB_CPB][16];
+// cpb chunk lanes x rows pixel lanes = up to 256 threads: cpb = the block's share of the C / 8 chunks (<= 64), rows = 256 / cpb - at C = 320 that is 40 x 6
+// (the fixed 64 x 4 layout left 96 of 256 threads idle there and 192 at the VAE decoder's C = 128); two pixels per thread and iteration in flight
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const pv_groupnorm_bwd_params p, const int cpb, const int rows) {
+    __shared__ float red[256][16];
     const int C = p.c0 + p.c1, nchunk = C / 8;
-    const int tid = threadIdx.x, cl = tid % GB_CPB, r = tid / GB_CPB;
-    const int chunk = blockIdx.z * GB_CPB + cl, b = blockIdx.y, split = blockIdx.x;
-    const bool ok = chunk < nchunk;
+    const int tid = threadIdx.x, cl = tid % cpb, r = tid / cpb;
+    const int chunk = blockIdx.z * cpb + cl, b = blockIdx.y, split = blockIdx.x;
+    const bool ok = chunk < nchunk && r < rows;
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
@@ -812,10 +813,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const pv_groupnorm_
         for (int j = 0; j < 8; ++j) beta[j] = p.beta[chunk * 8 + j];
         const int per = (p.hw + p.splits - 1) / p.splits;
         const int px0 = split * per, px1 = min(px0 + per, p.hw);
-        for (int px = px0 + r; px < px1; px += GB_ROWS) {
-            const size_t row = (size_t)b * p.hw + px;
-            const half8_t xv = gnb_load(p, row, chunk);
-            const half8_t dv = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.dy) + row * p.ld_dy + chunk * 8);
+        auto one = [&](const half8_t& xv, const half8_t& dv) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xh = (float)xv[j] * k.a[j] + k.bsh[j];
@@ -823,23 +821,37 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const pv_groupnorm_
                 s1[j] += dxh;
                 s2[j] += dxh * xh;
             }
+        };
+        const half_t* dyp = reinterpret_cast<const half_t*>(p.dy) + chunk * 8;
+        int px = px0 + r;
+        for (; px + rows < px1; px += 2 * rows) {
+            const size_t row = (size_t)b * p.hw + px;
+            const half8_t xa = gnb_load(p, row, chunk), xb = gnb_load(p, row + rows, chunk);
+            const half8_t da = *reinterpret_cast<const half8_t*>(dyp + row * p.ld_dy), db = *reinterpret_cast<const half8_t*>(dyp + (row + rows) * p.ld_dy);
+            one(xa, da);
+            one(xb, db);
+        }
+        if (px < px1) {
+            const size_t row = (size_t)b * p.hw + px;
+            one(gnb_load(p, row, chunk), *reinterpret_cast<const half8_t*>(dyp + row * p.ld_dy));
         }
     }
+    if (tid < cpb * rows) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        red[r][cl][j] = s1[j];
-        red[r][cl][8 + j] = s2[j];
+        for (int j = 0; j < 8; ++j) {
+            red[tid][j] = s1[j];
+            red[tid][8 + j] = s2[j];
+        }
     }
     __syncthreads();
-    if (r == 0 && ok) {
+    if (r == 0 && chunk < nchunk) {
         float* out = p.partial + (((size_t)b * p.splits + split) * 2) * C + chunk * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = 0.f, q = 0.f;
-#pragma unroll
-            for (int rr = 0; rr < GB_ROWS; ++rr) {
-                a += red[rr][cl][j];
-                q += red[rr][cl][8 + j];
+            for (int rr = 0; rr < rows; ++rr) {           // pixel lanes in order: deterministic
+                a += red[rr * cpb + cl][j];
+                q += red[rr * cpb + cl][8 + j];
             }
             out[j] = a;
             out[C + j] = q;
@@ -870,11 +882,11 @@ __global__ void gn_bwd_finalize_kernel(const pv_groupnorm_bwd_params p) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pv_groupnorm_bwd_params p, const int px_per_block) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pv_groupnorm_bwd_params p, const int px_per_block, const int cpb, const int rows) {
     const int C = p.c0 + p.c1, nchunk = C / 8;
-    const int tid = threadIdx.x, cl = tid % GB_CPB, r = tid / GB_CPB;
-    const int chunk = blockIdx.z * GB_CPB + cl, b = blockIdx.y;
-    if (chunk >= nchunk) return;
+    const int tid = threadIdx.x, cl = tid % cpb, r = tid / cpb;
+    const int chunk = blockIdx.z * cpb + cl, b = blockIdx.y;
+    if (chunk >= nchunk || r >= rows) return;
     GnbCoef k;
     gnb_coef(p, b, chunk, true, k);
     float beta[8];
@@ -887,12 +899,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pv_groupnorm_bw
     const int ldx = first ? p.ld_dx0 : p.ld_dx1, lda = first ? p.ld_add0 : p.ld_add1, cc = first ? c : c - p.c0;
     if (dx == nullptr) return;
     const int px0 = blockIdx.x * px_per_block, px1 = min(px0 + px_per_block, p.hw);
-    for (int px = px0 + r; px < px1; px += GB_ROWS) {
-        const size_t row = (size_t)b * p.hw + px;
-        const half8_t xv = gnb_load(p, row, chunk);
-        const half8_t dv = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.dy) + row * p.ld_dy + chunk * 8);
-        half8_t av = tz8();
-        if (add) av = *reinterpret_cast<const half8_t*>(add + row * lda + cc);
+    const half_t* dyp = reinterpret_cast<const half_t*>(p.dy) + chunk * 8;
+    auto one = [&](size_t row, const half8_t& xv, const half8_t& dv, const half8_t& av) {
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -901,6 +909,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pv_groupnorm_bw
             o[j] = (half_t)(k.rstd[j] * (dxh - k.m1[j] - xh * k.m2[j]) + (float)av[j]);
         }
         *reinterpret_cast<half8_t*>(dx + row * ldx + cc) = o;
+    };
+    int px = px0 + r;
+    for (; px + rows < px1; px += 2 * rows) {
+        const size_t ra = (size_t)b * p.hw + px, rb = ra + rows;
+        const half8_t xa = gnb_load(p, ra, chunk), xb = gnb_load(p, rb, chunk);
+        const half8_t da = *reinterpret_cast<const half8_t*>(dyp + ra * p.ld_dy), db = *reinterpret_cast<const half8_t*>(dyp + rb * p.ld_dy);
+        half8_t aa = tz8(), ab = tz8();
+        if (add) {
+            aa = *reinterpret_cast<const half8_t*>(add + ra * lda + cc);
+            ab = *reinterpret_cast<const half8_t*>(add + rb * lda + cc);
+        }
+        one(ra, xa, da, aa);
+        one(rb, xb, db, ab);
+    }
+    if (px < px1) {
+        const size_t ra = (size_t)b * p.hw + px;
+        one(ra, gnb_load(p, ra, chunk), *reinterpret_cast<const half8_t*>(dyp + ra * p.ld_dy), add ? *reinterpret_cast<const half8_t*>(add + ra * lda + cc) : tz8());
     }
 }
 
@@ -1408,11 +1433,12 @@ extern "C" int pv_groupnorm_backward(const pv_groupnorm_bwd_params* p, void* str
     if (C % 8 || p->c0 % 8 || C % p->groups || p->groups > 64 || p->splits < 1 || p->splits > 64 || (p->c1 > 0 && !p->x1)) return (int)hipErrorInvalidValue;
     if ((p->ld0 | p->ld1 | p->ld_dy | p->ld_dx0 | p->ld_dx1 | p->ld_add0 | p->ld_add1) % 8) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    const int zb = (C / 8 + GB_CPB - 1) / GB_CPB;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)p->splits, (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p);
+    const int nchunk = C / 8, zb = (nchunk + GB_CPB - 1) / GB_CPB;
+    const int cpb = (nchunk + zb - 1) / zb, rows = 256 / cpb;          // chunk lanes x pixel lanes of a workgroup (cpb <= 64, rows >= 4)
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)p->splits, (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p, cpb, rows);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)((p->batch * p->groups + 3) / 4)), dim3(256), 0, s, *p);
     const int ppb = 64;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((p->hw + ppb - 1) / ppb), (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p, ppb);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((p->hw + ppb - 1) / ppb), (unsigned)p->batch, (unsigned)zb), dim3(256), 0, s, *p, ppb, cpb, rows);
     return PV_CHECK_LAUNCH();
 }
 
