@@ -150,8 +150,11 @@ def test_full_size_vae_decode_and_encode(full_weights, golden_dir):
     assert post.mean.shape == (1, 4, 32, 32) and e_mean < 5e-3 and e_lv < 5e-3
 
 
-def test_full_size_training_gradients(full_weights, golden_dir):
-    """The training backward at the FULL model sizes (SD-v1.5 UNet, 12-layer CLIP text encoder, 1024-wide adapters, 5 tokens, LoRA r=8),
+@pytest.mark.parametrize("attn_bwd_min", ["128", "1"])
+def test_full_size_training_gradients(full_weights, golden_dir, monkeypatch, attn_bwd_min):
+    """``attn_bwd_min`` = PV_ATTN8_BWD_MIN: "128" is the library's rule (at B = 1 the attention backward runs on the 4-wave passes), "1" puts the 8-wave
+    staggered passes of pv_attnbwd.hip (d = 40 and d = 80) into the same plan - the form the bs = 16 training step uses.
+    The training backward at the FULL model sizes (SD-v1.5 UNet, 12-layer CLIP text encoder, 1024-wide adapters, 5 tokens, LoRA r=8),
     B=1, 64x64 latents: gradients of every trainable group against torch autograd over the fp32 oracle WITH THE INDEPENDENT peft
     restatement (oracle/lora_ref.py: un-merged W x + (alpha / r) B A x) - computed in the build container; here: per-group rel-L2 on
     strided sub-samples of every gradient tensor and per-group norms."""
@@ -160,6 +163,7 @@ def test_full_size_training_gradients(full_weights, golden_dir):
     from photoverse_amd.lora import LoraConfig, inject_adapter_in_model
     from photoverse_amd.train import TrainStep
     from photoverse_amd.unet import UNet2DConditionModel, set_visual_cross_attention_adapter
+    monkeypatch.setenv("PV_ATTN8_BWD_MIN", attn_bwd_min)
     c, exp = fs.train_case(), _load(golden_dir, "full_train.pt")
     E = c["E"]
     with fs.no_init():
