@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 16
+#define PV_ABI_VERSION 17
 
 enum pv_act { PV_ACT_NONE = 0, PV_ACT_SILU = 1, PV_ACT_QUICK_GELU = 2, PV_ACT_LEAKY_RELU = 3, PV_ACT_GELU = 4 };
 
@@ -98,6 +98,11 @@ typedef struct pv_gemm_params {
     int32_t a_norm_act;    /* PV_ACT_NONE or PV_ACT_SILU, applied after the affine part */
 } pv_gemm_params;
 int pv_gemm_conv(const pv_gemm_params* p, void* stream);
+/* (ABI 17) Which kernel pv_gemm_conv would launch for this block: the symbol as rocprofv3 prints it (without the namespace and the argument
+ * list, e.g. "big_tile_kernel<true, false, 8, 3, false>") and the workgroup count (split-K slices included).  Same validation and the same dispatch
+ * code as pv_gemm_conv with the launchers in describe-only mode: no HIP call, no GPU needed.  The host side tags its recorded launches with it
+ * (bench.py's per-symbol roofline reads the tags); nothing in the reference corresponds (measurement scaffolding of this build). */
+int pv_gemm_conv_kernel_info(const pv_gemm_params* p, char* name, int32_t name_len, int64_t* workgroups);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) over NHWC fp16, optionally over a channel concat of two tensors.
@@ -158,6 +163,8 @@ typedef struct pv_attn_params {
                                         pv_attention_backward; NULL = not written */
 } pv_attn_params;
 int pv_attention(const pv_attn_params* p, void* stream);
+/* (ABI 17) Which kernel pv_attention would launch for this block (pv_gemm_conv_kernel_info's contract): "attn8_kernel<497>", "attn_kernel<80, 2, false>", ... */
+int pv_attention_kernel_info(const pv_attn_params* p, char* name, int32_t name_len, int64_t* workgroups);
 
 /* Backward of pv_attention (the [EXT] AttnProcessor2_0 SDPA of attn1, models/unet.py:20-24, and the CLIP text layers the gradient
  * of text_adapter crosses, train.py:498-500).  Probabilities are recomputed from lse; delta: fp32 workspace [B][heads][nq]; qs: fp16 workspace like q.

@@ -163,9 +163,22 @@ SIGNATURES = {
     "pv_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pv_clip_vision_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pv_clip_text_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pv_gemm_conv_kernel_info": (c_int, [C.POINTER(GemmParams), C.c_char_p, c_int, C.POINTER(c_int64)]),
+    "pv_attention_kernel_info": (c_int, [C.POINTER(AttnParams), C.c_char_p, c_int, C.POINTER(c_int64)]),
 }
 
-ABI_VERSION = 16
+
+def kernel_info(fn, params):
+    """(symbol, workgroups) of the launch ``fn`` (pv_gemm_conv_kernel_info / pv_attention_kernel_info) would make for ``params``: the library's own
+    dispatch rule, asked - not restated - by the host side for its launch tags."""
+    buf = C.create_string_buffer(160)
+    wgs = c_int64(0)
+    rc = fn(C.byref(params), buf, len(buf), C.byref(wgs))
+    if rc != 0:
+        raise ValueError(f"{fn.__name__ if hasattr(fn, '__name__') else 'kernel_info'}: the library rejects this parameter block (hipError {rc})")
+    return buf.value.decode(), int(wgs.value)
+
+ABI_VERSION = 17
 _lib = None
 
 

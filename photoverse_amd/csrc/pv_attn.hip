@@ -519,10 +519,11 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qi][0], PREF ? negm[qi] : s[kb][qi], 0, 0, 0);
         }
-        // prologue call only (its own basic block): keep the 16-deep tail steps behind ALL the 32-deep ones.  hipcc is free to put a tail step two
-        // slots behind the 16x16x32 whose result it accumulates onto; in the backward passes (pv_attnbwd.hip, same two-shape chain) that schedule
-        // returned wrong sums, non-deterministically, once the wave ran at s_setprio 1.  The loop's copy is already in this order (the pins).
-        if (K48 && FIRST) __builtin_amdgcn_sched_barrier(0);
+        // Keep the 16-deep tail steps behind ALL the 32-deep ones, in EVERY copy of this block (prologue and tile loop).  hipcc is free to put a tail
+        // step one or two slots behind the 16x16x32 whose result it accumulates onto; in the backward passes (pv_attnbwd.hip, same two-shape chain) that
+        // schedule returned wrong sums, non-deterministically, once the wave ran at s_setprio 1.  The fence does not depend on where the scheduler
+        // happens to put the loop's copy today; tests/test_host_cpu.py scans the emitted ISA for such chains (tools/diag/mfma_chain_scan.py).
+        if (K48) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             if (K48) {
@@ -972,44 +973,73 @@ __global__ __launch_bounds__(256) void xattn_kernel(const pv_xattn_params p, con
     }   // query tiles of this workgroup
 }
 
+// Which kernel a pv_attention launch takes: ONE rule, used by the launcher and by pv_attention_kernel_info (the host side tags its launches with the
+// symbol rocprofv3 will show; it asks instead of restating this rule).
+enum AttnKind { ATTN8 = 0, ATTN40_4_DMA, ATTN40_2_DMA, ATTN_4, ATTN_2 };
+struct AttnChoice {
+    AttnKind kind;
+    int var8;          // ATTN8: the instantiated variant
+    long wgs;          // workgroups of the launch
+};
+// the forms of EXPERIMENTS.md's round-5 table that are instantiated (the per-segment priority schemes measured there were removed again)
+#define PV_A8_VARIANTS(X) X(0) X(1) X(9) X(13) X(33) X(49) X(73) X(201) X(225) X(241) X(481) X(497)
+constexpr bool attn8_variant_built(int v) {
+#define PV_A8_TEST(V) if (v == V) return true;
+    PV_A8_VARIANTS(PV_A8_TEST)
+#undef PV_A8_TEST
+    return false;
+}
+static_assert(attn8_variant_built(PV_ATTN8_DEFAULT), "the default variant must be an instantiated one");
+
 template <int D>
-int launch_attn(const pv_attn_params& p, hipStream_t s) {
-    using C = ACfg<D>;
-    constexpr int smem1 = 64 * (C::KS + C::VS) * 2;
+AttnChoice choose_attn(const pv_attn_params& p) {
     // four query fragments per wave where the accumulators fit two waves per SIMD (d = 40) and the launch still fills the chip
     static const int nq_env = getenv("PV_ATTN_NQ") ? atoi(getenv("PV_ATTN_NQ")) : 0;
-    const long wg256 = (long)((p.nq + 255) / 256) * p.heads * p.batch;
+    const long wg256 = (long)((p.nq + 255) / 256) * p.heads * p.batch, wg128 = (long)((p.nq + 127) / 128) * p.heads * p.batch;
     const bool four = D == 40 && (nq_env ? nq_env == 4 : wg256 >= 1024);
     if constexpr (D == 40) {
         static const bool no_dma = getenv("PV_ATTN_NO_DMA") != nullptr;      // A/B switch
         if (!no_dma && (size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 < (1ull << 31)) {
-            constexpr int smem3 = 4 * smem1;            // 56 KiB: above the 48-KiB default of dynamic LDS
             // 8-wave staggered form: one 512-query workgroup per CU; taken when the launch fills the chip with them
             // (read per call, not cached: tests run several forms in one process; launches are recorded once and replayed from graphs)
-            const char* env8 = getenv("PV_ATTN8");
+            const char* env8 = getenv("PV_ATTN8");                  // negative or not an instantiated form: the 4-wave kernels take the launch
             const char* env8min = getenv("PV_ATTN8_MIN");           // fewest 512-query workgroups a launch must have (default: one per CU)
             const int var8 = env8 ? atoi(env8) : PV_ATTN8_DEFAULT;
             const long wg512 = (long)((p.nq + 511) / 512) * p.heads * p.batch;
-            if (var8 >= 0 && !p.causal && wg512 >= (env8min ? atol(env8min) : 256)) {
-                void (*kern)(const pv_attn_params) = nullptr;
-                switch (var8) {
+            if (attn8_variant_built(var8) && !p.causal && wg512 >= (env8min ? atol(env8min) : 256)) return {ATTN8, var8, wg512};
+            return four ? AttnChoice{ATTN40_4_DMA, 0, wg256} : AttnChoice{ATTN40_2_DMA, 0, wg128};
+        }
+    }
+    return four ? AttnChoice{ATTN_4, 0, wg256} : AttnChoice{ATTN_2, 0, wg128};
+}
+
+template <int D>
+int launch_attn(const pv_attn_params& p, hipStream_t s) {
+    using C = ACfg<D>;
+    constexpr int smem1 = 64 * (C::KS + C::VS) * 2;
+    const AttnChoice ch = choose_attn<D>(p);
+    if constexpr (D == 40) {
+        constexpr int smem3 = 4 * smem1;            // 56 KiB: above the 48-KiB default of dynamic LDS
+        if (ch.kind == ATTN8) {
+            void (*kern)(const pv_attn_params) = nullptr;
+            switch (ch.var8) {
 #define PV_A8_CASE(V) case V: kern = attn8_kernel<V>; break;
-                    // the forms of EXPERIMENTS.md's round-5 table (the seven per-segment priority schemes measured there were removed again)
-                    PV_A8_CASE(0) PV_A8_CASE(1) PV_A8_CASE(9) PV_A8_CASE(13) PV_A8_CASE(33) PV_A8_CASE(49) PV_A8_CASE(73) PV_A8_CASE(201) PV_A8_CASE(225) PV_A8_CASE(241) PV_A8_CASE(481) PV_A8_CASE(497)
+                PV_A8_VARIANTS(PV_A8_CASE)
 #undef PV_A8_CASE
-                    default: return (int)hipErrorInvalidValue;
-                }
-                static bool attr8_set[64][512] = {};
-                int dev8 = 0;
-                (void)hipGetDevice(&dev8);
-                if (!attr8_set[dev8 & 63][var8]) {
-                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-                    if (e != hipSuccess) return (int)e;
-                    attr8_set[dev8 & 63][var8] = true;
-                }
-                hipLaunchKernelGGL(kern, dim3((unsigned)wg512), dim3(512), smem3, s, p);
-                return PV_CHECK_LAUNCH();
+                default: return (int)hipErrorInvalidValue;          // unreachable: choose_attn names instantiated forms only
             }
+            static bool attr8_set[64][512] = {};
+            int dev8 = 0;
+            (void)hipGetDevice(&dev8);
+            if (!attr8_set[dev8 & 63][ch.var8 & 511]) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+                if (e != hipSuccess) return (int)e;
+                attr8_set[dev8 & 63][ch.var8 & 511] = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)ch.wgs), dim3(512), smem3, s, p);
+            return PV_CHECK_LAUNCH();
+        }
+        if (ch.kind == ATTN40_4_DMA || ch.kind == ATTN40_2_DMA) {
             static bool attr_set_dev[64] = {};
             int dev_id = 0;
             (void)hipGetDevice(&dev_id);
@@ -1019,14 +1049,30 @@ int launch_attn(const pv_attn_params& p, hipStream_t s) {
                 if (e != hipSuccess) return (int)e;
                 attr_set_dev[dev_id & 63] = true;
             }
-            if (four) hipLaunchKernelGGL((attn_kernel<40, 4, true>), dim3((unsigned)wg256), dim3(256), smem3, s, p);
-            else hipLaunchKernelGGL((attn_kernel<40, 2, true>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem3, s, p);
+            if (ch.kind == ATTN40_4_DMA) hipLaunchKernelGGL((attn_kernel<40, 4, true>), dim3((unsigned)ch.wgs), dim3(256), smem3, s, p);
+            else hipLaunchKernelGGL((attn_kernel<40, 2, true>), dim3((unsigned)ch.wgs), dim3(256), smem3, s, p);
             return PV_CHECK_LAUNCH();
         }
     }
-    if (four) hipLaunchKernelGGL((attn_kernel<D, D == 40 ? 4 : 2, false>), dim3((unsigned)wg256), dim3(256), smem1, s, p);
-    else hipLaunchKernelGGL((attn_kernel<D, 2, false>), dim3(((p.nq + 127) / 128) * p.heads * p.batch), dim3(256), smem1, s, p);
+    if (ch.kind == ATTN_4) hipLaunchKernelGGL((attn_kernel<D, D == 40 ? 4 : 2, false>), dim3((unsigned)ch.wgs), dim3(256), smem1, s, p);
+    else hipLaunchKernelGGL((attn_kernel<D, 2, false>), dim3((unsigned)ch.wgs), dim3(256), smem1, s, p);
     return PV_CHECK_LAUNCH();
+}
+
+template <int D>
+int attn_info(const pv_attn_params& p, char* name, int name_len, int64_t* workgroups) {
+    const AttnChoice ch = choose_attn<D>(p);
+    int n;
+    switch (ch.kind) {
+        case ATTN8: n = snprintf(name, (size_t)name_len, "attn8_kernel<%d>", ch.var8); break;
+        case ATTN40_4_DMA: n = snprintf(name, (size_t)name_len, "attn_kernel<40, 4, true>"); break;
+        case ATTN40_2_DMA: n = snprintf(name, (size_t)name_len, "attn_kernel<40, 2, true>"); break;
+        case ATTN_4: n = snprintf(name, (size_t)name_len, "attn_kernel<%d, 4, false>", D); break;
+        default: n = snprintf(name, (size_t)name_len, "attn_kernel<%d, 2, false>", D); break;
+    }
+    if (n < 0 || n >= name_len) return (int)hipErrorInvalidValue;
+    if (workgroups) *workgroups = ch.wgs;
+    return 0;
 }
 
 template <int D>
@@ -1065,6 +1111,18 @@ extern "C" int pv_attention(const pv_attn_params* p, void* stream) {
         case 64: return launch_attn<64>(*p, s);
         case 80: return launch_attn<80>(*p, s);
         case 160: return launch_attn<160>(*p, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// The kernel pv_attention would launch for this parameter block (symbol as rocprofv3 prints it, workgroup count): the launcher's own rule.  No HIP call.
+extern "C" int pv_attention_kernel_info(const pv_attn_params* p, char* name, int32_t name_len, int64_t* workgroups) {
+    if (!p || !name || name_len <= 0 || p->batch <= 0 || p->heads <= 0 || p->nq <= 0 || p->nk <= 0) return (int)hipErrorInvalidValue;
+    switch (p->d) {
+        case 40: return attn_info<40>(*p, name, name_len, workgroups);
+        case 64: return attn_info<64>(*p, name, name_len, workgroups);
+        case 80: return attn_info<80>(*p, name, name_len, workgroups);
+        case 160: return attn_info<160>(*p, name, name_len, workgroups);
         default: return (int)hipErrorInvalidValue;
     }
 }

@@ -463,6 +463,10 @@ extern "C" int pv_attn8_bwd_read_stamps(unsigned long long* out) {
 #endif
 
 namespace {
+// the forms instantiated below (PV_B8_CASE): anything else named by PV_ATTN8_BWD is not eligible and falls back to the 4-wave kernels
+constexpr bool attn8_bwd_variant_built(int var) { return var == 0 || var == 1 || var == 65 || var == 81; }
+static_assert(attn8_bwd_variant_built(PV_ATTN8_BWD_DEFAULT), "the default variant must be an instantiated one");
+
 template <int D>
 int launch_attn8_bwd(const pv_attn_bwd_params& p, hipStream_t s, int var) {
     using C = BWD<D>;
@@ -507,7 +511,7 @@ __attribute__((visibility("hidden"))) bool pv_attn8_bwd_eligible(const pv_attn_b
     if ((size_t)p.ws_bytes < pv_attn8_bwd_ws_bytes(p)) return false;
     if ((size_t)p.nk * (size_t)(p.ldk > p.ldv ? p.ldk : p.ldv) * 2 >= (1ull << 31) || (size_t)p.nq * rs * 2 >= (1ull << 31)) return false;
     const char* env = getenv("PV_ATTN8_BWD");             // read per call (tests run both forms in one process); -1 = the 4-wave kernels
-    if (env && atoi(env) < 0) return false;
+    if (env && !attn8_bwd_variant_built(atoi(env))) return false;      // negative or not an instantiated form: the 4-wave kernels take the launch
     const char* envmin = getenv("PV_ATTN8_BWD_MIN");      // fewest workgroups a pass must have (default: half the CUs)
     const long wgs = (long)p.batch * p.heads * ((p.nq < p.nk ? p.nq : p.nk) / own);
     return wgs >= (envmin ? atol(envmin) : 128);

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 #include "../../include/photoverse_hip.h"
 
 typedef _Float16 half_t;

@@ -703,6 +703,12 @@ template <bool CS, bool UPS, int MI, int MODE, bool LN = false>
 int launch_big(const pv_gemm_params_dev& p, hipStream_t stream) {
     using Cfg = BigCfg<MI, MODE == 2 ? 4 : 5>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, SMEM_BYTES = MODE >= 5 ? Cfg::SMEM_NORM_BYTES : MODE >= 3 ? Cfg::SMEM_PATCH_BYTES : Cfg::SMEM_BYTES;
+    if (pv_gemm_probe) {                 // pv_gemm_conv_kernel_info: describe, do not launch
+        snprintf(pv_gemm_probe->name, sizeof(pv_gemm_probe->name), "big_tile_kernel<%s, %s, %d, %d, %s>", CS ? "true" : "false", UPS ? "true" : "false", MI, MODE,
+                 LN ? "true" : "false");
+        pv_gemm_probe->wgs = (long)((p.M + BM - 1) / BM) * (p.N / BN) * ((p.splitk > 1 && p.splitk_ws) ? p.splitk : 1);
+        return 0;
+    }
     static bool attr_set_dev[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);

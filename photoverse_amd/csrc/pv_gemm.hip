@@ -519,6 +519,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const pv_gemm_params
 template <int NF, bool CONV, bool GEGLU, bool CS = false, bool MULTI = false, int MIV = 4>
 int launch(const pv_gemm_params_dev& p, hipStream_t stream, int tpw = 1) {
     using Cfg = TileCfg<NF, MIV>;
+    if (pv_gemm_probe) {                 // pv_gemm_conv_kernel_info: describe, do not launch
+        const int splits_ = (!GEGLU && p.splitk > 1 && p.splitk_ws) ? p.splitk : 1;
+        snprintf(pv_gemm_probe->name, sizeof(pv_gemm_probe->name), "gemm_conv_kernel<%d, %s, %s, %s, %s, %d>", NF, CONV ? "true" : "false", GEGLU ? "true" : "false",
+                 CS ? "true" : "false", MULTI ? "true" : "false", MIV);
+        pv_gemm_probe->wgs = (long)(((p.M + Cfg::BM - 1) / Cfg::BM) * (p.N / Cfg::BN) / tpw) * splits_;
+        return 0;
+    }
     static bool attr_set_dev[64] = {};   // per device: one process may drive several GPUs
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -589,6 +596,27 @@ int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStr
     return PV_CHECK_LAUNCH();
 }
 
+thread_local pv_launch_probe* pv_gemm_probe = nullptr;
+
+extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_);
+
+// The kernel pv_gemm_conv would launch for this parameter block (symbol as rocprofv3 prints it, workgroups incl. split-K slices): the same validation and
+// the same dispatch code, with the launchers in describe-only mode.  No HIP call is made.
+extern "C" int pv_gemm_conv_kernel_info(const pv_gemm_params* pp, char* name, int32_t name_len, int64_t* workgroups) {
+    if (!pp || !name || name_len <= 0) return (int)hipErrorInvalidValue;
+    pv_launch_probe probe;
+    probe.name[0] = 0;
+    probe.wgs = 0;
+    pv_gemm_probe = &probe;
+    const int rc = pv_gemm_conv(pp, nullptr);
+    pv_gemm_probe = nullptr;
+    if (rc != 0) return rc;
+    if ((int)strlen(probe.name) >= name_len) return (int)hipErrorInvalidValue;
+    strcpy(name, probe.name);
+    if (workgroups) *workgroups = probe.wgs;
+    return 0;
+}
+
 extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
     pv_gemm_params_dev p;
     static_cast<pv_gemm_params&>(p) = *pp;
@@ -609,6 +637,9 @@ extern "C" int pv_gemm_conv(const pv_gemm_params* pp, void* stream_) {
         p.w_bytes = (uint32_t)bw;
     }
     if (p.geglu && (p.taps != 1 || (p.N % 128))) return (int)hipErrorInvalidValue;
+    // the GroupNorm fold exists for 3x3 convs only, with no activation or SiLU behind the affine part: a Linear launch carrying a_norm would
+    // run the 256-row tile and silently ignore it (the taps == 1 branch of pv_conv_big_launch returns before any a_norm check)
+    if (p.a_norm && (p.taps != 9 || (p.a_norm_act != PV_ACT_NONE && p.a_norm_act != PV_ACT_SILU))) return (int)hipErrorInvalidValue;
     {                                                    // the 256-row tile (pv_convbig.hip) where the launch fills the chip with it
         const int rc = pv_conv_big_launch(p, stream);
         if (rc >= 0) return rc;

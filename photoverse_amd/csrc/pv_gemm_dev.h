@@ -15,3 +15,13 @@ __attribute__((visibility("hidden"))) int pv_conv_big_launch(const pv_gemm_param
 
 // pv_gemm.hip: the fixed-order reduction of split-K slabs + GEMM epilogue (+ column statistics) as its own launch
 __attribute__((visibility("hidden"))) int pv_gemm_splitk_reduce_launch(const pv_gemm_params_dev& p, int splits, hipStream_t stream);
+
+
+// pv_gemm_conv_kernel_info: while a probe is installed (this thread), launch<> / launch_big<> describe the launch they WOULD make - the kernel symbol as
+// rocprofv3 prints it and the workgroup count - and return without touching the device.  The host side tags its recorded launches with it instead of
+// restating the dispatch rules.
+struct pv_launch_probe {
+    char name[160];
+    long wgs;
+};
+extern thread_local pv_launch_probe* pv_gemm_probe;

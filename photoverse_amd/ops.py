@@ -16,6 +16,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib
+from ._lib import kernel_info as _kernel_info, load
 from ._lib import (AttnBwdParams, AttnParams, GemmParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    XAttnBwdParams, XAttnFusedParams, XAttnLnqParams, XAttnParams)
 
@@ -232,32 +233,9 @@ class Recorder:
                        _ptr(out), ldc, M, N, taps, *geo, act, int(out_f32), int(geglu), splitk, _ptr(ws), _ptr(cs), _ptr(ln_rowsum), float(ln_eps), big_min if big_min > 0 else -1,
                        _ptr(a_norm), int(a_norm_act))
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum, a_norm) if t is not None)
-        nf = 4 if geglu else (5 if N % 160 == 0 else 4)
-        # the symbol rocprof shows for this launch: gemm_conv_kernel<NF, CONV, GEGLU, CS, MULTI, MI>
-        # (MULTI = the tile-loop instantiation pv_gemm.hip's choose_tpw picks for the short-K GEGLU layers with >= 1024 workgroups)
-        multi = False
-        if geglu and conv is None:
-            tiles_n, nblk = N // (nf * 32), ((M + 127) // 128) * (N // (nf * 32))
-            multi = any(tiles_n % c == 0 and kdim // 64 <= 5 and nblk // c >= 1024 for c in range(2, 9))
-        mi = 2 if (conv is None and not geglu and cs is None and splitk == 1 and ((M + 127) // 128) * (N // (nf * 32)) < 512) else 4
-        name = (f"gemm_conv_kernel<{nf}, {'true' if conv is not None else 'false'}, {'true' if geglu else 'false'}, "
-                f"{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if multi else 'false'}, {mi}>")
-        # pv_convbig.hip's 256 x 320 tile (pv_conv_big_launch's rule): stride-1 / pad-1 3x3 convs whose launch has >= PV_CONV_BIG (256) such tiles
-        # pv_convbig.hip's 256-row tile (pv_conv_big_launch's rules): 3x3 convs, and Linear layers with K >= 640 (GEGLU: 256-column tiles)
-        if big_shape and not (out_f32 and splitk == 1) and (splitk == 1 or (kdim // 64) // splitk >= 8):
-            if tiles256 * splitk >= big_min:
-                # MODE 3 / 4: the LDS-resident input patch (pv_conv_big_launch's rule: whole 64- / 32-pixel image rows per tile, no split-K, no upsampling)
-                pmode = int(os.environ.get("PV_CONV_PATCH", "64"))      # 0: never; 64 (default): the 64-pixel-row form only; 1: the 32-pixel-row form too
-                patch = (pmode != 0 and not geo[6] and splitk == 1 and (geo[4] == 64 or (geo[4] == 32 and pmode != 64)) and (geo[3] * geo[4]) % 256 == 0
-                         and M % 256 == 0 and c0 % 32 == 0 and (c0 + c1) % 32 == 0)
-                mode = ((3 if geo[4] == 64 else 4) if patch else 0) + (2 if a_norm is not None else 0)
-                name = f"big_tile_kernel<{'true' if (cs is not None and splitk == 1) else 'false'}, {'true' if geo[6] else 'false'}, 8, {mode}, false>"
-        bn_big = 256 if geglu else 320
-        if (conv is None and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and a1 is None and splitk == 1 and not out_f32 and kdim >= 640
-                and N % bn_big == 0 and not (geglu and cs is not None) and ((M + 255) // 256) * (N // bn_big) >= big_min):
-            name = f"big_tile_kernel<{'true' if cs is not None else 'false'}, false, 8, {2 if geglu else 1}, {'true' if ln_rowsum is not None else 'false'}>"
-        # 4th tag field: workgroups of the launch (bench.py separates the chip-filling launches of the one-per-CU tile from the half-chip ones)
-        wgs = (((M + 255) // 256) * (N // (256 if geglu else 320)) if name.startswith("big_tile_kernel") else ((M + 127) // 128) * max(N // bn, 1)) * splitk
+        # the symbol rocprofv3 shows for this launch and its workgroup count (4th tag field: bench.py separates the chip-filling launches of the
+        # one-per-CU tile from the half-chip ones): asked from the library's own dispatch code, not restated here
+        name, wgs = _kernel_info(self.lib.pv_gemm_conv_kernel_info, p)
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out), wgs))
         return out
 
@@ -267,12 +245,27 @@ class Recorder:
     GEMM_LN = os.environ.get("PV_GEMM_LN", "0") != "0"
 
     @staticmethod
+    def _probe_gemm(**fields) -> str:
+        """Symbol pv_gemm_conv would launch for a parameter block with these fields (pointers are placeholders: the query never touches them), '' if the
+        library rejects the block."""
+        p = GemmParams()
+        for k in ("a0", "w", "out"):
+            setattr(p, k, 0x1000)
+        for k, v in fields.items():
+            setattr(p, k, v)
+        try:
+            return _kernel_info(load().pv_gemm_conv_kernel_info, p)[0]
+        except ValueError:
+            return ""
+
+    @staticmethod
     def gemm_ln_supported(M: int, N: int, K: int, geglu: bool, big_min: Optional[int] = None) -> bool:
-        """Where ``gemm(ln_gamma=...)`` exists: the Linear modes of the 256-row tile (pv_conv_big_launch's rule)."""
-        big_min = int(os.environ.get("PV_CONV_BIG", "256")) if big_min is None else big_min
-        bn = 256 if geglu else 320
-        return (Recorder.GEMM_LN and big_min > 0 and os.environ.get("PV_GEMM_BIG", "1") != "0" and K >= 640 and N % bn == 0
-                and ((M + 255) // 256) * (N // bn) >= big_min)
+        """Where ``gemm(ln_gamma=...)`` exists: the launches the library puts on the LayerNorm instantiation of the 256-row tile's Linear modes (asked
+        from pv_gemm_conv_kernel_info: a block carrying ``ln_rowsum`` that lands on ``big_tile_kernel<..., true>``)."""
+        big_min = 0 if big_min is None else (big_min if big_min > 0 else -1)
+        name = Recorder._probe_gemm(c0=K, lda0=K, N=N, ldc=N // 2 if geglu else N, M=M, taps=1, batch=1, hin=1, win=1, hout=M, wout=1, stride=1, pad=1,
+                                    geglu=int(geglu), ln_rowsum=0x1000, ln_eps=1e-5, big_tile_min=big_min)
+        return bool(Recorder.GEMM_LN and name.startswith("big_tile_kernel") and name.endswith("true>"))
 
     #: GroupNorm + SiLU folded into the 3x3 conv behind it (pv_gemm_params.a_norm, round 5): exact (bit-identical to GroupNorm-apply + conv), removes the
     #: 64 x 64 level's 20 GroupNorm-apply launches per step - and measures 32.3 -> 32.1 steps/s same box (three rounds): the conv pays ~600 cycles per
@@ -282,14 +275,14 @@ class Recorder:
 
     @staticmethod
     def gn_conv_supported(geo, M: int, N: int, c0: int, c1: int, big_min: int, splitk: int = 1) -> bool:
-        """Where ``gemm(a_norm=...)`` exists: the launches pv_conv_big_launch puts on the LDS-resident-patch modes (its rule, restated), whose inputs carry
-        column statistics (whole 64-row blocks per image) and whose scale / shift table fits the kernel's LDS slot."""
-        pmode = int(os.environ.get("PV_CONV_PATCH", "64"))
-        hw = geo[3] * geo[4]
-        up = 2 if geo[6] else 1
-        shape = (big_min > 0 and geo[5] == 1 and geo[7] == 1 and not geo[6] and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
-        patch = (pmode != 0 and splitk == 1 and (geo[4] == 64 or (geo[4] == 32 and pmode != 64)) and hw % 256 == 0 and M % 256 == 0 and c0 % 32 == 0 and (c0 + c1) % 32 == 0)
-        return bool(Recorder.GN_FOLD and shape and patch and ((M + 255) // 256) * (N // 320) >= big_min and 2 * (c0 + c1) * 4 <= 16 * 1024)
+        """Where ``gemm(a_norm=...)`` exists: the launches the library puts on the GroupNorm-folding modes (5 / 6) of the LDS-resident-patch conv (asked from
+        pv_gemm_conv_kernel_info with a block that carries ``a_norm``; the library rejects such a block everywhere else)."""
+        if not Recorder.GN_FOLD:
+            return False
+        name = Recorder._probe_gemm(a1=0x1000 if c1 else 0, c0=c0, c1=c1, lda0=c0, lda1=c1, N=N, ldc=N, M=M, taps=9, batch=geo[0], hin=geo[1], win=geo[2],
+                                    hout=geo[3], wout=geo[4], stride=geo[5], upsample=geo[6], pad=geo[7], splitk=splitk, splitk_ws=0x1000 if splitk > 1 else 0,
+                                    big_tile_min=big_min if big_min > 0 else -1, a_norm=0x1000, a_norm_act=ACT_SILU)
+        return name.startswith("big_tile_kernel") and (", 8, 5, " in name or ", 8, 6, " in name)
 
     def groupnorm_table(self, x: torch.Tensor, gamma, beta, *, batch: int, hw: int, x1: Optional[torch.Tensor] = None, eps=1e-5, groups=32) -> Optional[torch.Tensor]:
         """The GroupNorm of ``x`` (| ``x1``) as a per-(image, channel) scale / shift table, fp32 [batch][2][C], for ``gemm(a_norm=...)``; None when the inputs
@@ -358,16 +351,8 @@ class Recorder:
         ldo, _ = _rows(out)
         p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal), _ptr(lse))
         self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
-        # the symbol rocprof shows for this launch (pv_attn.hip: launch_attn's rule), and its workgroup count
-        wg512, wg256 = ((nq + 511) // 512) * heads * batch, ((nq + 255) // 256) * heads * batch
-        var8 = int(os.environ.get("PV_ATTN8", "497"))
-        if d == 40 and not os.environ.get("PV_ATTN_NO_DMA") and var8 >= 0 and not causal and wg512 >= int(os.environ.get("PV_ATTN8_MIN", "256")):
-            name, wgs = f"attn8_kernel<{var8}>", wg512
-        elif d == 40:
-            four = wg256 >= 1024
-            name, wgs = f"attn_kernel<40, {4 if four else 2}, {'false' if os.environ.get('PV_ATTN_NO_DMA') else 'true'}>", (wg256 if four else ((nq + 127) // 128) * heads * batch)
-        else:
-            name, wgs = f"attn_kernel<{d}, 2, false>", ((nq + 127) // 128) * heads * batch
+        # the symbol rocprofv3 shows for this launch and its workgroup count: pv_attn.hip's own rule (choose_attn), asked from the library
+        name, wgs = _kernel_info(self.lib.pv_attention_kernel_info, p)
         self._add(self.lib.pv_attention, p, tag=(name, 4.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (2 * nq + 2 * nk), wgs))
         return out
 
@@ -382,7 +367,15 @@ class Recorder:
         qs = self.empty((batch * nq, C_))
         # workspace of the 8-wave staggered passes (pv_attnbwd.hip, d = 40 / 80): scaled queries and dO head-major in 48- / 112-column rows
         ws_cols, own = {40: (48, 512), 80: (112, 256)}.get(d, (0, 1))
-        ws = self.empty((2 * batch * heads * nq, ws_cols)) if (ws_cols and not causal and nq % own == 0 and nk % own == 0) else None
+        # ONE scratch buffer per Recorder, shared by every attention_backward call of the plan: it is written and consumed inside one stream-ordered call
+        # (the plan's calls run in order on one stream), so 0.8 GB of per-layer buffers at bs = 16 become the largest layer's ~100 MB.  A later call that needs
+        # more gets a new, larger buffer (earlier calls keep theirs); a backward plan meets its largest layer first.
+        ws = None
+        if ws_cols and not causal and nq % own == 0 and nk % own == 0:
+            need = 2 * batch * heads * nq * ws_cols
+            if getattr(self, "_attn_bwd_ws", None) is None or self._attn_bwd_ws.numel() < need:
+                self._attn_bwd_ws = self.empty((need,))
+            ws = self._attn_bwd_ws[:need]
         p = AttnBwdParams(_ptr(q), _ptr(k), _ptr(v), _rows(q)[0], _rows(k)[0], _rows(v)[0], _ptr(out), _rows(out)[0], _ptr(dout), _rows(dout)[0],
                           _ptr(lse), _ptr(delta), _ptr(qs), C_, _ptr(dq), _ptr(dk), _ptr(dv), _rows(dq)[0], _rows(dk)[0], _rows(dv)[0], batch, heads, nq, nk, d,
                           int(causal), _ptr(ws), 0 if ws is None else ws.numel() * 2)

@@ -974,6 +974,40 @@ def test_self_attention_backward_8wave_staggered_passes(rec_cls, monkeypatch, va
         assert rel_l2(got[var][:, sl], got[-1][:, sl]) < 2e-3, name
 
 
+@pytest.mark.parametrize("d,NQ,NK", [(40, 512, 1024), (40, 1536, 512), (80, 256, 768), (80, 512, 256)])
+def test_self_attention_backward_8wave_passes_with_unequal_query_and_key_counts(rec_cls, monkeypatch, d, NQ, NK):
+    """pv_attn8_bwd_eligible accepts nq != nk (the dK/dV pass owns keys and walks the queries, the dQ pass the other way round): both passes against
+    autograd through fp32 SDPA and against the 4-wave kernels at rectangular sizes; a PV_ATTN8_BWD value that names no instantiated form is not
+    eligible and takes the 4-wave kernels (same bits as -1) instead of failing the launch."""
+    B, H = 2, 8
+    C = H * d
+    g = torch.Generator().manual_seed(NQ + NK)
+    q, kv, dout = torch.randn(B * NQ, C, generator=g), torch.randn(B * NK, 2 * C, generator=g), torch.randn(B * NQ, C, generator=g)
+    heads = lambda t, n: t.half().float().view(B, n, H, d).transpose(1, 2).clone().requires_grad_()
+    q32, k32, v32 = heads(q, NQ), heads(kv[:, :C], NK), heads(kv[:, C:], NK)
+    F.scaled_dot_product_attention(q32, k32, v32).backward(dout.half().float().view(B, NQ, H, d).transpose(1, 2))
+    want = [q32.grad.transpose(1, 2).reshape(B * NQ, C), k32.grad.transpose(1, 2).reshape(B * NK, C), v32.grad.transpose(1, 2).reshape(B * NK, C)]
+    xq, xkv, do = q.half().cuda(), kv.half().cuda(), dout.half().cuda()
+    monkeypatch.setenv("PV_ATTN8_BWD_MIN", "1")
+    got = {}
+    for form in (81, -1, 17):
+        monkeypatch.setenv("PV_ATTN8_BWD", str(form))
+        rec = rec_cls("cuda")
+        lse = rec.empty((B, H, NQ), torch.float32)
+        o = rec.attention(xq, xkv[:, :C], xkv[:, C:], batch=B, heads=H, nq=NQ, nk=NK, d=d, lse=lse)
+        dq, dkv = rec.empty((B * NQ, C)), rec.empty((B * NK, 2 * C))
+        dq.fill_(float("nan")); dkv.fill_(float("nan"))
+        rec.attention_backward(xq, xkv[:, :C], xkv[:, C:], o, do, lse, batch=B, heads=H, nq=NQ, nk=NK, d=d, dq=dq, dk=dkv[:, :C], dv=dkv[:, C:])
+        rec.run()
+        torch.cuda.synchronize()
+        got[form] = [dq.float().cpu(), dkv[:, :C].float().cpu(), dkv[:, C:].float().cpu()]
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert torch.isfinite(got[81][i]).all(), name
+        e8, e4 = rel_l2(got[81][i], want[i]), rel_l2(got[-1][i], want[i])
+        assert e8 < 4e-3 and e8 < 1.5 * e4 + 2e-4, (name, e8, e4)
+        assert torch.equal(got[17][i], got[-1][i]), name            # unknown variant: the 4-wave kernels, not an error
+
+
 @pytest.mark.parametrize("B,N,d", [(16, 4096, 40), (4, 4608, 40), (3, 1536, 40), (16, 1024, 80), (5, 2304, 80)])
 def test_self_attention_8wave_kernels_repeat_bit_for_bit_under_load(rec_cls, B, N, d):
     """Race screen for the LDS-DMA rings and the segment schedules of attn8_kernel and attn8_bwd_kernel at the sizes that fill the chip: the kernels

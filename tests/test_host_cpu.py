@@ -81,6 +81,27 @@ def test_cabi_rejects_bad_parameter_blocks_before_touching_the_device(lib):
     rowg = lambda **kw: call(lib.pv_row_gemm, _lib.RowGemmParams, ("x", "w", "out"), dict(ld_x=320, M=4096, K=320, N=960, ln=1, ln_eps=1e-5, geglu=0, ld_out=960), **kw)
     for bad in (dict(K=640, ld_x=640), dict(N=1000, ld_out=1000), dict(ld_out=320), dict(M=0)):                   # K == 320; N % 320 == 0; ld_out >= N
         assert rowg(**bad) == INVALID, bad
+    # the GroupNorm fold (pv_gemm_params.a_norm) exists for 3x3 convs only, with NONE or SILU behind the affine part: a Linear launch carrying it, or
+    # another activation code, is rejected up front instead of running with the fold silently ignored
+    gemm = lambda **kw: call(lib.pv_gemm_conv, _lib.GemmParams, ("a0", "w", "out", "a_norm"),
+                             dict(lda0=640, c0=640, batch=16, hin=64, win=64, hout=64, wout=64, taps=1, stride=1, pad=0, N=320, ldc=320, M=65536,
+                                  a_norm_act=1), **kw)                  # PV_ACT_SILU
+    assert gemm() == INVALID                                                                              # Linear (taps == 1) + a_norm
+    assert gemm(taps=9, pad=1, lda0=320, c0=320, a_norm_act=2) == INVALID    # 3x3 conv + PV_ACT_QUICK_GELU: an activation the fold does not have
+
+
+def test_no_mixed_shape_mfma_chain_in_the_shipped_isa():
+    """A 16x16x16 tail MFMA that hipcc put ONE instruction behind the 16x16x32 whose result it accumulates onto returned wrong sums, differently per
+    run (round 5, EXPERIMENTS.md; root cause not established).  Every kernel that chains the two shapes fences its groups; this scans the ISA hipcc
+    emits today for the two sources that hold such chains (every instantiated variant, the default attn8_kernel<497> and the backward passes included)
+    and requires that no dependent pair of different shapes sits within three instructions of each other.  hipcc cross-compiles: CPU only, ~15 s."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_chain_scan", os.path.join(ROOT, "tools", "diag", "mfma_chain_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    hits, n_mfma = scan.scan(scan.TWO_SHAPE_SOURCES, dist=3)
+    assert n_mfma > 1000, "the scan saw no MFMA instructions: it scanned nothing"
+    assert not hits, "\n".join("%s %s: %s -> %s, %d between (%s) x%d" % (*k[:5], ", ".join(k[5]), v) for k, v in hits.items())
 
 
 def test_struct_layouts_match_header():
