@@ -19,9 +19,18 @@
 // 392-404 us against 483 us for attn_kernel<40, 4, true> on the 64 x 64 level's launch, same box, sustained) + the tile's LDS-DMA issued behind
 // the prefetch reads + per-segment priority (388-390 us where 225 takes 404; +1.0 % of a step over 225, profiles/r05_attn8_ab7*.txt).
 #define PV_ATTN8_DEFAULT 497
-#ifndef PV_ATTN8_LOOP_PAD
-#define PV_ATTN8_LOOP_PAD 3      // -1: no alignment directive
 #endif
+#ifndef PV_ATTN8_FENCE_LOOP
+#define PV_ATTN8_FENCE_LOOP 1      // 0: the round-5 build (fence in the prologue's copy only) - timing A/B of the fence, never shipped
+#endif
+#ifndef PV_ATTN8_MAX3
+// 1: the exponentiate-first reference check reduces the 32 packed fp16 P registers of a tile with gfx950's three-input v_pk_maximum3_f16 (16 instructions on the
+// shared vector issue port instead of 31 v_pk_max_f16); same boolean, same results.  Round 6, same box, sustained: 378.4 -> 368.5 us (-2.6 %) together with
+// the loop re-pinned in the instruction-fetch windows (PV_ATTN8_LOOP_PAD 3 -> 2: the shorter vector segment moved the loop; at pad 3 the launch reads 377.7)
+#define PV_ATTN8_MAX3 1
+#endif
+#ifndef PV_ATTN8_LOOP_PAD
+#define PV_ATTN8_LOOP_PAD 2      // -1: no alignment directive (round 5: 3, before PV_ATTN8_MAX3 shortened the vector segment)
 #endif
 #ifndef PV_ATTN_LAZY_UP
 #define PV_ATTN_LAZY_UP 8.f    // attn_kernel: how far (log2 units) a score may exceed its row's softmax reference before the reference moves; 0 = eager
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
         // step one or two slots behind the 16x16x32 whose result it accumulates onto; in the backward passes (pv_attnbwd.hip, same two-shape chain) that
         // schedule returned wrong sums, non-deterministically, once the wave ran at s_setprio 1.  The fence does not depend on where the scheduler
         // happens to put the loop's copy today; tests/test_host_cpu.py scans the emitted ISA for such chains (tools/diag/mfma_chain_scan.py).
-        if (K48) __builtin_amdgcn_sched_barrier(0);
+        if (K48 && (FIRST || PV_ATTN8_FENCE_LOOP)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             if (K48) {
@@ -589,12 +598,25 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) exp_pack(qi);
                 half2_t m2 = half2_t{(half_t)0.f, (half_t)0.f};
+#if PV_ATTN8_MAX3
+                // gfx950's three-input packed maximum: two of the 32 packed registers per instruction (16 instead of 31 on the shared vector issue port)
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const half2_t a = half2_t{pb[s2][qi][2 * j], pb[s2][qi][2 * j + 1]}, b2 = half2_t{pb[s2][qi][2 * j + 2], pb[s2][qi][2 * j + 3]};
+                            asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m2) : "v"(m2), "v"(a), "v"(b2));
+                        }
+#else
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) m2 = __builtin_elementwise_max(m2, half2_t{pb[s2][qi][2 * j], pb[s2][qi][2 * j + 1]});
+#endif
                 redo = __any(fmaxf((float)m2[0], (float)m2[1]) > 256.f);         // an fp16 overflow (inf) lands here too
             }
             if (redo) {

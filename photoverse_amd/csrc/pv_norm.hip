@@ -363,7 +363,10 @@ extern "C" int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream) {
         return (int)hipErrorInvalidValue;
     if (threads < p->groups) return (int)hipErrorInvalidValue;
     // enough workgroups to fill the chip (>= ~4096 when the tensor allows), at least 8 pixel rows each
-    long ppb = ((long)p->batch * p->hw) / 4096;
+    // PV_GN_WGS (A/B): target workgroup count.  4096 leaves a thread of the 64 x 64 level's launches 2-3 pixel rows - its loop of four loads in flight
+    // never runs; fewer, longer workgroups keep more bytes in flight per CU
+    static const long wg_target = getenv("PV_GN_WGS") ? atol(getenv("PV_GN_WGS")) : 4096;
+    long ppb = ((long)p->batch * p->hw) / wg_target;
     const int px_per_block = (int)(ppb < 8 ? 8 : (ppb > 128 ? 128 : ppb));
     const int gx = (p->hw + px_per_block - 1) / px_per_block;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, p->batch), dim3(threads), 0, (hipStream_t)stream, *p, nchunk, rpp, px_per_block);

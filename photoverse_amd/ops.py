@@ -235,7 +235,10 @@ class Recorder:
         self.keep.extend(t for t in (a, a1, w, bias, rowadd, residual, out, ln_rowsum, a_norm) if t is not None)
         # the symbol rocprofv3 shows for this launch and its workgroup count (4th tag field: bench.py separates the chip-filling launches of the
         # one-per-CU tile from the half-chip ones): asked from the library's own dispatch code, not restated here
-        name, wgs = _kernel_info(self.lib.pv_gemm_conv_kernel_info, p)
+        try:
+            name, wgs = _kernel_info(self.lib.pv_gemm_conv_kernel_info, p)
+        except ValueError:              # a block the library rejects: recorded all the same - run() raises HipLaunchError, as for every other entry point
+            name, wgs = "pv_gemm_conv", 0
         self._add(self.lib.pv_gemm_conv, p, tag=(name, 2.0 * M * N * kdim, 2.0 * (M * (c0 + c1) + N * kdim + M * n_out), wgs))
         return out
 
@@ -352,7 +355,10 @@ class Recorder:
         p = AttnParams(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(out), ldo, batch, heads, nq, nk, d, int(causal), _ptr(lse))
         self.keep.extend(t for t in (q, k, v, out, lse) if t is not None)
         # the symbol rocprofv3 shows for this launch and its workgroup count: pv_attn.hip's own rule (choose_attn), asked from the library
-        name, wgs = _kernel_info(self.lib.pv_attention_kernel_info, p)
+        try:
+            name, wgs = _kernel_info(self.lib.pv_attention_kernel_info, p)
+        except ValueError:              # rejected block: run() raises HipLaunchError
+            name, wgs = "pv_attention", 0
         self._add(self.lib.pv_attention, p, tag=(name, 4.0 * batch * heads * nq * nk * d * (0.5 if causal else 1.0), 2.0 * batch * heads * d * (2 * nq + 2 * nk), wgs))
         return out
 

@@ -74,6 +74,29 @@ def test_headline_schedule_latents_within_north_star_tolerance(full_hip_unet, go
     del loop
 
 
+def test_headline_batch16_plan_latents_within_north_star_tolerance(full_hip_unet, golden_dir):
+    """The same 1e-3 bound on the plan ``bench.py`` times: batch 16, the DEFAULT launch plans (two-stream heads / tails, merged low-resolution plan with its
+    split-K heuristics, 8-wave self-attention, LDS-resident-patch convs, fused attn2), constructed with ``bench.py``'s own arguments.  The oracle's B = 1
+    expectation is a batch member: the fixture's noise and conditioning sit at batch position 5, fifteen other seeded samples around it (samples never
+    interact inside the UNet: ``test_unet_gpu.py`` proves that bit for bit with split-K off; here the headline plan itself meets the fp32 oracle)."""
+    from photoverse_amd.pipeline import DenoiseLoop
+    c, exp = fs.loop_case(), _load(golden_dir, "full_loop.pt")["latents"]
+    B, pos = 16, 5
+    g = torch.Generator().manual_seed(77)
+    fill = lambda ref: torch.cat([torch.randn(B, *ref.shape[1:], generator=g)[:pos], ref, torch.randn(B, *ref.shape[1:], generator=g)[:B - pos - 1]])
+    cond, uncond, noise = tuple(fill(t) for t in c["cond"]), tuple(fill(t) for t in c["uncond"]), fill(c["noise"])
+    loop = DenoiseLoop(full_hip_unet, B, 64, 1, c["steps"], c["guidance"], use_graph=True, two_streams=True, batch_splits=1, share_prefix=False)
+    loop.set_conditioning(tuple(t.cuda() for t in cond), tuple(t.cuda() for t in uncond))
+    loop.reset(noise)
+    got10 = loop.run(10)[pos:pos + 1].clone().cpu()
+    got50 = loop.run(40)[pos:pos + 1].clone().cpu()
+    assert loop.state[0].item() == 50 and torch.isfinite(loop.latents).all()
+    e10, e50 = rel_l2(got10, exp[10]), rel_l2(got50, exp[50])
+    print(f"headline plan (bs = 16) on the 50-step schedule, the oracle's sample at batch position {pos}: after 10 steps {e10:.3e}, after 50 steps {e50:.3e}")
+    assert e10 < 1e-3 and e50 < 1e-3
+    del loop
+
+
 def _pipeline_models(full_hip_unet, full_weights):
     from photoverse_amd.adapters import PhotoVerseAdapter
     from photoverse_amd.clip import CLIPTextModel, CLIPVisionModel, patch_clip_text_transformer
