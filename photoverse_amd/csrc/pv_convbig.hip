@@ -744,12 +744,15 @@ int pv_conv_big_launch(const pv_gemm_params_dev& p, hipStream_t stream) {
         const int bn = p.geglu ? 256 : 320;
         if (p.c1 || splits > 1 || p.out_f32 || cin < 640 || (p.N % bn) || (p.geglu && p.colstats)) return -1;
         if ((long)((p.M + 255) / 256) * (p.N / bn) < min_tiles) {
-            // The 128-row form of the tile (MI = 4: 128 x 320, still one 8-wave workgroup per CU) for Linear launches that reach one workgroup per CU only with
-            // it - the N = 1280 Linear layers of the 16 x 16 level in the merged plan (M = 8192: 64 x 4 = 256 tiles; the 128 x 160 kernel runs them as 512
-            // tiles).  Round 6, same box, sustained, results bit-identical: K = 1280 38.9 -> 38.0 us (35.1 -> 33.5 without residual), K = 5120 115.5 -> 108 us
-            // (profiles/r06_linear128_ab.txt).  PV_GEMM_BIG128=0 keeps the 128 x 160 kernel.  (The same form for 3x3 convs lost in round 4: EXPERIMENTS.md.)
-            static const int b128 = getenv("PV_GEMM_BIG128") ? atoi(getenv("PV_GEMM_BIG128")) : 1;
-            if (b128 && !p.geglu && !p.ln_rowsum && cin >= (b128 > 1 ? b128 : 1280) && (long)((p.M + 127) / 128) * (p.N / bn) >= min_tiles)    // measured at K >= 1280; PV_GEMM_BIG128=<K> lowers the bound
+            // OFF by default (PV_GEMM_BIG128=1 / =<minimum K> enables): the 128-row form of the tile (MI = 4: 128 x 320, still one 8-wave workgroup per CU) for
+            // Linear launches that reach one workgroup per CU only with it - the N = 1280 Linear layers of the 16 x 16 level in the merged plan (M = 8192:
+            // 64 x 4 = 256 tiles; the 128 x 160 kernel runs them as 512 tiles).  Round 6, same box: bit-identical and FASTER alone, sustained (K = 1280
+            // 38.9 -> 38.0 us, K = 5120 115.5 -> 108 us) - and 0.4 % SLOWER in the loop (33.67 vs 33.81 steps/s, three rounds): behind other launches the
+            // one-workgroup-per-CU ring starts cold where the 128 x 160 kernel's second workgroup covers it (profiles/r06_linear128_ab.txt, r06_loop_ab_*.txt)
+            static const int b128 = getenv("PV_GEMM_BIG128") ? atoi(getenv("PV_GEMM_BIG128")) : 0;
+            if (b128 && !p.geglu && !p.ln_rowsum && cin >= (b128 > 1 ? b128 : 1280) && (long)((p.M + 127) / 128) * (p.N / bn) >= (min_tiles > 256 ? min_tiles : 256))
+                // measured at K >= 1280 (PV_GEMM_BIG128=<K> lowers the bound); only where the 128-row tiles fill the whole chip: as a half-chip launch beside
+                // the other CFG branch (min_tiles = 128) the form loses to the 128 x 160 kernel (M = 4096: 31.4 vs 24.9 us)
                 return p.colstats ? launch_big<true, false, 4, 1>(p, stream) : launch_big<false, false, 4, 1>(p, stream);
             return -1;
         }

@@ -363,8 +363,8 @@ extern "C" int pv_groupnorm_apply(const pv_groupnorm_params* p, void* stream) {
         return (int)hipErrorInvalidValue;
     if (threads < p->groups) return (int)hipErrorInvalidValue;
     // enough workgroups to fill the chip (>= ~4096 when the tensor allows), at least 8 pixel rows each
-    // PV_GN_WGS (A/B): target workgroup count.  4096 leaves a thread of the 64 x 64 level's launches 2-3 pixel rows - its loop of four loads in flight
-    // never runs; fewer, longer workgroups keep more bytes in flight per CU
+    // PV_GN_WGS (A/B): target workgroup count.  Round 6, sustained, alone: 4096 / 2048 / 1024 / 512 workgroups read 15.7 / 15.6 / 15.0 / 16.0 us on the
+    // 64 x 64 level's tensor (5.3 - 5.6 TB/s) and 8.6 / 8.7 / 8.6 / 9.7 us on the 16 x 16 level's: nothing to gain (profiles/r06_gn_apply_ab.txt)
     static const long wg_target = getenv("PV_GN_WGS") ? atol(getenv("PV_GN_WGS")) : 4096;
     long ppb = ((long)p->batch * p->hw) / wg_target;
     const int px_per_block = (int)(ppb < 8 ? 8 : (ppb > 128 ? 128 : ppb));

@@ -171,7 +171,10 @@ __device__ __forceinline__ void xf_wait_vmcnt() {
 #ifndef PV_XF_S640
 #define PV_XF_S640 8
 #endif
-constexpr int xf_ring_slots(int C, int NQ) { return C == 640 && NQ == 1 ? PV_XF_S640 : 4; }
+#ifndef PV_XF_S640_NQ2
+#define PV_XF_S640_NQ2 4           // the 128-row form at C = 640 is one workgroup per CU too (390 VGPRs): 8 = all of the CU's LDS for its two rings (A/B switch)
+#endif
+constexpr int xf_ring_slots(int C, int NQ) { return C == 640 ? (NQ == 1 ? PV_XF_S640 : PV_XF_S640_NQ2) : 4; }
 
 // wave-uniform count -> immediate
 __device__ __forceinline__ void xf_wait_vmcnt_dyn(int n) {
@@ -400,6 +403,8 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
         iinit[r] = g * 4 + r < p.nip ? 0.f : -INFINITY;
     }
     const half4_t ip1p = half4_t{g == 0 ? (half_t)w_ip : (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    float4_t zero4 = float4_t{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(zero4));            // one register quad for the whole phase (a literal would be re-materialised per chain)
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
         // group grp landed; in flight behind it: group grp+1 (grp < 3); at grp == 3 additionally the three Wo stages issued after group 2
@@ -416,8 +421,6 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             constexpr int NKB = IP1 ? 5 : 6;
             float4_t s[NKB][NQ];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) { const float4_t v0 = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = v0; }
-#pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
                 half8_t bq[NQ];
 #pragma unroll
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
                 for (int kb = 0; kb < NKB; ++kb) {
                     const half8_t a = ld_frag256(sK, kb * 16 + fr, ks * 4 + g);
 #pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi)
+                        s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], ks == 0 ? (kb == 4 ? tinit : kb == 5 ? iinit : zero4) : s[kb][qi], 0, 0, 0);
                 }
             }
             half8_t pb[3][NQ];
@@ -479,14 +483,12 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             }
             float4_t o[5][NQ];
 #pragma unroll
-            for (int fi = 0; fi < 5; ++fi) { const float4_t v0 = float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = v0; }
-#pragma unroll
             for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
                 for (int fi = 0; fi < 5; ++fi) {
                     const half8_t a = vt_frag80(sV, s2 * 32, fi * 16, fr, g);
 #pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[fi][qi], 0, 0, 0);
+                    for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], s2 == 0 ? zero4 : o[fi][qi], 0, 0, 0);
                 }
 #pragma unroll
             for (int fi = 0; fi < 5; ++fi)
@@ -505,8 +507,6 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
                 constexpr int NKB = IP1 ? 5 : 6;   // score fragments: 5 of text keys (+ 1 of image-token keys)
                 float4_t s[NKB][NQ];
     #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) { const float4_t v0 = kb == 4 ? tinit : kb == 5 ? iinit : float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = v0; }
-    #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     half8_t bq[NQ];
     #pragma unroll
@@ -514,8 +514,11 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
     #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {
                         const half8_t a = ld_frag128(sK, kb * 16 + fr, ks * 4 + g);
+                        // a chain's first step reads its initial value (zero / the padding masks) as the C operand from loop-invariant registers: no
+                        // accumulator-initialising v_mov (a tenth of the kernel's vector instructions were those)
     #pragma unroll
-                        for (int qi = 0; qi < NQ; ++qi) s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], s[kb][qi], 0, 0, 0);
+                        for (int qi = 0; qi < NQ; ++qi)
+                            s[kb][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[qi], ks == 0 ? (kb == 4 ? tinit : kb == 5 ? iinit : zero4) : s[kb][qi], 0, 0, 0);
                     }
                 }
                 // two independent softmaxes over the key axis (registers r, fragments kb, and the 4 lane groups).  Text keys are
@@ -571,14 +574,12 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
                 // O^T = V^T . P^T for this head's three fragments of the group's 80 value columns
                 float4_t o[3][NQ];
     #pragma unroll
-                for (int fi = 0; fi < 3; ++fi) { const float4_t v0 = float4_t{0.f, 0.f, 0.f, 0.f}; for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = v0; }
-    #pragma unroll
                 for (int s2 = 0; s2 < 3; ++s2)
     #pragma unroll
                     for (int fi = 0; fi < 3; ++fi) {
                         const half8_t a = vt_frag80(sV, s2 * 32, (hh == 0 ? fi : fi + 2) * 16, fr, g);
     #pragma unroll
-                        for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], o[fi][qi], 0, 0, 0);
+                        for (int qi = 0; qi < NQ; ++qi) o[fi][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[s2][qi], s2 == 0 ? zero4 : o[fi][qi], 0, 0, 0);
                     }
     #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
@@ -764,7 +765,9 @@ extern "C" int pv_cross_attention_fused(const pv_xattn_fused_params* pp, void* s
               : variant == 1 ? (ip1 ? xattn_fused_kernel<640, true, 2> : xattn_fused_kernel<640, false, 2>)
                              : (ip1 ? xattn_fused_kernel<640, true, 1> : xattn_fused_kernel<640, false, 1>);
     // two buffers of one weight ring (or one 39-KiB K/V group) each: 2 x 40 KiB = two workgroups per CU; the 64-row form 2 x 80 KiB = the whole CU
-    const int SMEM = 2 * xf_ring_slots(C, rows == 64 ? 1 : 2) * GF * 128;
+    // PV_XF_LDS_PAD (diagnostics): extra dynamic LDS bytes per workgroup - 4096 leaves room for ONE 128-row workgroup per CU instead of two (occupancy probe)
+    static const int lds_pad = getenv("PV_XF_LDS_PAD") ? atoi(getenv("PV_XF_LDS_PAD")) : 0;
+    const int SMEM = 2 * xf_ring_slots(C, rows == 64 ? 1 : 2) * GF * 128 + (rows == 128 ? lds_pad : 0);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return (int)e;
