@@ -11,7 +11,7 @@ import os
 from .build import LIB
 
 #: diagnostics only (tools/ab_lib_bench.sh: same-box A/B of two builds of the library): another build of the SAME sources' library, never a fallback
-LIB = os.environ.get("PV_HIP_LIB", LIB)
+LIB = os.environ.get("PV_HIP_LIB") or LIB
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 

@@ -168,6 +168,11 @@ __device__ __forceinline__ void xf_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef PV_XF_SPAN
+// 1: the C = 320 form runs its weight rings over both 40-KiB buffers (8 slots, three pairs of stages in flight; xattn_fused_kernel, SPAN).  Round 6, same box,
+// sustained: 53.9 -> 51.1 us at B = 16 / N = 4096 (P = 5: 54.2 -> 52.5), level in the loop; results unchanged (profiles/r06_xfused_span.txt)
+#define PV_XF_SPAN 1
+#endif
 #ifndef PV_XF_S640
 #define PV_XF_S640 8
 #endif
@@ -211,14 +216,20 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
     // ring slots: two stages being read + 2 LEAD in flight (one workgroup barrier per PAIR of stages).  The 64-row form has ONE workgroup per CU
     // (256 workgroups) and all of the CU's LDS: a deeper ring keeps three pairs of stages in flight instead of one - with one pair the weight
     // stream of a lone workgroup is bound by the L2 round trip, not by its MFMAs
-    constexpr int S = xf_ring_slots(C, NQ);
+    // SPAN (C = 320, PV_XF_SPAN): the two-workgroups-per-CU form keeps its 80 KiB but runs each weight ring over BOTH buffers - eight slots, three pairs of
+    // stages in flight instead of one.  Round 6 (profiles/r06_xfused_occupancy.txt): a workgroup ALONE on its CU takes 35 us for its 128 rows where its
+    // resource floors sum to ~22 us, and a second co-resident workgroup adds only 17 us: the weight phases wait for the L2 round trip of the one pair of
+    // stages in flight, as the C = 640 form did before its 8-slot ring.  The K / V group that used to wait in buffer 1 through phase 1 is fetched when the
+    // last Wq stages have left that half (t = 16); the Wo ring starts in buffer 1 under the last group and takes buffer 0 over at the phase boundary.
+    constexpr bool SPAN = C == 320 && NQ == 2 && PV_XF_SPAN != 0;
+    constexpr int S = SPAN ? 8 : xf_ring_slots(C, NQ);
     constexpr int LEAD = S / 2 - 1;   // pairs of stages in flight behind the pair being read
     constexpr int TILE_BYTES = GF * 128;                   // one stage: 80 weight rows x 64 k = 10 KiB
     constexpr int KIMG_BYTES = XK * KROW;                  // one head
     constexpr int VIMG_BYTES = XK * GF * 2;
     constexpr int GROUP_BYTES = 2 * KIMG_BYTES + VIMG_BYTES;   // K images of the group's two heads + V image: 39 KiB
     constexpr int GROUP_PIECES = GROUP_BYTES / 1024;
-    constexpr int BUF_BYTES = S * TILE_BYTES;              // 40 KiB
+    constexpr int BUF_BYTES = (SPAN ? 4 : S) * TILE_BYTES;     // 40 KiB
     static_assert(GROUP_BYTES % 1024 == 0 && GROUP_BYTES <= BUF_BYTES, "LDS plan: a K/V group fits inside one ring buffer");
     // LDS: two 40-KiB buffers.  Buffer 0 = Wq ring (phase 1), K/V of groups 1 and 3; buffer 1 = K/V of groups 0 and 2, Wo ring (phase 3).
     // 80 KiB per workgroup -> TWO independent workgroups per CU (each other's barrier / DMA / HBM waits are covered, as in the GEMM).
@@ -252,9 +263,11 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
     unsigned piece_off[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) piece_off[i] = w_lane_off + (unsigned)((wave + 4 * i) * 8) * (unsigned)(C * 2);
-    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rw, char* ring, int t) {
+    // ring slot of stage t: phase 1 (Wq) counts from buffer 0, phase 3 (Wo) from buffer 1; SPAN: slots 4-7 lie in the other buffer
+    auto slot1 = [&](int t) -> char* { return buf0 + (t % S) * TILE_BYTES; };                        // buffers are adjacent: slot s at smem + s * 10 KiB
+    auto slot3 = [&](int t) -> char* { const int sl = t % S; return SPAN && sl >= 4 ? buf0 + (sl - 4) * TILE_BYTES : buf1 + sl * TILE_BYTES; };
+    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rw, char* dst, int t) {
         const int nc = t / KT, kt = t % KT;
-        char* dst = ring + (t % S) * TILE_BYTES;
         const int soff = nc * GF * (C * 2) + kt * 128;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) xf[kk][qi] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rh, off, kk * 64, 0));
     }
-    issue_group(0, buf1);                 // K/V of group 0 waits in buffer 1 while the Wq ring runs in buffer 0
+    if (!SPAN) issue_group(0, buf1);      // K/V of group 0 waits in buffer 1 while the Wq ring runs in buffer 0 (SPAN: fetched at t = 16)
 #pragma unroll
-    for (int t = 0; t < 2 * LEAD; ++t) issue_stage(rq, buf0, t);
+    for (int t = 0; t < 2 * LEAD; ++t) issue_stage(rq, slot1(t), t);
     if (p.ln) {
         // LayerNorm WITHOUT its affine part (the caller folds gamma into the columns of wq and beta into q_bias):
         // x^ = x * rstd - mean * rstd, one mixed-precision FMA per element (fp16 in, fp32 math, fp16 out).  Statistics: the row sum
@@ -361,14 +374,17 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             if ((t & 1) == 0) {
                 // ONE barrier per pair of stages: stages t and t+1 were issued two stages ago right behind that barrier and nothing younger
                 // is in flight, so "landed" is vmcnt(0); behind the barrier the slots of stages t-2 / t-1 are read out by every wave
-                if (t >= 2) wait_except(min(2 * (LEAD - 1), max(NT - (t + 2), 0)), 0);     // stages t, t+1 landed; younger pairs may be in flight
+                // stages t, t+1 landed; younger pairs may be in flight (SPAN: and, from t = 18 on, K / V group 0, issued behind the last stages)
+                if (t >= 2) wait_except(min(2 * (LEAD - 1), max(NT - (t + 2), 0)), SPAN && t >= NT - 2 ? 1 : 0);
                 wg_barrier();
-                if (t + 2 * LEAD < NT) issue_stage(rq, buf0, t + 2 * LEAD);
-                if (t + 2 * LEAD + 1 < NT) issue_stage(rq, buf0, t + 2 * LEAD + 1);
+                if (t + 2 * LEAD < NT) issue_stage(rq, slot1(t + 2 * LEAD), t + 2 * LEAD);
+                if (t + 2 * LEAD + 1 < NT) issue_stage(rq, slot1(t + 2 * LEAD + 1), t + 2 * LEAD + 1);
+                // SPAN: behind this barrier every wave has read stages <= 15 out of slots 4-7 (buffer 1), and no later stage goes there
+                if (SPAN && t == NT - 4) issue_group(0, buf1);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const char* base = buf0 + (t % S) * TILE_BYTES + ring_lane[ks];
+                const char* base = slot1(t) + ring_lane[ks];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const half8_t a = *reinterpret_cast<const half8_t*>(base + i * 2048);
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
         // group grp landed; in flight behind it: group grp+1 (grp < 3); at grp == 3 additionally the three Wo stages issued after group 2
         if (grp == 0) wait_except(0, 1);
         else if (grp < NG - 1) { wait_except(0, 1); }
-        else wait_except(2 * LEAD, 0);
+        else wait_except(SPAN ? 4 : 2 * LEAD, 0);
         wg_barrier();
         const char* sbuf = ((grp + 1) & 1) ? buf1 : buf0;
         const half_t* sV = reinterpret_cast<const half_t*>(sbuf + 2 * KIMG_BYTES);
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
         } else if (grp == NG - 2) {
             wg_barrier();                  // buffer 1 (group 2) is free: the Wo ring starts there while group 3 computes out of buffer 0
 #pragma unroll
-            for (int t = 0; t < 2 * LEAD; ++t) issue_stage(ro, buf1, t);
+            for (int t = 0; t < (SPAN ? 4 : 2 * LEAD); ++t) issue_stage(ro, slot3(t), t);     // SPAN: slots 4-7 (buffer 0) follow at the phase boundary
         }
     }
 
@@ -648,8 +664,12 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
                 if (t >= 2) xf_wait_vmcnt_dyn(younger);
                 else xf_wait_vmcnt<0>();
                 wg_barrier();
-                if (t + 2 * LEAD < NT) issue_stage(ro, buf1, t + 2 * LEAD);
-                if (t + 2 * LEAD + 1 < NT) issue_stage(ro, buf1, t + 2 * LEAD + 1);
+                if (SPAN && t == 0) {          // buffer 0 (the last K / V group) is free now: the ring's other half
+                    issue_stage(ro, slot3(4), 4);
+                    issue_stage(ro, slot3(5), 5);
+                }
+                if (t + 2 * LEAD < NT) issue_stage(ro, slot3(t + 2 * LEAD), t + 2 * LEAD);
+                if (t + 2 * LEAD + 1 < NT) issue_stage(ro, slot3(t + 2 * LEAD + 1), t + 2 * LEAD + 1);
             }
             if (kt == 0) {
                 // chunk start: accumulators start from the output bias; the residual rows are requested now and consumed five stages later
@@ -666,7 +686,7 @@ __global__ __launch_bounds__(256, (C == 320 || NQ == 1) ? 2 : 1) void xattn_fuse
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const char* base = buf1 + (t % S) * TILE_BYTES + ring_lane[ks];
+                const char* base = slot3(t) + ring_lane[ks];
                 half8_t bc[NQ];
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) bc[qi] = cat4(cf[2 * (2 * kt + ks)][qi], cf[2 * (2 * kt + ks) + 1][qi]);

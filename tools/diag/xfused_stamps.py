@@ -23,7 +23,7 @@ def stamped_source():
     s = s.replace('#include "pv_common.h"', '#include "%s"\n__device__ unsigned long long xf_stamps[16];\n'
                   '#define STAMP(i) do { if (blockIdx.x == 100 && threadIdx.x == 0) xf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)'
                   % os.path.join(b.CSRC, "pv_common.h"))
-    marks = ["    half8_t xf[KK][NQ];\n    int mrow[NQ];", "    issue_group(0, buf1);", "    // The register loads above made the compiler wait;",
+    marks = ["    half8_t xf[KK][NQ];\n    int mrow[NQ];", "    if (!SPAN) issue_group(0, buf1);", "    // The register loads above made the compiler wait;",
              "    // ---- phase 1: Q^T = Wq", "    // ---- phase 2: dual-branch attention, one", "    // ---- phase 3: out^T = Wo'"]
     for i, m in enumerate(marks):
         assert m in s, m
@@ -39,10 +39,12 @@ src = "/tmp/pv_xfused_stamps.hip"
 open(src, "w").write(stamped_source())
 lib = "/tmp/libpv_diag.so"
 objs = []
-for s in b.SOURCES:
-    path = src if s == "pv_xfused.hip" else os.path.join(b.CSRC, s)
-    o = f"/tmp/diag_{s}.o"
-    subprocess.check_call([b._hipcc(), *b.FLAGS, *b.EXTRA_FLAGS.get(s, []), "-I", b.CSRC, "-c", path, "-o", o])
+for s in b.SOURCES:       # the other sources: the in-tree objects (they travel with the snapshot)
+    if s == "pv_xfused.hip":
+        o = "/tmp/diag_pv_xfused.o"
+        subprocess.check_call([b._hipcc(), *b.FLAGS, *b.EXTRA_FLAGS.get(s, []), "-I", b.CSRC, "-c", src, "-o", o], stderr=subprocess.DEVNULL)
+    else:
+        o = os.path.join(b.LIBDIR, s.replace(".hip", ".o"))
     objs.append(o)
 subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
 from photoverse_amd import _lib  # noqa: E402
