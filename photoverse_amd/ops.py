@@ -28,7 +28,6 @@ SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "4"))      # same-box sweep (b
 SPLITK_TARGET = int(_os.environ.get("PV_SPLITK_TARGET", "512"))
 #: K slices of a 3x3 conv that reaches one 256 x 320 tile per CU only with split-K (16 x 16 level: 64 tiles); 0 / 1 = keep the 128-row kernel there
 BIG_SPLITK = int(_os.environ.get("PV_CONV_BIG_SPLITK", "4"))
-BIG_SPLITK8 = int(_os.environ.get("PV_CONV_BIG_SPLITK8", "0"))
 
 
 class HipLaunchError(RuntimeError):
@@ -208,10 +207,6 @@ class Recorder:
         if (big_shape and auto_splitk and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
                 and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
             splitk = BIG_SPLITK
-        elif (big_shape and auto_splitk and BIG_SPLITK8 and tiles256 * 4 < big_min <= tiles256 * 8 and (kdim // 64) // 8 >= 16):
-            # EXPERIMENT (PV_CONV_BIG_SPLITK8=1): the merged plan's 8 x 8 convs (batch 2B: 32 tiles of 256 x 320) as 8 K-slices on the one-per-CU tile instead
-            # of 128 tiles x 4 slices of the 128-row kernel
-            splitk = 8
         elif (big_shape and auto_splitk and self.big_split2 and 2 <= SPLITK_MAX and tiles256 < big_min <= tiles256 * 2 and (kdim // 64) // 2 >= 16):
             # the merged low-resolution plan's 16 x 16 convs (batch 2B: 128 tiles): two K-slices on the one-per-CU tile instead of 512 unsplit
             # 128-row workgroups: +0.35 % of a step same-box; the same rule on plans that do not run alone (training, --one-stream) loses 0.4 %
