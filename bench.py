@@ -23,7 +23,7 @@ UNET_TFLOP_PER_SAMPLE_64 = 0.8040
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 #: committed PMC summary `roofline.traffic` is read from (tools/profile_bench.py writes it together with the git blob hashes of the
 #: kernel sources it was measured on; bench.py reports `traffic_stale` when those differ from the sources in the tree)
-PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r06_pmc_traffic.json"
 KERNEL_SOURCES = ("photoverse_amd/csrc/pv_gemm.hip", "photoverse_amd/csrc/pv_convbig.hip", "photoverse_amd/csrc/pv_attn.hip")
 
 
