@@ -29,8 +29,18 @@
 // the loop re-pinned in the instruction-fetch windows (PV_ATTN8_LOOP_PAD 3 -> 2: the shorter vector segment moved the loop; at pad 3 the launch reads 377.7)
 #define PV_ATTN8_MAX3 1
 #endif
+#ifndef PV_ATTN8_RECOMPUTE
+// 1: a wave that finds a score above its reference computes the tile's scores AGAIN in its vector segment instead of keeping the 64 score registers alive across
+// the check (attn8_kernel, PCHECK path).  On the common path the scores die at their exponential and the packed P takes their registers: 254 -> 204 VGPRs, and the
+// eight 64-bit + sixteen 32-bit register copies hipcc had put on the common path are gone.  Round 6, same box: alone 371 -> 377 us (SLOWER: the common path now ends
+// in a taken branch), in the loop 33.00 -> 33.11 steps/s at loop pad 4 (+0.3 %, three rounds; profiles/r06_attn8_recompute.txt): the loop decides.
+#define PV_ATTN8_RECOMPUTE 1
+#endif
+#ifndef PV_ATTN8_REDO_HINT
+#define PV_ATTN8_REDO_HINT 0      // 1: the 'a score exceeded the reference' branch carries an unlikely hint (A/B switch)
+#endif
 #ifndef PV_ATTN8_LOOP_PAD
-#define PV_ATTN8_LOOP_PAD 2      // -1: no alignment directive (round 5: 3, before PV_ATTN8_MAX3 shortened the vector segment)
+#define PV_ATTN8_LOOP_PAD 4      // -1: no alignment directive (round 5: 3; round 6: 2 with PV_ATTN8_MAX3, 4 with PV_ATTN8_RECOMPUTE - best of the loop A/B)
 #endif
 #ifndef PV_ATTN_LAZY_UP
 #define PV_ATTN_LAZY_UP 8.f    // attn_kernel: how far (log2 units) a score may exceed its row's softmax reference before the reference moves; 0 = eager
@@ -582,16 +592,17 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
                 pb[s2][qi][r + 4] = (half_t)PV_EXP2(s[2 * s2 + 1][qi][r]);
             }
     };
+    auto mask_tail = [&](int t) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t * KB + kb * 16 + fq * 4 + r >= p.nk) s[kb][qi][r] = -INFINITY;
+    };
     auto softmax = [&](int t, const bool MASKED, const bool FIRST) {
-        if (MASKED) {
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t * KB + kb * 16 + fq * 4 + r >= p.nk) s[kb][qi][r] = -INFINITY;
-        }
+        if (MASKED) mask_tail(t);
         if (PCHECK) {
             bool redo = FIRST;
             if (!FIRST) {
@@ -619,7 +630,19 @@ __global__ __launch_bounds__(512, 2) void attn8_kernel(const pv_attn_params p) {
 #endif
                 redo = __any(fmaxf((float)m2[0], (float)m2[1]) > 256.f);         // an fp16 overflow (inf) lands here too
             }
+#if PV_ATTN8_REDO_HINT
+            if (__builtin_expect(redo, 0)) {
+#else
             if (redo) {
+#endif
+#if PV_ATTN8_RECOMPUTE
+                // the rare path computes the tile's scores AGAIN (its K fragments are still in slot t & 3, the reference has not moved yet) instead of
+                // keeping 64 score registers alive across the check: on the common path they die at their exponential and the packed P takes their place
+                if (PREF && K48) {
+                    qk(t, FIRST);
+                    if (MASKED) mask_tail(t);
+                }
+#endif
                 float mx[NQ];
                 row_max(mx);
 #pragma unroll
