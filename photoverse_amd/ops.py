@@ -28,6 +28,8 @@ SPLITK_MAX = int(_os.environ.get("PV_SPLITK_MAX", "4"))      # same-box sweep (b
 SPLITK_TARGET = int(_os.environ.get("PV_SPLITK_TARGET", "512"))
 #: K slices of a 3x3 conv that reaches one 256 x 320 tile per CU only with split-K (16 x 16 level: 64 tiles); 0 / 1 = keep the 128-row kernel there
 BIG_SPLITK = int(_os.environ.get("PV_CONV_BIG_SPLITK", "4"))
+#: choose the slice count of such a conv by wave quantisation (rounds of workgroups x K-steps per slice) instead of always BIG_SPLITK; 0 = the round-5 rule
+QUANT_SPLITK = _os.environ.get("PV_QUANT_SPLITK", "1") != "0"
 
 
 class HipLaunchError(RuntimeError):
@@ -206,7 +208,11 @@ class Recorder:
         tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
         if (big_shape and auto_splitk and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
                 and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
-            splitk = BIG_SPLITK
+            # ... and of the slice counts that do, the one with the fewest (rounds of workgroups) x (K-steps per slice): at 72 tiles (configs[4]'s per-rank
+            # shape, 24 x 24 level of the merged plan) 4 slices are 288 workgroups = two rounds of 45 stages, 3 slices 216 = ONE round of 60
+            nk = kdim // 32
+            cands = [k for k in range(2, BIG_SPLITK + 1) if (kdim // 64) // k >= 16 and tiles256 * k * 5 >= big_min * 4]
+            splitk = min(cands, key=lambda k: (-(-tiles256 * k // big_min) * -(-nk // k), k)) if (cands and QUANT_SPLITK) else BIG_SPLITK
         elif (big_shape and auto_splitk and self.big_split2 and 2 <= SPLITK_MAX and tiles256 < big_min <= tiles256 * 2 and (kdim // 64) // 2 >= 16):
             # the merged low-resolution plan's 16 x 16 convs (batch 2B: 128 tiles): two K-slices on the one-per-CU tile instead of 512 unsplit
             # 128-row workgroups: +0.35 % of a step same-box; the same rule on plans that do not run alone (training, --one-stream) loses 0.4 %
@@ -622,6 +628,8 @@ class Recorder:
         p = XAttnFusedParams(_ptr(hs), _rows(hs)[0], int(ln_gamma is not None), float(ln_eps), _ptr(wq), _ptr(q_bias), _ptr(wo_packed), _ptr(bias_o),
                              _ptr(kimg), _ptr(vimg), _ptr(out), _rows(out)[0], batch, nq, heads, d, nt, nip, float(w_text), float(w_ip),
                              _ptr(fusion), 128 if (C == 640 and 0 < self.big_min <= 128) else 0)   # half-chip launches when the plan runs beside its CFG twin
+        # (also where 128-row workgroups do NOT fill that half: configs[4]'s per-rank shape has 72 of them per launch and is still 0.7 % of a step faster
+        #  with them than with 144 64-row workgroups, which stream the weights twice per row: profiles/r06_loop_ab_cfg4_splitk.txt)
         self.keep.extend(t for t in (hs, wq, q_bias, wo_packed, bias_o, kimg, vimg, fusion, out) if t is not None)
         M = batch * nq
         flops = 4.0 * M * C * C + 4.0 * M * (nt + nip) * C           # to_q + to_out + both SDPA products (dense-counted)

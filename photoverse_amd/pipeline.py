@@ -19,6 +19,10 @@ from .ops import Recorder, require_cuda
 from .scheduler import DPMSolverMultistepScheduler
 
 
+#: 256-row-tile threshold of plans that run beside their CFG twin (each fills half of the chip); PV_SIDE_BIG_MIN overrides it for A/Bs
+_SIDE_BIG_MIN = int(os.environ.get("PV_SIDE_BIG_MIN", "128"))
+
+
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
@@ -99,7 +103,7 @@ class DenoiseLoop:
             mid_out = torch.empty((2 * batch * n_out, c_out), dtype=f16, device=dev)
             mid_out_cs = torch.zeros((2 * batch * n_out // 64, 2, c_out), dtype=f32, device=dev)
             kw = dict(timesteps=self.timesteps, state=self.state, n_text=n_text, split=split)
-            side_by_side = dict(big_min=128) if two_streams else {}      # heads / tails of the two branches run concurrently: half the chip each
+            side_by_side = dict(big_min=_SIDE_BIG_MIN) if two_streams else {}      # heads / tails of the two branches run concurrently: half the chip each
             for i, (text, ip, eps, lst) in enumerate(((self.text_u, self.ip_u, self.eps_u, self.engines_u), (self.text_c, self.ip_c, self.eps_c, self.engines_c))):
                 half_in = (mid_in[i * batch * n_in:(i + 1) * batch * n_in], mid_in_cs[i * batch * n_in // 64:(i + 1) * batch * n_in // 64])
                 half_out = (mid_out[i * batch * n_out:(i + 1) * batch * n_out], mid_out_cs[i * batch * n_out // 64:(i + 1) * batch * n_out // 64])
@@ -111,7 +115,7 @@ class DenoiseLoop:
             sl = slice(i * sb, (i + 1) * sb)
             kw = dict(timesteps=self.timesteps, state=self.state, latents_in=self.latents[sl], n_text=n_text, **pre_kw)
             if two_streams and batch_splits == 1:
-                kw.update(big_min=128)                    # the two whole forwards run side by side
+                kw.update(big_min=_SIDE_BIG_MIN)                    # the two whole forwards run side by side
             if training_mode:
                 kw.update(device_fusion="last_step")
             fs = dict(fusion_seed=fusion_seed * 4096 + 2 * i) if training_mode else {}
