@@ -201,11 +201,12 @@ class Recorder:
         tiles = ((M + 127) // 128) * (N // bn)
         auto_splitk = splitk is None
         splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
-        if auto_splitk and QUANT_SPLITK2 and splitk == SPLITK_MAX and tiles * splitk * 4 < SPLITK_TARGET * 3:
+        if auto_splitk and QUANT_SPLITK2 and splitk > 1 and splitk == SPLITK_MAX and tiles * splitk * 4 < SPLITK_TARGET * 3:      # never where split-K is off (SPLITK_MAX = 1)
             # the cap, not the chip, stopped the split (configs[4]'s per-rank shape: 72 tiles of the 12 x 12 level x 4 slices = 288 of 512 workgroup
             # slots): more slices while they still fit ONE round, fewest (K-steps per slice + a slab term)
             cands = [k for k in range(splitk, 9) if (kdim // 64) // k >= 16 and tiles * k <= SPLITK_TARGET]
-            splitk = min(cands, key=lambda k: (-(-(kdim // 64) // k) + 2 * k, k))
+            if cands:
+                splitk = min(cands, key=lambda k: (-(-(kdim // 64) // k) + 2 * k, k))
         # pv_convbig.hip's 256 x 320 tile on the 16 x 16 level: 64 tiles x BIG_SPLITK K-slices = one workgroup per CU (the 128-row kernel runs
         # these convs as 256 tiles x 2 slices)
         big_min = self.big_min
