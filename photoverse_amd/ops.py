@@ -33,6 +33,43 @@ QUANT_SPLITK = _os.environ.get("PV_QUANT_SPLITK", "1") != "0"
 QUANT_SPLITK2 = _os.environ.get("PV_QUANT_SPLITK2", "1") != "0"      # the same idea for the 128-row kernel's slice count: +0.85 % at configs[4]'s per-rank shape, level at the headline
 
 
+def choose_splitk(M: int, N: int, kdim: int, *, geglu: bool = False, splitk=None, conv_geo=None, big_min: int = 256, big_split2: bool = False) -> int:
+    """K-slices of a ``Recorder.gemm`` launch (pure host logic; ``splitk``: the caller's choice, None = automatic, 0 = off).  ``conv_geo`` =
+    (batch, hin, win, hout, wout, stride, upsample, pad) of a 3x3 conv, None for a Linear layer.
+
+    Automatic rule: split the layers whose 128-row tiles cannot fill the chip (8 x 8 / 16 x 16 levels of the UNet) until about SPLITK_TARGET workgroups
+    exist, at most SPLITK_MAX ways (SPLITK_MAX = 1 turns every automatic split off); 3x3 convs that reach one 256 x 320 tile per CU only with split-K take
+    the one-per-CU tile with the slice count wave quantisation prefers."""
+    auto = splitk is None
+    bn = 128 if (geglu or N % 160) else 160
+    tiles = ((M + 127) // 128) * (N // bn)
+    splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
+    if auto and QUANT_SPLITK2 and splitk > 1 and splitk == SPLITK_MAX and tiles * splitk * 4 < SPLITK_TARGET * 3:      # never where split-K is off (SPLITK_MAX = 1)
+        # the cap, not the chip, stopped the split (configs[4]'s per-rank shape: 72 tiles of the 12 x 12 level x 4 slices = 288 of 512 workgroup
+        # slots): more slices while they still fit ONE round, fewest (K-steps per slice + a slab term)
+        cands = [k for k in range(splitk, 9) if (kdim // 64) // k >= 16 and tiles * k <= SPLITK_TARGET]
+        if cands:
+            splitk = min(cands, key=lambda k: (-(-(kdim // 64) // k) + 2 * k, k))
+    # pv_convbig.hip's 256 x 320 tile on the 16 x 16 level: 64 tiles x BIG_SPLITK K-slices = one workgroup per CU (the 128-row kernel runs
+    # these convs as 256 tiles x 2 slices)
+    geo = conv_geo
+    up = 2 if (geo is not None and geo[6]) else 1
+    big_shape = (geo is not None and big_min > 0 and geo[5] == 1 and geo[7] == 1 and (geo[1] * up, geo[2] * up) == tuple(geo[3:5]) and N % 320 == 0)
+    tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
+    if (big_shape and auto and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
+            and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
+        # ... and of the slice counts that do, the one with the fewest (rounds of workgroups) x (K-steps per slice): at 72 tiles (configs[4]'s per-rank
+        # shape, 24 x 24 level of the merged plan) 4 slices are 288 workgroups = two rounds of 45 stages, 3 slices 216 = ONE round of 60
+        nk = kdim // 32
+        cands = [k for k in range(2, BIG_SPLITK + 1) if (kdim // 64) // k >= 16 and tiles256 * k * 5 >= big_min * 4]
+        splitk = min(cands, key=lambda k: (-(-tiles256 * k // big_min) * -(-nk // k), k)) if (cands and QUANT_SPLITK) else BIG_SPLITK
+    elif (big_shape and auto and big_split2 and 2 <= SPLITK_MAX and tiles256 < big_min <= tiles256 * 2 and (kdim // 64) // 2 >= 16):
+        # the merged low-resolution plan's 16 x 16 convs (batch 2B: 128 tiles): two K-slices on the one-per-CU tile instead of 512 unsplit
+        # 128-row workgroups: +0.35 % of a step same-box; the same rule on plans that do not run alone (training, --one-stream) loses 0.4 %
+        splitk = 2
+    return splitk
+
+
 class HipLaunchError(RuntimeError):
     pass
 
@@ -195,35 +232,9 @@ class Recorder:
         if residual is not None:
             ldr, rc = _rows(residual)
             assert rc == n_out and residual.shape[0] == M
-        # split-K for layers whose 128-row tiles cannot fill the 256 CUs (8x8 / 16x16 levels of the UNet)
         kdim = taps * (c0 + c1)
-        bn = 128 if (geglu or N % 160) else 160
-        tiles = ((M + 127) // 128) * (N // bn)
-        auto_splitk = splitk is None
-        splitk = 1 if (geglu or splitk == 0) else (splitk or max(1, min(SPLITK_MAX, SPLITK_TARGET // tiles, (kdim // 64) // 16)))
-        if auto_splitk and QUANT_SPLITK2 and splitk > 1 and splitk == SPLITK_MAX and tiles * splitk * 4 < SPLITK_TARGET * 3:      # never where split-K is off (SPLITK_MAX = 1)
-            # the cap, not the chip, stopped the split (configs[4]'s per-rank shape: 72 tiles of the 12 x 12 level x 4 slices = 288 of 512 workgroup
-            # slots): more slices while they still fit ONE round, fewest (K-steps per slice + a slab term)
-            cands = [k for k in range(splitk, 9) if (kdim // 64) // k >= 16 and tiles * k <= SPLITK_TARGET]
-            if cands:
-                splitk = min(cands, key=lambda k: (-(-(kdim // 64) // k) + 2 * k, k))
-        # pv_convbig.hip's 256 x 320 tile on the 16 x 16 level: 64 tiles x BIG_SPLITK K-slices = one workgroup per CU (the 128-row kernel runs
-        # these convs as 256 tiles x 2 slices)
         big_min = self.big_min
-        up = 2 if (conv is not None and geo[6]) else 1
-        big_shape = (conv is not None and big_min > 0 and geo[5] == 1 and geo[7] == 1 and (geo[1] * up, geo[2] * up) == geo[3:5] and N % 320 == 0)
-        tiles256 = ((M + 255) // 256) * (N // 320) if big_shape else 0
-        if (big_shape and auto_splitk and 1 < BIG_SPLITK <= SPLITK_MAX and tiles256 * (BIG_SPLITK // 2) < big_min <= tiles256 * BIG_SPLITK
-                and (kdim // 64) // BIG_SPLITK >= 16):     # only where it takes ALL the slices to fill the chip (32 x 32 level, 128 tiles: measured slower)
-            # ... and of the slice counts that do, the one with the fewest (rounds of workgroups) x (K-steps per slice): at 72 tiles (configs[4]'s per-rank
-            # shape, 24 x 24 level of the merged plan) 4 slices are 288 workgroups = two rounds of 45 stages, 3 slices 216 = ONE round of 60
-            nk = kdim // 32
-            cands = [k for k in range(2, BIG_SPLITK + 1) if (kdim // 64) // k >= 16 and tiles256 * k * 5 >= big_min * 4]
-            splitk = min(cands, key=lambda k: (-(-tiles256 * k // big_min) * -(-nk // k), k)) if (cands and QUANT_SPLITK) else BIG_SPLITK
-        elif (big_shape and auto_splitk and self.big_split2 and 2 <= SPLITK_MAX and tiles256 < big_min <= tiles256 * 2 and (kdim // 64) // 2 >= 16):
-            # the merged low-resolution plan's 16 x 16 convs (batch 2B: 128 tiles): two K-slices on the one-per-CU tile instead of 512 unsplit
-            # 128-row workgroups: +0.35 % of a step same-box; the same rule on plans that do not run alone (training, --one-stream) loses 0.4 %
-            splitk = 2
+        splitk = choose_splitk(M, N, kdim, geglu=geglu, splitk=splitk, conv_geo=geo if conv is not None else None, big_min=big_min, big_split2=self.big_split2)
         ws = self.empty((splitk, M, N), torch.float32) if splitk > 1 else None
         cs = None
         key = (out.data_ptr(), M, n_out)

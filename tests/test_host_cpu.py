@@ -104,6 +104,36 @@ def test_no_mixed_shape_mfma_chain_in_the_shipped_isa():
     assert not hits, "\n".join("%s %s: %s -> %s, %d between (%s) x%d" % (*k[:5], ", ".join(k[5]), v) for k, v in hits.items())
 
 
+def test_splitk_choice_by_wave_quantisation(monkeypatch):
+    """``ops.choose_splitk`` (pure host logic): the headline's shapes keep the slice counts of round 5; configs[4]'s per-rank shape gets the counts wave
+    quantisation prefers (72 one-per-CU tiles x 3 slices = ONE round of workgroups instead of x 4 = two; 72 tiles of the 128-row kernel x 7 slices = 504 of
+    512 workgroup slots instead of x 4 = 288); SPLITK_MAX = 1 (the batch-invariance tests) turns every automatic split off; the caller's choice wins."""
+    from photoverse_amd import ops
+    conv = lambda b, s: (b, s, s, s, s, 1, 0, 1)
+    K9 = 9 * 1280
+    # headline (bs = 16): merged plan at batch 32
+    assert ops.choose_splitk(32 * 256, 1280, K9, conv_geo=conv(32, 16), big_min=256, big_split2=True) == 2      # 16 x 16 convs: 128 tiles x 2
+    assert ops.choose_splitk(32 * 64, 1280, K9, conv_geo=conv(32, 8), big_min=256, big_split2=True) == 4        # 8 x 8 convs: 128 tiles of the 128-row kernel x 4 = 512 slots
+    assert ops.choose_splitk(16 * 4096, 320, 9 * 320, conv_geo=conv(16, 64), big_min=128) == 1                  # chip-filling convs: no split
+    assert ops.choose_splitk(32 * 64, 1280, 1280) == 1                                                           # short-K Linear: no split
+    # configs[4] per-rank shape (bs = 4): merged plan at batch 8
+    assert ops.choose_splitk(8 * 576, 1280, K9, conv_geo=conv(8, 24), big_min=256, big_split2=True) == 3        # 72 one-per-CU tiles: 216 workgroups, one round
+    assert ops.choose_splitk(8 * 144, 1280, K9, conv_geo=conv(8, 12), big_min=256, big_split2=True) == 7        # 72 tiles x 7 = 504 of 512 slots
+    monkeypatch.setattr(ops, "QUANT_SPLITK", False)
+    monkeypatch.setattr(ops, "QUANT_SPLITK2", False)
+    assert ops.choose_splitk(8 * 576, 1280, K9, conv_geo=conv(8, 24), big_min=256, big_split2=True) == 4        # the round-5 rule
+    assert ops.choose_splitk(8 * 144, 1280, K9, conv_geo=conv(8, 12), big_min=256, big_split2=True) == 4
+    monkeypatch.setattr(ops, "QUANT_SPLITK", True)
+    monkeypatch.setattr(ops, "QUANT_SPLITK2", True)
+    # the caller's choice, and split-K off
+    assert ops.choose_splitk(8 * 144, 1280, K9, splitk=0, conv_geo=conv(8, 12)) == 1 and ops.choose_splitk(8 * 144, 1280, K9, splitk=3, conv_geo=conv(8, 12)) == 3
+    assert ops.choose_splitk(4096, 5120, 640, geglu=True) == 1
+    monkeypatch.setattr(ops, "SPLITK_MAX", 1)
+    for M, s in ((32 * 256, 16), (32 * 64, 8), (8 * 576, 24), (8 * 144, 12), (2 * 64, 8), (64, 8)):
+        assert ops.choose_splitk(M, 1280, K9, conv_geo=conv(M // (s * s), s), big_min=256, big_split2=True) == 1, (M, s)
+        assert ops.choose_splitk(M, 1280, 64, conv_geo=None) == 1
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors of the parameter structs: field names and order equal the header's."""
     from photoverse_amd import _lib
