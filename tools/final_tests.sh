@@ -1,0 +1,5 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/round
+python -m pytest tests -q -m gpu --durations=25 > gpurun_out/round/final_tests.txt 2>&1
+tail -3 gpurun_out/round/final_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
