@@ -104,6 +104,48 @@ def test_no_mixed_shape_mfma_chain_in_the_shipped_isa():
     assert not hits, "\n".join("%s %s: %s -> %s, %d between (%s) x%d" % (*k[:5], ", ".join(k[5]), v) for k, v in hits.items())
 
 
+def test_kernel_info_names_the_launch_without_a_gpu(lib):
+    """ABI 17: ``pv_gemm_conv_kernel_info`` / ``pv_attention_kernel_info`` answer from the launchers' own validation + dispatch code in describe-only mode - no
+    HIP call, so the headline's dispatch decisions are pinned here on the CPU: 64 x 64 convs on the LDS-resident-patch instantiation of the one-per-CU
+    tile, half-chip launches only with the side-by-side threshold, short-K Linear layers and the 8 x 8 convs (split-K) on the 128-row kernel, GEGLU on the
+    256-column tile, d = 40 self-attention on the 8-wave kernel from one workgroup per CU on; and a rejected block is rejected by the query too."""
+    from photoverse_amd import _lib
+    FAKE = 0x1000
+
+    def gemm(**kw):
+        p = _lib.GemmParams()
+        for k in ("a0", "w", "out"):
+            setattr(p, k, FAKE)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return _lib.kernel_info(lib.pv_gemm_conv_kernel_info, p)
+
+    conv = lambda B, s, cin, cout, **kw: gemm(c0=cin, lda0=cin, N=cout, ldc=cout, M=B * s * s, taps=9, batch=B, hin=s, win=s, hout=s, wout=s, stride=1, pad=1, **kw)
+    lin = lambda M, K, N, **kw: gemm(c0=K, lda0=K, N=N, ldc=kw.pop("ldc", N), M=M, taps=1, batch=1, hin=1, win=1, hout=M, wout=1, stride=1, pad=1, **kw)
+    assert conv(16, 64, 320, 320, colstats=FAKE) == ("big_tile_kernel<true, false, 8, 3, false>", 256)
+    assert conv(16, 32, 640, 640, colstats=FAKE) == ("gemm_conv_kernel<5, true, false, true, false, 4>", 512)          # 128 tiles of 256 rows: below the default threshold
+    assert conv(16, 32, 640, 640, colstats=FAKE, big_tile_min=128) == ("big_tile_kernel<true, false, 8, 0, false>", 128)   # beside the CFG twin: half the chip
+    assert conv(32, 16, 1280, 1280, splitk=2, splitk_ws=FAKE, big_tile_min=256) == ("big_tile_kernel<false, false, 8, 0, false>", 256)
+    assert conv(32, 8, 1280, 1280, splitk=4, splitk_ws=FAKE) == ("gemm_conv_kernel<5, true, false, false, false, 4>", 512)
+    assert lin(65536, 320, 320) == ("gemm_conv_kernel<5, false, false, false, false, 4>", 1024)
+    assert lin(65536, 1280, 320) == ("big_tile_kernel<false, false, 8, 1, false>", 256)
+    assert lin(8192, 1280, 1280) == ("gemm_conv_kernel<5, false, false, false, false, 4>", 512)                       # PV_GEMM_BIG128 (off): 128 x 320 tiles
+    assert lin(16384, 640, 5120, geglu=1, ldc=2560) == ("big_tile_kernel<false, false, 8, 2, false>", 1280)
+    assert lin(1232, 768, 640) == ("gemm_conv_kernel<5, false, false, false, false, 2>", 80)                           # 64-row tiles for small launches
+    with pytest.raises(ValueError):
+        lin(65536, 300, 320)                                                                                           # K % 64
+
+    def attn(B, n, d, **kw):
+        a = _lib.AttnParams(q=FAKE, k=FAKE, v=FAKE, out=FAKE, ldq=24 * d, ldk=24 * d, ldv=24 * d, ldo=8 * d, batch=B, heads=8, nq=n, nk=n, d=d, **kw)
+        return _lib.kernel_info(lib.pv_attention_kernel_info, a)
+    assert attn(16, 4096, 40) == ("attn8_kernel<497>", 1024) and attn(4, 9216, 40) == ("attn8_kernel<497>", 576)
+    assert attn(1, 4096, 40) == ("attn_kernel<40, 2, true>", 256)                                                      # 64 512-query workgroups: below one per CU
+    assert attn(16, 4096, 40, causal=1)[0] == "attn_kernel<40, 4, true>"
+    assert attn(16, 1024, 80) == ("attn_kernel<80, 2, false>", 1024) and attn(32, 256, 160) == ("attn_kernel<160, 2, false>", 512)
+    with pytest.raises(ValueError):
+        attn(16, 1024, 48)
+
+
 def test_splitk_choice_by_wave_quantisation(monkeypatch):
     """``ops.choose_splitk`` (pure host logic): the headline's shapes keep the slice counts of round 5; configs[4]'s per-rank shape gets the counts wave
     quantisation prefers (72 one-per-CU tiles x 3 slices = ONE round of workgroups instead of x 4 = two; 72 tiles of the 128-row kernel x 7 slices = 504 of
