@@ -23,6 +23,10 @@ from .scheduler import DPMSolverMultistepScheduler
 _SIDE_BIG_MIN = int(os.environ.get("PV_SIDE_BIG_MIN", "128"))
 
 
+#: rows (batch 2B x pixels of the first merged level) from which the low-resolution levels of the two CFG forwards run as ONE merged plan
+_MERGE_MIN_ROWS = int(os.environ.get("PV_MERGE_MIN_ROWS", "8192"))
+
+
 class DenoiseLoop:
     def __init__(self, unet, batch: int, latent_size: int, n_ip: int, num_steps: int, guidance_scale: float,
                  scheduler: Optional[DPMSolverMultistepScheduler] = None, n_text: int = 77, use_graph: bool = True,
@@ -33,7 +37,7 @@ class DenoiseLoop:
         the captured step (``pv_fusion_draw`` keyed on the step counter), so the same graph serves all steps.  This is the forward semantics
         of that mode; the differentiated last step lives in ``train.TrainStep(face_loss=...)``.
 
-        ``merge_lowres`` (default: env ``PV_MERGE_LOWRES``, on): the two CFG forwards (infer.py:103-114) run their two highest-resolution levels
+        ``merge_lowres`` (default: on from 8192 rows at the first merged level; env ``PV_MERGE_LOWRES`` forces it): the two CFG forwards (infer.py:103-114) run their two highest-resolution levels
         as two parallel graph branches, but everything below (16 x 16 and 8 x 8 levels, mid block) as ONE plan over both branches' samples:
         at M = B * 256 / B * 64 rows a single branch cannot fill the chip without split-K (fp32 slabs + a reduce launch per conv) and both
         branches stream the same 29.5 MB of weights per conv.  Samples never interact inside the UNet, so the result per sample is unchanged.
@@ -83,10 +87,14 @@ class DenoiseLoop:
             self.engines_p.append(unet.engine(batch, latent_size, latent_size, n_ip, 1, latents_in=self.latents, segment="prefix", timesteps=self.timesteps,
                                               state=self.state, n_text=n_text))
             pre_kw = dict(prefix=self.engines_p[0].prefix_out)
-        if merge_lowres is None:
-            merge_lowres = os.environ.get("PV_MERGE_LOWRES", "1") != "0"
         n_lv = len(cfg.block_out_channels)
         split = int(os.environ.get("PV_MERGE_SPLIT", "2"))     # resolution levels that stay in the per-branch plans (A/B switch; 3 = only 8 x 8 + mid merged)
+        if merge_lowres is None:
+            # default: merge where the merged plan, which runs ALONE on the chip, can fill it - from 8192 rows at its first level (batch 2B) on: the headline
+            # (2 x 16 x 256 rows) merges (+ round 4); configs[4]'s per-rank shape (2 x 4 x 576 = 4608 rows) is 4.8 % of a step faster with its two
+            # low-resolution plans side by side on the two streams (round 6, profiles/r06_loop_ab_cfg4_env.txt).  PV_MERGE_LOWRES=1 / 0 forces it.
+            env = os.environ.get("PV_MERGE_LOWRES")
+            merge_lowres = (env != "0") if env is not None else (2 * batch * (latent_size >> split) ** 2 >= _MERGE_MIN_ROWS)
         self.merge_lowres = bool(merge_lowres and not training_mode and batch_splits == 1 and n_lv > split
                                  and ((latent_size >> split) ** 2) % 64 == 0 and latent_size % (1 << (n_lv - 1)) == 0)
         if self.merge_lowres:
