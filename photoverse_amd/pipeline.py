@@ -94,7 +94,9 @@ class DenoiseLoop:
             # (2 x 16 x 256 rows) merges (+ round 4); configs[4]'s per-rank shape (2 x 4 x 576 = 4608 rows) is 4.8 % of a step faster with its two
             # low-resolution plans side by side on the two streams (round 6, profiles/r06_loop_ab_cfg4_env.txt).  PV_MERGE_LOWRES=1 / 0 forces it.
             env = os.environ.get("PV_MERGE_LOWRES")
-            merge_lowres = (env != "0") if env is not None else (2 * batch * (latent_size >> split) ** 2 >= _MERGE_MIN_ROWS)
+            rows = 2 * batch * (latent_size >> split) ** 2
+            # (... and at the launch-bound end, up to 1024 rows - bs = 1 / 2 at 64 x 64 latents - the merged plan's fewer launches win again: +1.0 % / +0.4 %)
+            merge_lowres = (env != "0") if env is not None else (rows >= _MERGE_MIN_ROWS or rows <= 1024)
         self.merge_lowres = bool(merge_lowres and not training_mode and batch_splits == 1 and n_lv > split
                                  and ((latent_size >> split) ** 2) % 64 == 0 and latent_size % (1 << (n_lv - 1)) == 0)
         if self.merge_lowres:
